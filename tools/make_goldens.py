@@ -1,0 +1,100 @@
+"""Generate tests/golden/*.npz by RUNNING THE REFERENCE (imported from /root/reference, see
+tools/ref_loader.py) on the synthetic checkpoint of radzero_amd/weights.py.
+
+Run in the build container only:  python tools/make_goldens.py
+Fixtures hold seeds + small inputs + expected outputs (data, not source).  SURVEY.md §8(c) G1..G7.
+"""
+from __future__ import annotations
+
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+
+from radzero_amd.config import RadZeroConfig  # noqa: E402
+from radzero_amd.synthetic import synthetic_pixels, synthetic_prompts  # noqa: E402
+from radzero_amd.weights import make_state_dict, state_dict_digest  # noqa: E402
+from ref_loader import load_reference_model  # noqa: E402
+
+OUT = os.path.join(ROOT, "tests", "golden")
+STAGE_TOKENS = np.array([0, 1, 2, 17, 100, 255, 256])        # token rows kept for per-stage goldens
+
+
+def run_case(model, name, side, batch, n_prompts, min_len, max_len, px_seed, txt_seed, meta, stages=False):
+    px = synthetic_pixels(batch, side, px_seed)
+    ids, mask = synthetic_prompts(n_prompts, min_len, max_len, txt_seed)
+    enc = {"input_ids": torch.from_numpy(ids), "attention_mask": torch.from_numpy(mask)}
+    t0 = time.time()
+    with torch.no_grad():
+        out = model.compute_logits(torch.from_numpy(px), [enc])
+        rec = dict(
+            side=side, batch=batch, n_prompts=n_prompts, min_len=min_len, max_len=max_len,
+            px_seed=px_seed, txt_seed=txt_seed, input_ids=ids, attention_mask=mask,
+            logits=out["logits"].numpy(), similarity_scores=out["similarity_scores"].numpy(),
+            t2i_logits=out["t2i_logits"].numpy(), scores_with_cls=out["t2i_attn_weights"][0].numpy(),
+            **meta)
+        if stages:
+            # G4: per-stage intermediates (token subset) straight from the reference modules
+            vm = model.vision_model
+            h = vm.embeddings(torch.from_numpy(px))
+            rec["stage_embeddings"] = h[:, STAGE_TOKENS].numpy()
+            for i, layer in enumerate(vm.encoder.layer):
+                h = layer(h)
+                if i in (0, 5, 11):
+                    rec[f"stage_vit_layer_{i}"] = h[:, STAGE_TOKENS].numpy()
+            h = vm.layernorm(h)
+            rec["stage_vit_final_ln"] = h[:, STAGE_TOKENS].numpy()
+            for i, layer in enumerate(model.align_transformer.transformer_layers.layer):
+                h = layer(h)
+                rec[f"stage_align_layer_{i}"] = h[:, STAGE_TOKENS].numpy()
+            rec["stage_tokens"] = STAGE_TOKENS
+            rec["vision_tokens_full_img0"] = h[0].numpy()
+            vo = model.forward_vision_model(torch.from_numpy(px))
+            assert torch.equal(vo["vision_tokens"], h)
+            rec["image_features"] = vo["image_features"].numpy()
+            # text side: per-row (reference semantics: rows split, pads kept) and batched
+            feats = [model.forward_text_model({"input_ids": enc["input_ids"][i:i + 1],
+                                               "attention_mask": enc["attention_mask"][i:i + 1]})
+                     ["text_features_wo_l2_norm"] for i in range(n_prompts)]
+            rec["text_features_wo_l2_norm"] = torch.cat(feats).numpy()
+            rec["text_features_batched"] = model.forward_text_model(enc)["text_features_wo_l2_norm"].numpy()
+            rec["text_last_hidden_row0"] = model.text_model(input_ids=enc["input_ids"][:1],
+                                                            attention_mask=enc["attention_mask"][:1])[0][0].numpy()
+    np.savez_compressed(os.path.join(OUT, f"{name}.npz"), **rec)
+    print(f"{name}: {time.time() - t0:.1f}s logits{tuple(out['logits'].shape)} "
+          f"scores{tuple(out['similarity_scores'].shape)} "
+          f"range[{float(out['similarity_scores'].min()):.3f},{float(out['similarity_scores'].max()):.3f}]", flush=True)
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    torch.set_num_threads(8)
+    cfg = RadZeroConfig()
+    seed = 20260103
+    sd = make_state_dict(cfg, seed)
+    meta = dict(weights_seed=seed, weights_digest=state_dict_digest(sd),
+                torch_version=torch.__version__, attn_implementation="eager")
+    model = load_reference_model(cfg, sd, attn_implementation="eager")
+    # G1 plumbing (BASELINE cfg1): 224^2, B=1, T=1 -> degenerate 0-d logits
+    run_case(model, "g1_s224_b1_t1", 224, 1, 1, 7, 7, 1234, 4321, meta)
+    # G2 shape semantics + G4 stages + G5 padding
+    run_case(model, "g2_s224_b2_t3", 224, 2, 3, 5, 12, 1235, 4322, meta, stages=True)
+    run_case(model, "g2_s224_b1_t14", 224, 1, 14, 6, 10, 1236, 4323, meta)
+    run_case(model, "g2_s224_b3_t1", 224, 3, 1, 9, 9, 1237, 4324, meta)
+    # G3 non-trivial grids (pos-embed interpolation, tail tiles): 266 -> g=19, 518 -> g=37
+    run_case(model, "g3_s266_b2_t3", 266, 2, 3, 6, 10, 1238, 4325, meta)
+    run_case(model, "g3_s518_b1_t14", 518, 1, 14, 6, 10, 1239, 4326, meta)
+    # long prompts (L=32) and many prompts, small image
+    run_case(model, "g5_s224_b1_t64_l32", 224, 1, 64, 8, 32, 1240, 4327, meta)
+    # G7 north-star shape: 1024^2, one image, 14 prompts (outputs only)
+    run_case(model, "g7_s1024_b1_t14", 1024, 1, 14, 6, 10, 1241, 4328, meta)
+
+
+if __name__ == "__main__":
+    main()
