@@ -1,0 +1,132 @@
+/* radzero_hip.h — C-ABI of libradzero_hip.so: MI355X (gfx950) implementation of RadZero's VL-CABS
+ * zero-shot inference hot path.
+ *
+ * The reference (deepnoid-ai/RadZero) has NO native/FFI layer: its boundary is the Python method
+ * protocol of `CxrAlignModel` (exp/cxr_pt/model/modeling.py).  Each entry point below names the
+ * reference interface it replaces; INTEGRATION.md shows the ctypes binding a reference maintainer
+ * would add.  Conventions:
+ *   - plain pointers and sizes only (no torch types); every *_dev pointer is device memory owned by the
+ *     caller (e.g. a torch tensor's data_ptr()); every *_host pointer is host memory;
+ *   - every function returns 0 on success, otherwise an rz_status / hipError_t code; the message of the
+ *     last failure on the calling thread is available from rz_last_error();
+ *   - `stream` is a hipStream_t passed as void* (torch.cuda.current_stream().cuda_stream); calls are
+ *     asynchronous on that stream; a handle is not re-entrant (one handle per GPU / process);
+ *   - the library allocates only packed weights + workspaces (rz_load_weight / rz_reserve), never in
+ *     the forward calls (hipGraph-capturable).
+ */
+#ifndef RADZERO_HIP_H
+#define RADZERO_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct rz_model* rz_handle_t;
+
+enum rz_dtype { RZ_F32 = 0, RZ_BF16 = 1, RZ_F16 = 2 };
+
+enum rz_status {
+    RZ_OK = 0,
+    RZ_ERR_INVALID = 10001,      /* bad argument / shape (reference raises ValueError) */
+    RZ_ERR_STATE = 10002,        /* weights / workspace / position table not ready */
+    RZ_ERR_UNSUPPORTED = 10003,  /* reference raises NotImplementedError (modeling.py:108, :206) */
+    RZ_ERR_NOMEM = 10004
+};
+
+/* Hyper-parameters.  Field names follow exp/cxr_pt/configs/radzero.yaml:16-46,
+ * exp/cxr_pt/model/configuration.py:91-104 and the HF Dinov2Config / MPNetConfig the reference builds. */
+typedef struct rz_config {
+    int32_t compute_dtype;            /* rz_dtype of MFMA operands; statistics/residual/VL-CABS stay fp32 */
+    int32_t hidden_size;              /* 768 */
+    int32_t num_attention_heads;      /* 12 */
+    int32_t mlp_ratio;                /* 4 */
+    int32_t patch_size;               /* 14 */
+    int32_t num_channels;             /* 3 */
+    int32_t vit_layers;               /* 12: transformers Dinov2Model (vision_encoders.py:28-29) */
+    int32_t align_layers;             /* 2:  AlignTransformer (align_transformers.py:23-45), no final LN */
+    float vit_layer_norm_eps;         /* 1e-6 */
+    int32_t vocab_size;               /* 30527 */
+    int32_t max_position_embeddings;  /* 514 */
+    int32_t text_layers;              /* 12: MPNetModel (text_encoders.py:13-14) */
+    int32_t text_intermediate_size;   /* 3072 */
+    float text_layer_norm_eps;        /* 1e-5 */
+    int32_t pad_token_id;             /* 1 */
+    float shared_layer_norm_eps;      /* 1e-5: RadZeroLoss.layer_norm (losses.py:51) */
+} rz_config;
+
+const char* rz_last_error(void);
+const char* rz_version(void);
+
+/* ---- lifecycle: replaces CxrAlignModel.__init__ + from_pretrained (modeling.py:51-94, README.md:77-82) ---- */
+int rz_create(const rz_config* cfg, rz_handle_t* out);
+int rz_destroy(rz_handle_t h);
+
+/* One tensor of the checkpoint, by its state_dict name (modeling.py:55-86; e.g.
+ * "vision_model.encoder.layer.3.mlp.fc1.weight", "align_transformer.transformer_layers.layer.0.norm1.bias",
+ * "text_model.encoder.layer.0.attention.attn.q.weight", "loss_fns.RadZeroLoss.loss_temperature").
+ * fp32 host data; packed / cast / fused (q scale 1/sqrt(dh) folded) on upload.  Unknown names that the path
+ * does not use (mask_token, pooler) are accepted and ignored (returns 0). */
+int rz_load_weight(rz_handle_t h, const char* name, const float* data_host, int64_t numel);
+/* 0 when every tensor the path needs has been loaded; otherwise RZ_ERR_STATE and rz_last_error() names one. */
+int rz_weights_ready(rz_handle_t h);
+
+/* Position table for one patch grid: pos_host is (1 + grid_h*grid_w, hidden) fp32, the output of
+ * Dinov2Embeddings.interpolate_pos_encoding (bicubic, once per resolution, host side). */
+int rz_set_position_table(rz_handle_t h, int grid_h, int grid_w, const float* pos_host);
+
+/* Workspace for up to max_batch images of max_tokens (= 1 + grid_h*grid_w) tokens, max_prompts prompts of
+ * max_prompt_len tokens.  Re-callable (grows only). */
+int rz_reserve(rz_handle_t h, int max_batch, int max_tokens, int max_prompts, int max_prompt_len);
+
+/* ---- CxrAlignModel.forward_vision_model (modeling.py:96-123): Dinov2Model + AlignTransformer ----
+ * pixel_values_dev: fp32 (batch, channels, height, width).  The aligned tokens stay inside the handle
+ * (input of rz_vlcabs); vision_tokens_out_dev, if not NULL, receives them as fp32 (batch, N, hidden). */
+int rz_vision_forward(rz_handle_t h, const float* pixel_values_dev, int batch, int channels, int height, int width,
+                      float* vision_tokens_out_dev, void* stream);
+
+/* ---- CxrAlignModel.forward_text_model, MPNet branch (modeling.py:128-156): encoder + masked mean pool ----
+ * input_ids_dev / attention_mask_dev: int64 (n_prompts, len).  rel_bias_dev: fp32 (heads, len, len) =
+ * relative_attention_bias[bucket(j - i)] (MPNetEncoder.compute_position_bias, computed once by the host).
+ * text_features_out_dev: fp32 (n_prompts, hidden) = "text_features_wo_l2_norm". */
+int rz_text_forward(rz_handle_t h, const int64_t* input_ids_dev, const int64_t* attention_mask_dev, int n_prompts,
+                    int len, const float* rel_bias_dev, float* text_features_out_dev, void* stream);
+
+/* ---- RadZeroLoss.forward(compute_loss=False) + SimilarityLogit + final scaling
+ *      (losses.py:71-105, :187-240; modeling.py:311-328) on the tokens of the last rz_vision_forward ----
+ * text_features_dev: fp32 (n_prompts, hidden), pre-LayerNorm.
+ * scores_out_dev: fp32 (batch, n_prompts, N) = "t2i_attn_weights"[0] (cosine / tau, CLS column included;
+ *                 similarity_scores is its [:, :, 1:] view).
+ * t2i_logits_out_dev: fp32 (n_prompts, batch).  logits_out_dev: fp32 (batch, n_prompts) = t2i^T / tau. */
+int rz_vlcabs(rz_handle_t h, const float* text_features_dev, int n_prompts, int batch, float* scores_out_dev,
+              float* t2i_logits_out_dev, float* logits_out_dev, void* stream);
+
+/* ---- interpolate_similarity_scores, BlipImageProcessor branch (inference/segmentation_utils.py:62-70)
+ *      (+ torch.sigmoid of attention_map_base.py:57 when apply_sigmoid != 0) ----
+ * maps_dev: n_maps maps of grid*grid fp32, consecutive maps map_stride floats apart; out_dev (n_maps, H, W). */
+int rz_upsample_maps(rz_handle_t h, const float* maps_dev, int64_t map_stride, int n_maps, int grid, int out_h, int out_w,
+                     int apply_sigmoid, float* out_dev, void* stream);
+
+/* ---- per-kernel entry points (used by the parity tests; all pointers device) ---- */
+/* C = A[M,K] W[N,K]^T + bias; dtype of A/W/out = rz_dtype; epilogue: 0 store, 1 GELU(erf), 7 store fp32 */
+int rz_gemm(int dtype, int epilogue, const void* a_dev, const void* w_dev, const float* bias_dev, void* out_dev, int m,
+            int n, int k, void* stream);
+/* LayerNorm rows of `dim` (=768) fp32 -> out_t_dev (dtype, may be NULL) and/or out_f32_dev (may alias in) */
+int rz_layernorm(int dtype, const float* in_dev, const float* gamma_dev, const float* beta_dev, float eps, void* out_t_dev,
+                 float* out_f32_dev, int64_t rows, int dim, void* stream);
+/* softmax(q k^T) v, heads of 64: q,k (B,H,n_pad,64), v_t (B,H,64,n_pad), ctx (B*n_pad, H*64); no scaling inside */
+int rz_flash_attention(int dtype, const void* q_dev, const void* k_dev, const void* v_t_dev, void* ctx_dev, int batch,
+                       int heads, int n_valid, int n_pad, void* stream);
+
+/* ---- measurement: HIP-event timing of kernel families on the launch stream ---- */
+enum rz_prof_family { RZ_PROF_ATTN = 0, RZ_PROF_GEMM = 1, RZ_PROF_ROWOPS = 2, RZ_PROF_VLCABS = 3, RZ_PROF_NFAM = 4 };
+int rz_profile_enable(rz_handle_t h, int enable);
+/* after a stream synchronize: total milliseconds and launch count per family since enable; resets them */
+int rz_profile_read(rz_handle_t h, float* ms_per_family, int64_t* launches_per_family);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RADZERO_HIP_H */

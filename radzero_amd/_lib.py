@@ -1,0 +1,130 @@
+"""Build + load libradzero_hip.so (the C-ABI of include/radzero_hip.h) through ctypes.
+
+There is NO fallback: if the library is missing or fails to load, importing the product path raises.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+PKG_DIR = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(PKG_DIR, "csrc")
+LIB_PATH = os.path.join(PKG_DIR, "libradzero_hip.so")
+SOURCES = ["gemm.hip", "attention.hip", "rowops.hip", "vlcabs.hip", "api.hip"]
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+ARCH = "gfx950"
+
+RZ_F32, RZ_BF16, RZ_F16 = 0, 1, 2
+PROF_FAMILIES = ("attn", "gemm", "rowops", "vlcabs")
+
+
+def _needs_rebuild() -> bool:
+    if not os.path.exists(LIB_PATH):
+        return True
+    t = os.path.getmtime(LIB_PATH)
+    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(PKG_DIR, "..", "include", "radzero_hip.h")]
+    return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    """hipcc --offload-arch=gfx950 every source, link in-tree (the .so travels with the repo snapshot)."""
+    if not force and not _needs_rebuild():
+        return LIB_PATH
+    if not os.path.exists(HIPCC):
+        raise RuntimeError(f"hipcc not found at {HIPCC}; cannot build libradzero_hip.so")
+    obj_dir = os.path.join(PKG_DIR, "build")
+    os.makedirs(obj_dir, exist_ok=True)
+    flags = [f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
+
+    def cc(src):
+        obj = os.path.join(obj_dir, src.replace(".hip", ".o"))
+        cmd = [HIPCC, *flags, "-c", os.path.join(CSRC, src), "-o", obj]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"hipcc failed for {src}:\n{r.stderr}")
+        if verbose and r.stderr:
+            print(r.stderr, file=sys.stderr)
+        return obj
+
+    with ThreadPoolExecutor(max_workers=min(5, os.cpu_count() or 1)) as ex:
+        objs = list(ex.map(cc, SOURCES))
+    r = subprocess.run([HIPCC, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", LIB_PATH, *objs],
+                       capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f"link failed:\n{r.stderr}")
+    return LIB_PATH
+
+
+class RzConfig(ctypes.Structure):
+    _fields_ = [
+        ("compute_dtype", ctypes.c_int32), ("hidden_size", ctypes.c_int32), ("num_attention_heads", ctypes.c_int32),
+        ("mlp_ratio", ctypes.c_int32), ("patch_size", ctypes.c_int32), ("num_channels", ctypes.c_int32),
+        ("vit_layers", ctypes.c_int32), ("align_layers", ctypes.c_int32), ("vit_layer_norm_eps", ctypes.c_float),
+        ("vocab_size", ctypes.c_int32), ("max_position_embeddings", ctypes.c_int32), ("text_layers", ctypes.c_int32),
+        ("text_intermediate_size", ctypes.c_int32), ("text_layer_norm_eps", ctypes.c_float),
+        ("pad_token_id", ctypes.c_int32), ("shared_layer_norm_eps", ctypes.c_float),
+    ]
+
+
+# every symbol include/radzero_hip.h declares: name -> (restype, argtypes)
+_P, _I, _L, _F = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_float
+SYMBOLS = {
+    "rz_last_error": (ctypes.c_char_p, []),
+    "rz_version": (ctypes.c_char_p, []),
+    "rz_create": (_I, [ctypes.POINTER(RzConfig), ctypes.POINTER(_P)]),
+    "rz_destroy": (_I, [_P]),
+    "rz_load_weight": (_I, [_P, ctypes.c_char_p, _P, _L]),
+    "rz_weights_ready": (_I, [_P]),
+    "rz_set_position_table": (_I, [_P, _I, _I, _P]),
+    "rz_reserve": (_I, [_P, _I, _I, _I, _I]),
+    "rz_vision_forward": (_I, [_P, _P, _I, _I, _I, _I, _P, _P]),
+    "rz_text_forward": (_I, [_P, _P, _P, _I, _I, _P, _P, _P]),
+    "rz_vlcabs": (_I, [_P, _P, _I, _I, _P, _P, _P, _P]),
+    "rz_upsample_maps": (_I, [_P, _P, _L, _I, _I, _I, _I, _I, _P, _P]),
+    "rz_gemm": (_I, [_I, _I, _P, _P, _P, _P, _I, _I, _I, _P]),
+    "rz_layernorm": (_I, [_I, _P, _P, _P, _F, _P, _P, _L, _I, _P]),
+    "rz_flash_attention": (_I, [_I, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "rz_profile_enable": (_I, [_P, _I]),
+    "rz_profile_read": (_I, [_P, _P, _P]),
+}
+
+_lib = None
+
+
+def load(auto_build: bool = True) -> ctypes.CDLL:
+    """Load the shared library (building it first if the sources are newer and hipcc is present)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if auto_build and os.path.exists(HIPCC):
+        build()
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'`. "
+            "radzero_amd has no CPU / PyTorch fallback.")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SYMBOLS.items():
+        fn = getattr(lib, name)           # AttributeError if the library does not export it
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+class RzError(RuntimeError):
+    pass
+
+
+def check(rc: int, what: str = ""):
+    """Map C-ABI status codes to the exceptions the reference raises."""
+    if rc == 0:
+        return
+    msg = load().rz_last_error().decode(errors="replace")
+    if rc == 10001:
+        raise ValueError(msg)
+    if rc == 10003:
+        raise NotImplementedError(msg)
+    raise RzError(f"{what} failed with status {rc}: {msg}")

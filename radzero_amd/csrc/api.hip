@@ -1,0 +1,681 @@
+// radzero_hip — C-ABI (include/radzero_hip.h): handle, checkpoint packing, forward orchestration.
+#include "../../include/radzero_hip.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "rz_kernels.h"
+
+using namespace rz;
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const std::string& msg) {
+    g_err = msg;
+    return code;
+}
+int hip_fail(hipError_t e, const char* what) {
+    g_err = std::string(what) + ": " + hipGetErrorString(e);
+    return (int)e;
+}
+#define RZ_HIP(x)                                          \
+    do {                                                   \
+        hipError_t _e = (x);                               \
+        if (_e != hipSuccess) return hip_fail(_e, #x);     \
+    } while (0)
+
+size_t dsize(int dt) { return dt == RZ_F32 ? 4 : 2; }
+
+// fp32 -> compute dtype on the host (round-to-nearest-even; NaN-safe enough for weights)
+uint16_t f32_to_bf16(float f) {
+    uint32_t u;
+    memcpy(&u, &f, 4);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+}
+uint16_t f32_to_f16(float f) {
+    _Float16 h = (_Float16)f;
+    uint16_t r;
+    memcpy(&r, &h, 2);
+    return r;
+}
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t bytes = 0;
+    hipError_t ensure(size_t n, bool zero) {
+        if (n <= bytes) return hipSuccess;
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        bytes = 0;
+        hipError_t e = hipMalloc(&p, n);
+        if (e != hipSuccess) return e;
+        bytes = n;
+        if (zero) e = hipMemset(p, 0, n);
+        return e;
+    }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        bytes = 0;
+    }
+};
+
+struct Tensor {          // one packed checkpoint tensor on the device
+    void* p = nullptr;
+    bool loaded = false;
+};
+
+struct DinoBlock {       // TF:dinov2/modeling_dinov2.py:342-380
+    Tensor ln1_g, ln1_b, wqk, bqk, wv, bv, wo, bo, ls1, ln2_g, ln2_b, w1, b1, w2, b2, ls2;
+    int qkv_parts = 0;   // bit mask of loaded q/k/v weight (1,2,4) and bias (8,16,32) pieces
+};
+struct TextLayer {       // TF:mpnet/modeling_mpnet.py:234-261
+    Tensor wqkv, bqkv, wo, bo, lna_g, lna_b, w1, b1, w2, b2, lno_g, lno_b;
+    int qkv_parts = 0;
+};
+
+}  // namespace
+
+struct rz_model {
+    rz_config cfg;
+    int dt;               // compute dtype
+    int D, H, F, KP, KPAD;
+    std::vector<DinoBlock> blocks;
+    std::vector<TextLayer> tlayers;
+    Tensor patch_w, vit_ln_g, vit_ln_b, word_emb, pos_emb, temb_ln_g, temb_ln_b, shared_ln_g, shared_ln_b;
+    std::vector<float> cls_host, patch_bias_host;
+    bool cls_loaded = false, patch_bias_loaded = false, tau_loaded = false;
+    float tau = 0.07f;
+    // position tables per grid: [n_pad][D] fp32 = pos (+cls | +conv bias), zero on pad rows
+    struct PosTable { DevBuf buf; int n_valid, n_pad; };
+    std::map<std::pair<int, int>, PosTable> pos_tables;
+    // workspaces
+    int cap_batch = 0, cap_npad = 0, cap_trows = 0, cap_prompts = 0;
+    DevBuf h, xn, qk, vt, ctx, mid, vhat, vws, qhat;
+    DevBuf th, txn, tqkv, tctx, tmid, tsum;
+    // state of the last vision forward
+    int last_batch = 0, last_nvalid = 0, last_npad = 0;
+    // profiling
+    bool prof = false;
+    struct Ev { hipEvent_t a, b; int fam; };
+    std::vector<Ev> ev_pool;
+    size_t ev_used = 0;
+    float prof_ms[RZ_PROF_NFAM] = {0, 0, 0, 0};
+    int64_t prof_n[RZ_PROF_NFAM] = {0, 0, 0, 0};
+    std::vector<void*> allocs;
+
+    hipError_t upload(Tensor& t, const float* src, size_t n, bool as_compute) {
+        size_t es = as_compute ? dsize(dt) : 4;
+        if (!t.p) {
+            hipError_t e = hipMalloc(&t.p, n * es);
+            if (e != hipSuccess) return e;
+            allocs.push_back(t.p);
+        }
+        return upload_at(t.p, src, n, as_compute);
+    }
+    hipError_t upload_at(void* dst, const float* src, size_t n, bool as_compute) {
+        if (!as_compute || dt == RZ_F32) return hipMemcpy(dst, src, n * 4, hipMemcpyHostToDevice);
+        std::vector<uint16_t> tmp(n);
+        if (dt == RZ_BF16) for (size_t i = 0; i < n; ++i) tmp[i] = f32_to_bf16(src[i]);
+        else for (size_t i = 0; i < n; ++i) tmp[i] = f32_to_f16(src[i]);
+        return hipMemcpy(dst, tmp.data(), n * 2, hipMemcpyHostToDevice);
+    }
+};
+
+namespace {
+
+struct ProfScope {
+    rz_model* m;
+    hipStream_t s;
+    int idx = -1;
+    ProfScope(rz_model* m_, int fam, hipStream_t s_) : m(m_), s(s_) {
+        if (!m->prof) return;
+        if (m->ev_used == m->ev_pool.size()) {
+            rz_model::Ev e;
+            if (hipEventCreate(&e.a) != hipSuccess || hipEventCreate(&e.b) != hipSuccess) return;
+            m->ev_pool.push_back(e);
+        }
+        idx = (int)m->ev_used++;
+        m->ev_pool[idx].fam = fam;
+        (void)hipEventRecord(m->ev_pool[idx].a, s);
+    }
+    ~ProfScope() {
+        if (idx >= 0) (void)hipEventRecord(m->ev_pool[idx].b, s);
+    }
+};
+
+int round_up(int x, int m) { return (x + m - 1) / m * m; }
+
+bool parse_layer(const char* name, const char* prefix, int* idx, const char** rest) {
+    size_t n = strlen(prefix);
+    if (strncmp(name, prefix, n) != 0) return false;
+    char* end = nullptr;
+    long v = strtol(name + n, &end, 10);
+    if (end == name + n || *end != '.') return false;
+    *idx = (int)v;
+    *rest = end + 1;
+    return true;
+}
+
+// copy `rows x cols` fp32 host block scaled by `scale` into a compute-dtype device matrix at row offset
+int put_rows(rz_model* m, Tensor& t, size_t total_rows, size_t cols, size_t row_off, const float* src, size_t rows,
+             float scale, bool as_compute) {
+    size_t es = as_compute ? dsize(m->dt) : 4;
+    if (!t.p) {
+        RZ_HIP(hipMalloc(&t.p, total_rows * cols * es));
+        m->allocs.push_back(t.p);
+    }
+    std::vector<float> tmp;
+    const float* s = src;
+    if (scale != 1.0f) {
+        tmp.assign(src, src + rows * cols);
+        for (auto& x : tmp) x *= scale;
+        s = tmp.data();
+    }
+    RZ_HIP(m->upload_at((char*)t.p + row_off * cols * es, s, rows * cols, as_compute));
+    return 0;
+}
+
+int load_dino_block(rz_model* m, DinoBlock& b, const char* rest, const float* data, int64_t numel) {
+    const size_t D = m->D, F = m->F;
+    const float qscale = 1.0f / sqrtf((float)(m->D / m->H));   // softmax scaling folded into q (exact: power of two for dh=64)
+    auto vec = [&](Tensor& t, size_t n) -> int {
+        if ((size_t)numel != n) return fail(RZ_ERR_INVALID, std::string("bad numel for ") + rest);
+        RZ_HIP(m->upload(t, data, n, false));
+        t.loaded = true;
+        return 0;
+    };
+    auto mat = [&](Tensor& t, size_t r, size_t c) -> int {
+        if ((size_t)numel != r * c) return fail(RZ_ERR_INVALID, std::string("bad numel for ") + rest);
+        RZ_HIP(m->upload(t, data, r * c, true));
+        t.loaded = true;
+        return 0;
+    };
+    if (!strcmp(rest, "norm1.weight")) return vec(b.ln1_g, D);
+    if (!strcmp(rest, "norm1.bias")) return vec(b.ln1_b, D);
+    if (!strcmp(rest, "norm2.weight")) return vec(b.ln2_g, D);
+    if (!strcmp(rest, "norm2.bias")) return vec(b.ln2_b, D);
+    if (!strcmp(rest, "layer_scale1.lambda1")) return vec(b.ls1, D);
+    if (!strcmp(rest, "layer_scale2.lambda1")) return vec(b.ls2, D);
+    if (!strcmp(rest, "attention.output.dense.weight")) return mat(b.wo, D, D);
+    if (!strcmp(rest, "attention.output.dense.bias")) return vec(b.bo, D);
+    if (!strcmp(rest, "mlp.fc1.weight")) return mat(b.w1, F, D);
+    if (!strcmp(rest, "mlp.fc1.bias")) return vec(b.b1, F);
+    if (!strcmp(rest, "mlp.fc2.weight")) return mat(b.w2, D, F);
+    if (!strcmp(rest, "mlp.fc2.bias")) return vec(b.b2, D);
+    const char* names[3] = {"query", "key", "value"};
+    for (int i = 0; i < 3; ++i) {
+        char wn[64], bn[64];
+        snprintf(wn, sizeof wn, "attention.attention.%s.weight", names[i]);
+        snprintf(bn, sizeof bn, "attention.attention.%s.bias", names[i]);
+        if (!strcmp(rest, wn)) {
+            if ((size_t)numel != D * D) return fail(RZ_ERR_INVALID, "bad numel for qkv weight");
+            int rc = (i < 2) ? put_rows(m, b.wqk, 2 * D, D, i * D, data, D, i == 0 ? qscale : 1.f, true)
+                             : put_rows(m, b.wv, D, D, 0, data, D, 1.f, true);
+            if (rc) return rc;
+            b.qkv_parts |= (1 << i);
+            return 0;
+        }
+        if (!strcmp(rest, bn)) {
+            if ((size_t)numel != D) return fail(RZ_ERR_INVALID, "bad numel for qkv bias");
+            int rc = (i < 2) ? put_rows(m, b.bqk, 2, D, i, data, 1, i == 0 ? qscale : 1.f, false)
+                             : put_rows(m, b.bv, 1, D, 0, data, 1, 1.f, false);
+            if (rc) return rc;
+            b.qkv_parts |= (8 << i);
+            return 0;
+        }
+    }
+    return fail(RZ_ERR_INVALID, std::string("unknown Dinov2Layer tensor: ") + rest);
+}
+
+int load_text_layer(rz_model* m, TextLayer& l, const char* rest, const float* data, int64_t numel) {
+    const size_t D = m->D, F = m->cfg.text_intermediate_size;
+    const float qscale = 1.0f / sqrtf((float)(m->D / m->H));
+    auto vec = [&](Tensor& t, size_t n) -> int {
+        if ((size_t)numel != n) return fail(RZ_ERR_INVALID, std::string("bad numel for ") + rest);
+        RZ_HIP(m->upload(t, data, n, false));
+        t.loaded = true;
+        return 0;
+    };
+    auto mat = [&](Tensor& t, size_t r, size_t c) -> int {
+        if ((size_t)numel != r * c) return fail(RZ_ERR_INVALID, std::string("bad numel for ") + rest);
+        RZ_HIP(m->upload(t, data, r * c, true));
+        t.loaded = true;
+        return 0;
+    };
+    if (!strcmp(rest, "attention.attn.o.weight")) return mat(l.wo, D, D);
+    if (!strcmp(rest, "attention.attn.o.bias")) return vec(l.bo, D);
+    if (!strcmp(rest, "attention.LayerNorm.weight")) return vec(l.lna_g, D);
+    if (!strcmp(rest, "attention.LayerNorm.bias")) return vec(l.lna_b, D);
+    if (!strcmp(rest, "intermediate.dense.weight")) return mat(l.w1, F, D);
+    if (!strcmp(rest, "intermediate.dense.bias")) return vec(l.b1, F);
+    if (!strcmp(rest, "output.dense.weight")) return mat(l.w2, D, F);
+    if (!strcmp(rest, "output.dense.bias")) return vec(l.b2, D);
+    if (!strcmp(rest, "output.LayerNorm.weight")) return vec(l.lno_g, D);
+    if (!strcmp(rest, "output.LayerNorm.bias")) return vec(l.lno_b, D);
+    const char* names[3] = {"q", "k", "v"};
+    for (int i = 0; i < 3; ++i) {
+        char wn[64], bn[64];
+        snprintf(wn, sizeof wn, "attention.attn.%s.weight", names[i]);
+        snprintf(bn, sizeof bn, "attention.attn.%s.bias", names[i]);
+        if (!strcmp(rest, wn)) {
+            if ((size_t)numel != D * D) return fail(RZ_ERR_INVALID, "bad numel for qkv weight");
+            int rc = put_rows(m, l.wqkv, 3 * D, D, i * D, data, D, i == 0 ? qscale : 1.f, true);
+            if (rc) return rc;
+            l.qkv_parts |= (1 << i);
+            return 0;
+        }
+        if (!strcmp(rest, bn)) {
+            if ((size_t)numel != D) return fail(RZ_ERR_INVALID, "bad numel for qkv bias");
+            int rc = put_rows(m, l.bqkv, 3, D, i, data, 1, i == 0 ? qscale : 1.f, false);
+            if (rc) return rc;
+            l.qkv_parts |= (8 << i);
+            return 0;
+        }
+    }
+    return fail(RZ_ERR_INVALID, std::string("unknown MPNetLayer tensor: ") + rest);
+}
+
+int gemm(rz_model* m, int epi, const void* A, int64_t lda, const void* W, int64_t ldw, int M, int N, int K, const float* bias,
+         void* out, int64_t ldo, const float* scale, float* resid, int64_t ldr, int rpi, int heads, hipStream_t s) {
+    GemmArgs g;
+    g.A = A; g.lda = lda; g.W = W; g.ldw = ldw; g.M = M; g.N = N; g.K = K; g.bias = bias; g.out = out; g.ldo = ldo;
+    g.scale = scale; g.resid = resid; g.ldr = ldr; g.rows_per_image = rpi; g.heads_total = heads;
+    ProfScope ps(m, RZ_PROF_GEMM, s);
+    RZ_HIP(launch_gemm(m->dt, epi, g, s));
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* rz_last_error(void) { return g_err.c_str(); }
+const char* rz_version(void) { return "radzero_hip 0.1 (gfx950)"; }
+
+int rz_create(const rz_config* cfg, rz_handle_t* out) {
+    if (!cfg || !out) return fail(RZ_ERR_INVALID, "rz_create: null argument");
+    if (cfg->compute_dtype < 0 || cfg->compute_dtype > 2) return fail(RZ_ERR_INVALID, "rz_create: compute_dtype");
+    if (cfg->hidden_size != 768 || cfg->num_attention_heads != 12)
+        return fail(RZ_ERR_UNSUPPORTED, "rz_create: kernels are specialised for hidden 768 / 12 heads of 64 (dinov2-base, mpnet-base)");
+    if (cfg->patch_size <= 0 || cfg->num_channels <= 0 || cfg->vit_layers < 0 || cfg->align_layers < 0 || cfg->text_layers < 0)
+        return fail(RZ_ERR_INVALID, "rz_create: layer counts / patch size");
+    if ((cfg->hidden_size * cfg->mlp_ratio) % 128 || cfg->text_intermediate_size % 128)
+        return fail(RZ_ERR_INVALID, "rz_create: intermediate sizes must be multiples of 128");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
+        return fail(RZ_ERR_STATE, "rz_create: no HIP device visible (this library has no CPU fallback)");
+    rz_model* m = new rz_model();
+    m->cfg = *cfg;
+    m->dt = cfg->compute_dtype;
+    m->D = cfg->hidden_size;
+    m->H = cfg->num_attention_heads;
+    m->F = cfg->hidden_size * cfg->mlp_ratio;
+    m->KP = cfg->num_channels * cfg->patch_size * cfg->patch_size;
+    m->KPAD = round_up(m->KP, 64);
+    m->blocks.resize(cfg->vit_layers + cfg->align_layers);
+    m->tlayers.resize(cfg->text_layers);
+    *out = m;
+    return 0;
+}
+
+int rz_destroy(rz_handle_t m) {
+    if (!m) return 0;
+    for (void* p : m->allocs) (void)hipFree(p);
+    for (auto& kv : m->pos_tables) kv.second.buf.release();
+    DevBuf* bufs[] = {&m->h, &m->xn, &m->qk, &m->vt, &m->ctx, &m->mid, &m->vhat, &m->vws, &m->qhat,
+                      &m->th, &m->txn, &m->tqkv, &m->tctx, &m->tmid, &m->tsum};
+    for (DevBuf* b : bufs) b->release();
+    for (auto& e : m->ev_pool) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
+    delete m;
+    return 0;
+}
+
+int rz_load_weight(rz_handle_t m, const char* name, const float* data, int64_t numel) {
+    if (!m || !name || !data || numel <= 0) return fail(RZ_ERR_INVALID, "rz_load_weight: bad argument");
+    const size_t D = m->D;
+    int idx;
+    const char* rest;
+    auto vec = [&](Tensor& t, size_t n) -> int {
+        if ((size_t)numel != n) return fail(RZ_ERR_INVALID, std::string("bad numel for ") + name);
+        RZ_HIP(m->upload(t, data, n, false));
+        t.loaded = true;
+        return 0;
+    };
+    if (parse_layer(name, "vision_model.encoder.layer.", &idx, &rest)) {
+        if (idx < 0 || idx >= m->cfg.vit_layers) return fail(RZ_ERR_INVALID, std::string("layer index out of range: ") + name);
+        return load_dino_block(m, m->blocks[idx], rest, data, numel);
+    }
+    if (parse_layer(name, "align_transformer.transformer_layers.layer.", &idx, &rest)) {
+        if (idx < 0 || idx >= m->cfg.align_layers) return fail(RZ_ERR_INVALID, std::string("layer index out of range: ") + name);
+        return load_dino_block(m, m->blocks[m->cfg.vit_layers + idx], rest, data, numel);
+    }
+    if (parse_layer(name, "text_model.encoder.layer.", &idx, &rest)) {
+        if (idx < 0 || idx >= m->cfg.text_layers) return fail(RZ_ERR_INVALID, std::string("layer index out of range: ") + name);
+        return load_text_layer(m, m->tlayers[idx], rest, data, numel);
+    }
+    if (!strcmp(name, "vision_model.embeddings.cls_token")) {
+        if ((size_t)numel != D) return fail(RZ_ERR_INVALID, "bad numel for cls_token");
+        m->cls_host.assign(data, data + D);
+        m->cls_loaded = true;
+        return 0;
+    }
+    if (!strcmp(name, "vision_model.embeddings.patch_embeddings.projection.bias")) {
+        if ((size_t)numel != D) return fail(RZ_ERR_INVALID, "bad numel for patch bias");
+        m->patch_bias_host.assign(data, data + D);
+        m->patch_bias_loaded = true;
+        return 0;
+    }
+    if (!strcmp(name, "vision_model.embeddings.patch_embeddings.projection.weight")) {
+        if ((size_t)numel != D * (size_t)m->KP) return fail(RZ_ERR_INVALID, "bad numel for patch weight");
+        std::vector<float> padded(D * (size_t)m->KPAD, 0.f);          // [768][588] -> [768][640], zero padded
+        for (size_t r = 0; r < D; ++r) memcpy(&padded[r * m->KPAD], data + r * m->KP, m->KP * sizeof(float));
+        RZ_HIP(m->upload(m->patch_w, padded.data(), padded.size(), true));
+        m->patch_w.loaded = true;
+        return 0;
+    }
+    if (!strcmp(name, "vision_model.layernorm.weight")) return vec(m->vit_ln_g, D);
+    if (!strcmp(name, "vision_model.layernorm.bias")) return vec(m->vit_ln_b, D);
+    if (!strcmp(name, "text_model.embeddings.word_embeddings.weight")) return vec(m->word_emb, (size_t)m->cfg.vocab_size * D);
+    if (!strcmp(name, "text_model.embeddings.position_embeddings.weight")) return vec(m->pos_emb, (size_t)m->cfg.max_position_embeddings * D);
+    if (!strcmp(name, "text_model.embeddings.LayerNorm.weight")) return vec(m->temb_ln_g, D);
+    if (!strcmp(name, "text_model.embeddings.LayerNorm.bias")) return vec(m->temb_ln_b, D);
+    if (!strcmp(name, "loss_fns.RadZeroLoss.layer_norm.weight")) return vec(m->shared_ln_g, D);
+    if (!strcmp(name, "loss_fns.RadZeroLoss.layer_norm.bias")) return vec(m->shared_ln_b, D);
+    if (!strcmp(name, "loss_fns.RadZeroLoss.loss_temperature")) {
+        if (numel != 1) return fail(RZ_ERR_INVALID, "bad numel for loss_temperature");
+        m->tau = expf(data[0]);       // stored as log(tau) (losses.py:54-56); tau = exp(param) (losses.py:177-181)
+        m->tau_loaded = true;
+        return 0;
+    }
+    // tensors the path never reads: position_embeddings (interpolated on the host and passed through
+    // rz_set_position_table), mask_token, pooler, relative_attention_bias (passed expanded to rz_text_forward)
+    if (!strcmp(name, "vision_model.embeddings.position_embeddings") || !strcmp(name, "vision_model.embeddings.mask_token") ||
+        !strncmp(name, "text_model.pooler.", 18) || !strcmp(name, "text_model.encoder.relative_attention_bias.weight"))
+        return 0;
+    return fail(RZ_ERR_INVALID, std::string("rz_load_weight: unknown tensor name: ") + name);
+}
+
+int rz_weights_ready(rz_handle_t m) {
+    if (!m) return fail(RZ_ERR_INVALID, "null handle");
+    auto need = [&](bool ok, const std::string& what) -> int { return ok ? 0 : fail(RZ_ERR_STATE, "weight not loaded: " + what); };
+    int rc;
+    if ((rc = need(m->cls_loaded, "vision_model.embeddings.cls_token"))) return rc;
+    if ((rc = need(m->patch_bias_loaded && m->patch_w.loaded, "vision_model.embeddings.patch_embeddings.projection"))) return rc;
+    if ((rc = need(m->vit_ln_g.loaded && m->vit_ln_b.loaded, "vision_model.layernorm"))) return rc;
+    for (size_t i = 0; i < m->blocks.size(); ++i) {
+        const DinoBlock& b = m->blocks[i];
+        bool ok = b.ln1_g.loaded && b.ln1_b.loaded && b.qkv_parts == 63 && b.wo.loaded && b.bo.loaded && b.ls1.loaded &&
+                  b.ln2_g.loaded && b.ln2_b.loaded && b.w1.loaded && b.b1.loaded && b.w2.loaded && b.b2.loaded && b.ls2.loaded;
+        if ((rc = need(ok, "Dinov2Layer " + std::to_string(i)))) return rc;
+    }
+    if ((rc = need(m->word_emb.loaded && m->pos_emb.loaded && m->temb_ln_g.loaded && m->temb_ln_b.loaded, "text_model.embeddings"))) return rc;
+    for (size_t i = 0; i < m->tlayers.size(); ++i) {
+        const TextLayer& l = m->tlayers[i];
+        bool ok = l.qkv_parts == 63 && l.wo.loaded && l.bo.loaded && l.lna_g.loaded && l.lna_b.loaded && l.w1.loaded &&
+                  l.b1.loaded && l.w2.loaded && l.b2.loaded && l.lno_g.loaded && l.lno_b.loaded;
+        if ((rc = need(ok, "MPNetLayer " + std::to_string(i)))) return rc;
+    }
+    if ((rc = need(m->shared_ln_g.loaded && m->shared_ln_b.loaded && m->tau_loaded, "loss_fns.RadZeroLoss"))) return rc;
+    return 0;
+}
+
+int rz_set_position_table(rz_handle_t m, int gh, int gw, const float* pos_host) {
+    if (!m || !pos_host || gh <= 0 || gw <= 0) return fail(RZ_ERR_INVALID, "rz_set_position_table: bad argument");
+    if (!m->cls_loaded || !m->patch_bias_loaded) return fail(RZ_ERR_STATE, "rz_set_position_table: load cls_token and patch bias first");
+    const int D = m->D, nv = 1 + gh * gw, np = round_up(nv, 128);
+    std::vector<float> tbl((size_t)np * D, 0.f);
+    for (int d = 0; d < D; ++d) tbl[d] = pos_host[d] + m->cls_host[d];
+    for (int t = 1; t < nv; ++t)
+        for (int d = 0; d < D; ++d) tbl[(size_t)t * D + d] = pos_host[(size_t)t * D + d] + m->patch_bias_host[d];
+    auto& pt = m->pos_tables[{gh, gw}];
+    RZ_HIP(pt.buf.ensure(tbl.size() * 4, false));
+    RZ_HIP(hipMemcpy(pt.buf.p, tbl.data(), tbl.size() * 4, hipMemcpyHostToDevice));
+    pt.n_valid = nv;
+    pt.n_pad = np;
+    return 0;
+}
+
+int rz_reserve(rz_handle_t m, int max_batch, int max_tokens, int max_prompts, int max_len) {
+    if (!m || max_batch < 0 || max_tokens < 0 || max_prompts < 0 || max_len < 0) return fail(RZ_ERR_INVALID, "rz_reserve: bad argument");
+    const size_t es = dsize(m->dt), D = m->D, F = m->F;
+    const int npad = round_up(max_tokens, 128);
+    if (max_batch > 0 && max_tokens > 0) {
+        const int B = std::max(max_batch, m->cap_batch), NP = std::max(npad, m->cap_npad);
+        const size_t rows = (size_t)B * NP;
+        RZ_HIP(m->h.ensure(rows * D * 4, true));
+        RZ_HIP(m->xn.ensure(rows * D * es, true));
+        RZ_HIP(m->qk.ensure(rows * 2 * D * es, true));
+        RZ_HIP(m->vt.ensure(rows * D * es, true));
+        RZ_HIP(m->ctx.ensure(rows * D * es, true));
+        RZ_HIP(m->mid.ensure(rows * std::max(F, (size_t)m->KPAD) * es, true));
+        RZ_HIP(m->vhat.ensure(rows * D * 4, true));
+        m->cap_batch = B;
+        m->cap_npad = NP;
+    }
+    if (max_prompts > 0) {
+        const int P = std::max(max_prompts, m->cap_prompts);
+        RZ_HIP(m->qhat.ensure((size_t)P * D * 4, true));
+        m->cap_prompts = P;
+        if (max_len > 0) {
+            const int trows = std::max(round_up(P * max_len, 128), m->cap_trows);
+            const size_t TF = m->cfg.text_intermediate_size;
+            RZ_HIP(m->th.ensure((size_t)trows * D * 4, true));
+            RZ_HIP(m->tsum.ensure((size_t)trows * D * 4, true));
+            RZ_HIP(m->txn.ensure((size_t)trows * D * es, true));
+            RZ_HIP(m->tqkv.ensure((size_t)trows * 3 * D * es, true));
+            RZ_HIP(m->tctx.ensure((size_t)trows * D * es, true));
+            RZ_HIP(m->tmid.ensure((size_t)trows * TF * es, true));
+            m->cap_trows = trows;
+        }
+    }
+    if (m->cap_batch > 0 && m->cap_prompts > 0)
+        RZ_HIP(m->vws.ensure(vlcabs_workspace_floats(m->cap_batch, m->cap_prompts, m->cap_npad, m->D) * 4, false));
+    return 0;
+}
+
+int rz_vision_forward(rz_handle_t m, const float* px, int B, int C, int Himg, int Wimg, float* tokens_out, void* stream) {
+    if (!m || !px) return fail(RZ_ERR_INVALID, "rz_vision_forward: null argument");
+    hipStream_t s = (hipStream_t)stream;
+    if (C != m->cfg.num_channels)   // TF:dinov2/modeling_dinov2.py:143-147
+        return fail(RZ_ERR_INVALID, "Make sure that the channel dimension of the pixel values match with the one set in the configuration.");
+    const int P = m->cfg.patch_size, gh = Himg / P, gw = Wimg / P;
+    if (B <= 0 || gh <= 0 || gw <= 0) return fail(RZ_ERR_INVALID, "rz_vision_forward: image smaller than one patch or empty batch");
+    int rc = rz_weights_ready(m);
+    if (rc) return rc;
+    auto it = m->pos_tables.find({gh, gw});
+    if (it == m->pos_tables.end()) return fail(RZ_ERR_STATE, "rz_vision_forward: no position table for this patch grid (rz_set_position_table)");
+    const int nv = it->second.n_valid, np = it->second.n_pad;
+    if (B > m->cap_batch || np > m->cap_npad || (size_t)B * np > (size_t)m->cap_batch * m->cap_npad)
+        return fail(RZ_ERR_STATE, "rz_vision_forward: workspace too small (rz_reserve)");
+    const int D = m->D, H = m->H, F = m->F, M = B * np;
+    const float eps = m->cfg.vit_layer_norm_eps;
+    float* h = (float*)m->h.p;
+
+    {   // patch embedding: im2col + GEMM with (pos | cls | bias) table epilogue
+        ProfScope ps(m, RZ_PROF_ROWOPS, s);
+        RZ_HIP(launch_im2col(m->dt, px, m->mid.p, B, C, Himg, Wimg, P, gh, gw, np, m->KPAD, s));
+    }
+    if ((rc = gemm(m, EPI_PATCH, m->mid.p, m->KPAD, m->patch_w.p, m->KPAD, M, D, m->KPAD, nullptr, h, D,
+                   (const float*)it->second.buf.p, nullptr, 0, np, 0, s))) return rc;
+
+    const int nblocks = (int)m->blocks.size();
+    for (int li = 0; li < nblocks; ++li) {
+        const DinoBlock& b = m->blocks[li];
+        {
+            ProfScope ps(m, RZ_PROF_ROWOPS, s);
+            RZ_HIP(launch_layernorm(m->dt, h, (const float*)b.ln1_g.p, (const float*)b.ln1_b.p, eps, m->xn.p, nullptr, M, D, s));
+        }
+        if ((rc = gemm(m, EPI_HEADS, m->xn.p, D, b.wqk.p, D, M, 2 * D, D, (const float*)b.bqk.p, m->qk.p, 0, nullptr, nullptr, 0, np, 2 * H, s))) return rc;
+        if ((rc = gemm(m, EPI_VT, m->xn.p, D, b.wv.p, D, M, D, D, (const float*)b.bv.p, m->vt.p, 0, nullptr, nullptr, 0, np, H, s))) return rc;
+        {
+            ProfScope ps(m, RZ_PROF_ATTN, s);
+            // q heads are heads [0,H) and k heads [H,2H) of the [B][2H][np][64] tensor
+            const size_t es = dsize(m->dt);
+            const char* qb = (const char*)m->qk.p;
+            const char* kb = qb + (size_t)H * np * 64 * es;
+            RZ_HIP(launch_flash_attn(m->dt, qb, kb, m->vt.p, m->ctx.p, (int64_t)2 * H * np * 64, B, H, nv, np, s));
+        }
+        if ((rc = gemm(m, EPI_RESID_SCALE, m->ctx.p, D, b.wo.p, D, M, D, D, (const float*)b.bo.p, nullptr, 0, (const float*)b.ls1.p, h, D, np, 0, s))) return rc;
+        {
+            ProfScope ps(m, RZ_PROF_ROWOPS, s);
+            RZ_HIP(launch_layernorm(m->dt, h, (const float*)b.ln2_g.p, (const float*)b.ln2_b.p, eps, m->xn.p, nullptr, M, D, s));
+        }
+        if ((rc = gemm(m, EPI_GELU, m->xn.p, D, b.w1.p, D, M, F, D, (const float*)b.b1.p, m->mid.p, F, nullptr, nullptr, 0, np, 0, s))) return rc;
+        if ((rc = gemm(m, EPI_RESID_SCALE, m->mid.p, F, b.w2.p, F, M, D, F, (const float*)b.b2.p, nullptr, 0, (const float*)b.ls2.p, h, D, np, 0, s))) return rc;
+        if (li == m->cfg.vit_layers - 1) {   // Dinov2Model.layernorm (TF:dinov2/modeling_dinov2.py:469); align blocks follow
+            ProfScope ps(m, RZ_PROF_ROWOPS, s);
+            RZ_HIP(launch_layernorm(m->dt, h, (const float*)m->vit_ln_g.p, (const float*)m->vit_ln_b.p, eps, nullptr, h, M, D, s));
+        }
+    }
+    if (m->cfg.vit_layers == 0) {
+        ProfScope ps(m, RZ_PROF_ROWOPS, s);
+        RZ_HIP(launch_layernorm(m->dt, h, (const float*)m->vit_ln_g.p, (const float*)m->vit_ln_b.p, eps, nullptr, h, M, D, s));
+    }
+    m->last_batch = B;
+    m->last_nvalid = nv;
+    m->last_npad = np;
+    if (tokens_out) {
+        ProfScope ps(m, RZ_PROF_ROWOPS, s);
+        RZ_HIP(launch_copy_tokens(h, tokens_out, B, nv, np, D, s));
+    }
+    return 0;
+}
+
+int rz_text_forward(rz_handle_t m, const int64_t* ids, const int64_t* mask, int T, int L, const float* rel_bias, float* out, void* stream) {
+    if (!m || !ids || !mask || !rel_bias || !out) return fail(RZ_ERR_INVALID, "rz_text_forward: null argument");
+    if (T <= 0 || L <= 0) return fail(RZ_ERR_INVALID, "rz_text_forward: empty prompt batch");
+    if (L + m->cfg.pad_token_id + 1 > m->cfg.max_position_embeddings)
+        return fail(RZ_ERR_INVALID, "rz_text_forward: sequence longer than max_position_embeddings allows");
+    int rc = rz_weights_ready(m);
+    if (rc) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    const int D = m->D, H = m->H, TF = m->cfg.text_intermediate_size;
+    const int rows = T * L, Mp = round_up(rows, 128);
+    if (Mp > m->cap_trows) return fail(RZ_ERR_STATE, "rz_text_forward: workspace too small (rz_reserve)");
+    const float eps = m->cfg.text_layer_norm_eps;
+    float* th = (float*)m->th.p;
+    float* tsum = (float*)m->tsum.p;
+    {
+        ProfScope ps(m, RZ_PROF_ROWOPS, s);
+        RZ_HIP(launch_text_embed(m->dt, ids, (const float*)m->word_emb.p, (const float*)m->pos_emb.p, (const float*)m->temb_ln_g.p,
+                                 (const float*)m->temb_ln_b.p, eps, th, m->txn.p, T, L, D, m->cfg.vocab_size,
+                                 m->cfg.max_position_embeddings, m->cfg.pad_token_id, s));
+    }
+    for (const TextLayer& l : m->tlayers) {
+        if ((rc = gemm(m, EPI_STORE, m->txn.p, D, l.wqkv.p, D, Mp, 3 * D, D, (const float*)l.bqkv.p, m->tqkv.p, 3 * D, nullptr, nullptr, 0, Mp, 0, s))) return rc;
+        {
+            ProfScope ps(m, RZ_PROF_ATTN, s);
+            RZ_HIP(launch_text_attn(m->dt, m->tqkv.p, rel_bias, nullptr, mask, m->tctx.p, T, L, H, 0, s));
+        }
+        if ((rc = gemm(m, EPI_RESID_ADD, m->tctx.p, D, l.wo.p, D, Mp, D, D, (const float*)l.bo.p, tsum, D, nullptr, th, D, Mp, 0, s))) return rc;
+        {
+            ProfScope ps(m, RZ_PROF_ROWOPS, s);
+            RZ_HIP(launch_layernorm(m->dt, tsum, (const float*)l.lna_g.p, (const float*)l.lna_b.p, eps, m->txn.p, th, rows, D, s));
+        }
+        if ((rc = gemm(m, EPI_GELU, m->txn.p, D, l.w1.p, D, Mp, TF, D, (const float*)l.b1.p, m->tmid.p, TF, nullptr, nullptr, 0, Mp, 0, s))) return rc;
+        if ((rc = gemm(m, EPI_RESID_ADD, m->tmid.p, TF, l.w2.p, TF, Mp, D, TF, (const float*)l.b2.p, tsum, D, nullptr, th, D, Mp, 0, s))) return rc;
+        {
+            ProfScope ps(m, RZ_PROF_ROWOPS, s);
+            RZ_HIP(launch_layernorm(m->dt, tsum, (const float*)l.lno_g.p, (const float*)l.lno_b.p, eps, m->txn.p, th, rows, D, s));
+        }
+    }
+    {
+        ProfScope ps(m, RZ_PROF_ROWOPS, s);
+        RZ_HIP(launch_masked_meanpool(th, mask, out, T, L, D, s));
+    }
+    return 0;
+}
+
+int rz_vlcabs(rz_handle_t m, const float* text_features, int T, int B, float* scores, float* t2i, float* logits, void* stream) {
+    if (!m || !text_features || !scores || !t2i || !logits) return fail(RZ_ERR_INVALID, "rz_vlcabs: null argument");
+    if (T <= 0 || B <= 0) return fail(RZ_ERR_INVALID, "rz_vlcabs: empty batch");
+    if (B != m->last_batch) return fail(RZ_ERR_STATE, "rz_vlcabs: batch differs from the last rz_vision_forward");
+    if (T > m->cap_prompts || B > m->cap_batch) return fail(RZ_ERR_STATE, "rz_vlcabs: workspace too small (rz_reserve)");
+    if (!m->shared_ln_g.loaded || !m->tau_loaded) return fail(RZ_ERR_STATE, "rz_vlcabs: RadZeroLoss weights not loaded");
+    hipStream_t s = (hipStream_t)stream;
+    const int D = m->D;
+    ProfScope ps(m, RZ_PROF_VLCABS, s);
+    RZ_HIP(launch_ln_l2norm(text_features, D, (const float*)m->shared_ln_g.p, (const float*)m->shared_ln_b.p,
+                            m->cfg.shared_layer_norm_eps, (float*)m->qhat.p, T, D, s));
+    RZ_HIP(launch_vlcabs((const float*)m->h.p, (const float*)m->shared_ln_g.p, (const float*)m->shared_ln_b.p,
+                         m->cfg.shared_layer_norm_eps, (const float*)m->qhat.p, m->tau, (float*)m->vhat.p, (float*)m->vws.p,
+                         scores, t2i, logits, B, T, m->last_nvalid, m->last_npad, D, s));
+    return 0;
+}
+
+int rz_upsample_maps(rz_handle_t m, const float* maps, int64_t map_stride, int n_maps, int grid, int out_h, int out_w,
+                     int apply_sigmoid, float* out, void* stream) {
+    if (!maps || !out || n_maps <= 0 || grid <= 0 || out_h <= 0 || out_w <= 0 || map_stride < (int64_t)grid * grid)
+        return fail(RZ_ERR_INVALID, "rz_upsample_maps: bad argument");
+    hipStream_t s = (hipStream_t)stream;
+    if (m) {
+        ProfScope ps(m, RZ_PROF_VLCABS, s);
+        RZ_HIP(launch_upsample_bilinear(maps, map_stride, out, nullptr, n_maps, grid, out_h, out_w, apply_sigmoid, s));
+    } else {
+        RZ_HIP(launch_upsample_bilinear(maps, map_stride, out, nullptr, n_maps, grid, out_h, out_w, apply_sigmoid, s));
+    }
+    return 0;
+}
+
+int rz_gemm(int dtype, int epilogue, const void* a, const void* w, const float* bias, void* out, int M, int N, int K, void* stream) {
+    if (!a || !w || !out) return fail(RZ_ERR_INVALID, "rz_gemm: null argument");
+    if (epilogue != EPI_STORE && epilogue != EPI_GELU && epilogue != EPI_STORE_F32) return fail(RZ_ERR_INVALID, "rz_gemm: epilogue");
+    if (M % 128 || N % 128) return fail(RZ_ERR_INVALID, "rz_gemm: M and N must be multiples of 128");
+    GemmArgs g;
+    memset(&g, 0, sizeof g);
+    g.A = a; g.lda = K; g.W = w; g.ldw = K; g.M = M; g.N = N; g.K = K; g.bias = bias; g.out = out; g.ldo = N;
+    g.rows_per_image = M;
+    RZ_HIP(launch_gemm(dtype, epilogue, g, (hipStream_t)stream));
+    return 0;
+}
+
+int rz_layernorm(int dtype, const float* in, const float* gamma, const float* beta, float eps, void* out_t, float* out_f32,
+                 int64_t rows, int dim, void* stream) {
+    if (!in || !gamma || !beta || (!out_t && !out_f32)) return fail(RZ_ERR_INVALID, "rz_layernorm: null argument");
+    if (dim != 768) return fail(RZ_ERR_UNSUPPORTED, "rz_layernorm: dim must be 768");
+    RZ_HIP(launch_layernorm(dtype, in, gamma, beta, eps, out_t, out_f32, rows, dim, (hipStream_t)stream));
+    return 0;
+}
+
+int rz_flash_attention(int dtype, const void* q, const void* k, const void* vt, void* ctx, int B, int H, int n_valid, int n_pad,
+                       void* stream) {
+    if (!q || !k || !vt || !ctx) return fail(RZ_ERR_INVALID, "rz_flash_attention: null argument");
+    if (n_pad % 128 || n_valid <= 0 || n_valid > n_pad) return fail(RZ_ERR_INVALID, "rz_flash_attention: n_pad must be a multiple of 128 >= n_valid > 0");
+    RZ_HIP(launch_flash_attn(dtype, q, k, vt, ctx, (int64_t)H * n_pad * 64, B, H, n_valid, n_pad, (hipStream_t)stream));
+    return 0;
+}
+
+int rz_profile_enable(rz_handle_t m, int enable) {
+    if (!m) return fail(RZ_ERR_INVALID, "null handle");
+    m->prof = enable != 0;
+    m->ev_used = 0;
+    for (int i = 0; i < RZ_PROF_NFAM; ++i) { m->prof_ms[i] = 0.f; m->prof_n[i] = 0; }
+    return 0;
+}
+
+int rz_profile_read(rz_handle_t m, float* ms, int64_t* n) {
+    if (!m || !ms || !n) return fail(RZ_ERR_INVALID, "rz_profile_read: null argument");
+    for (size_t i = 0; i < m->ev_used; ++i) {
+        float t = 0.f;
+        RZ_HIP(hipEventElapsedTime(&t, m->ev_pool[i].a, m->ev_pool[i].b));
+        m->prof_ms[m->ev_pool[i].fam] += t;
+        m->prof_n[m->ev_pool[i].fam] += 1;
+    }
+    m->ev_used = 0;
+    for (int i = 0; i < RZ_PROF_NFAM; ++i) { ms[i] = m->prof_ms[i]; n[i] = m->prof_n[i]; m->prof_ms[i] = 0.f; m->prof_n[i] = 0; }
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,219 @@
+// radzero_hip — row-wise (HBM-bound) kernels: LayerNorm, im2col for the patch conv, MPNet embeddings,
+// masked mean pooling, LN+L2-normalise.  One 64-lane wave per row, 16-byte accesses, two-pass statistics
+// held in registers (exact mean/variance, no E[x^2]-E[x]^2 cancellation).
+#include "rz_common.h"
+#include "rz_kernels.h"
+
+namespace rz {
+
+// ---- row held by one wave: D = 256*NV floats, lane owns float4 chunks lane + 64*i ----
+template <int NV> struct RowRegs { f32x4 v[NV]; };
+
+template <int NV> __device__ __forceinline__ RowRegs<NV> load_row(const float* p, int lane) {
+    RowRegs<NV> r;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) r.v[i] = *reinterpret_cast<const f32x4*>(p + (lane + 64 * i) * 4);
+    return r;
+}
+
+// in-register LayerNorm of a row (biased variance), returns normalised*gamma+beta in place
+template <int NV>
+__device__ __forceinline__ void row_layernorm(RowRegs<NV>& r, const float* gamma, const float* beta, float eps, int lane) {
+    constexpr float invD = 1.0f / (256.0f * NV);
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) s += (r.v[i][0] + r.v[i][1]) + (r.v[i][2] + r.v[i][3]);
+    const float mu = wave_sum(s) * invD;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        r.v[i] -= mu;
+        q += (r.v[i][0] * r.v[i][0] + r.v[i][1] * r.v[i][1]) + (r.v[i][2] * r.v[i][2] + r.v[i][3] * r.v[i][3]);
+    }
+    const float rstd = rsqrtf(wave_sum(q) * invD + eps);
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const f32x4 g = *reinterpret_cast<const f32x4*>(gamma + (lane + 64 * i) * 4);
+        const f32x4 b = *reinterpret_cast<const f32x4*>(beta + (lane + 64 * i) * 4);
+        r.v[i] = r.v[i] * rstd * g + b;
+    }
+}
+
+// TF:dinov2/modeling_dinov2.py:348,353,441 (norm1/norm2/final layernorm); TF:mpnet/modeling_mpnet.py:198,229.
+template <typename T, int NV>
+__global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ in, const float* __restrict__ gamma,
+                                                        const float* __restrict__ beta, float eps, T* out_t,
+                                                        float* out_f32, int64_t rows) {
+    constexpr int D = 256 * NV;
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    RowRegs<NV> r = load_row<NV>(in + row * D, lane);
+    row_layernorm<NV>(r, gamma, beta, eps, lane);
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = (lane + 64 * i) * 4;
+        if (out_f32) *reinterpret_cast<f32x4*>(out_f32 + row * D + c) = r.v[i];
+        if (out_t)
+            *reinterpret_cast<typename Traits<T>::vec4*>(out_t + row * D + c) =
+                pack4<T>(r.v[i][0], r.v[i][1], r.v[i][2], r.v[i][3]);
+    }
+}
+
+hipError_t launch_layernorm(int dtype, const float* in, const float* gamma, const float* beta, float eps,
+                            void* out_t, float* out_f32, int64_t rows, int D, hipStream_t s) {
+    if (D != 768 || rows <= 0) return hipErrorInvalidValue;
+    dim3 grid((unsigned)((rows + 3) / 4)), block(256);
+    switch (dtype) {
+        case DT_F32: hipLaunchKernelGGL((layernorm_kernel<float, 3>), grid, block, 0, s, in, gamma, beta, eps, (float*)out_t, out_f32, rows); break;
+        case DT_BF16: hipLaunchKernelGGL((layernorm_kernel<bf16_t, 3>), grid, block, 0, s, in, gamma, beta, eps, (bf16_t*)out_t, out_f32, rows); break;
+        case DT_F16: hipLaunchKernelGGL((layernorm_kernel<f16_t, 3>), grid, block, 0, s, in, gamma, beta, eps, (f16_t*)out_t, out_f32, rows); break;
+        default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+// ---- shared LayerNorm + L2 normalisation (exp/cxr_pt/model/losses.py:90-91,163-164 then :212-213) ----
+template <int NV>
+__global__ __launch_bounds__(256) void ln_l2norm_kernel(const float* __restrict__ in, int64_t ld_in,
+                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                        float eps, float* __restrict__ out, int64_t rows) {
+    constexpr int D = 256 * NV;
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    RowRegs<NV> r = load_row<NV>(in + row * ld_in, lane);
+    row_layernorm<NV>(r, gamma, beta, eps, lane);
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) q += (r.v[i][0] * r.v[i][0] + r.v[i][1] * r.v[i][1]) + (r.v[i][2] * r.v[i][2] + r.v[i][3] * r.v[i][3]);
+    const float nrm = fmaxf(sqrtf(wave_sum(q)), 1e-12f);   // F.normalize: x / max(||x||, eps)
+#pragma unroll
+    for (int i = 0; i < NV; ++i) *reinterpret_cast<f32x4*>(out + row * D + (lane + 64 * i) * 4) = r.v[i] / nrm;
+}
+
+hipError_t launch_ln_l2norm(const float* in, int64_t ld_in, const float* gamma, const float* beta, float eps,
+                            float* out, int64_t rows, int D, hipStream_t s) {
+    if (D != 768 || rows <= 0) return hipErrorInvalidValue;
+    hipLaunchKernelGGL((ln_l2norm_kernel<3>), dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, in, ld_in, gamma, beta, eps, out, rows);
+    return hipGetLastError();
+}
+
+// ---- im2col for Conv2d(3,768,k=14,s=14): TF:dinov2/modeling_dinov2.py:139-148 ----
+// out[b][tok][k], tok = 1 + py*gw + px, k = (c*14 + ky)*14 + kx; zero for tok==0, tok>=1+gh*gw, k>=C*P*P.
+template <typename T>
+__global__ __launch_bounds__(256) void im2col_kernel(const float* __restrict__ px, T* __restrict__ out, int B, int C,
+                                                     int Himg, int Wimg, int P, int gh, int gw, int n_pad, int k_pad) {
+    const int tok = blockIdx.x, b = blockIdx.y;
+    T* o = out + ((int64_t)b * n_pad + tok) * k_pad;
+    const int np = gh * gw;
+    const bool live = tok >= 1 && tok <= np;
+    const int p = tok - 1;
+    const int py = live ? p / gw : 0, pxx = live ? p % gw : 0;
+    const int kreal = C * P * P;
+    for (int kk = threadIdx.x; kk < k_pad; kk += blockDim.x) {
+        float v = 0.f;
+        if (live && kk < kreal) {
+            const int c = kk / (P * P), rem = kk - c * P * P;
+            const int ky = rem / P, kx = rem - ky * P;
+            v = px[(((int64_t)b * C + c) * Himg + (py * P + ky)) * Wimg + (pxx * P + kx)];
+        }
+        o[kk] = from_f32<T>(v);
+    }
+}
+
+hipError_t launch_im2col(int dtype, const float* px, void* out, int B, int C, int Himg, int Wimg, int patch, int gh,
+                         int gw, int n_pad, int k_pad, hipStream_t s) {
+    if (B <= 0 || gh * patch > Himg || gw * patch > Wimg || 1 + gh * gw > n_pad || C * patch * patch > k_pad) return hipErrorInvalidValue;
+    dim3 grid(n_pad, B), block(256);
+    switch (dtype) {
+        case DT_F32: hipLaunchKernelGGL(im2col_kernel<float>, grid, block, 0, s, px, (float*)out, B, C, Himg, Wimg, patch, gh, gw, n_pad, k_pad); break;
+        case DT_BF16: hipLaunchKernelGGL(im2col_kernel<bf16_t>, grid, block, 0, s, px, (bf16_t*)out, B, C, Himg, Wimg, patch, gh, gw, n_pad, k_pad); break;
+        case DT_F16: hipLaunchKernelGGL(im2col_kernel<f16_t>, grid, block, 0, s, px, (f16_t*)out, B, C, Himg, Wimg, patch, gh, gw, n_pad, k_pad); break;
+        default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+// ---- MPNet embeddings: TF:mpnet/modeling_mpnet.py:58-95, position ids :873-881 ----
+// position id = (number of non-pad tokens at or before i) * (ids[i] != pad) + pad
+template <typename T, int NV>
+__global__ __launch_bounds__(256) void text_embed_kernel(const int64_t* __restrict__ ids, const float* __restrict__ word_emb,
+                                                         const float* __restrict__ pos_emb, const float* __restrict__ gamma,
+                                                         const float* __restrict__ beta, float eps, float* __restrict__ h,
+                                                         T* __restrict__ xn, int Tn, int L, int vocab, int max_pos, int pad_id) {
+    constexpr int D = 256 * NV;
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= (int64_t)Tn * L) return;
+    const int t = (int)(row / L), i = (int)(row % L);
+    int cnt = 0;
+    for (int jj = lane; jj <= i; jj += 64) cnt += (ids[(int64_t)t * L + jj] != pad_id) ? 1 : 0;
+    cnt = (int)wave_sum((float)cnt);
+    int64_t id = ids[row];
+    int pos = (id != pad_id) ? cnt + pad_id : pad_id;
+    id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);        // host validates; clamp keeps the access in bounds
+    pos = pos >= max_pos ? max_pos - 1 : pos;
+    RowRegs<NV> r = load_row<NV>(word_emb + id * D, lane);
+    const RowRegs<NV> pe = load_row<NV>(pos_emb + (int64_t)pos * D, lane);
+#pragma unroll
+    for (int k = 0; k < NV; ++k) r.v[k] += pe.v[k];
+    row_layernorm<NV>(r, gamma, beta, eps, lane);
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+        const int c = (lane + 64 * k) * 4;
+        *reinterpret_cast<f32x4*>(h + row * D + c) = r.v[k];
+        *reinterpret_cast<typename Traits<T>::vec4*>(xn + row * D + c) = pack4<T>(r.v[k][0], r.v[k][1], r.v[k][2], r.v[k][3]);
+    }
+}
+
+hipError_t launch_text_embed(int dtype, const int64_t* ids, const float* word_emb, const float* pos_emb,
+                             const float* gamma, const float* beta, float eps, float* h, void* xn, int T, int L, int D,
+                             int vocab, int max_pos, int pad_id, hipStream_t s) {
+    if (D != 768 || T <= 0 || L <= 0) return hipErrorInvalidValue;
+    dim3 grid((unsigned)(((int64_t)T * L + 3) / 4)), block(256);
+    switch (dtype) {
+        case DT_F32: hipLaunchKernelGGL((text_embed_kernel<float, 3>), grid, block, 0, s, ids, word_emb, pos_emb, gamma, beta, eps, h, (float*)xn, T, L, vocab, max_pos, pad_id); break;
+        case DT_BF16: hipLaunchKernelGGL((text_embed_kernel<bf16_t, 3>), grid, block, 0, s, ids, word_emb, pos_emb, gamma, beta, eps, h, (bf16_t*)xn, T, L, vocab, max_pos, pad_id); break;
+        case DT_F16: hipLaunchKernelGGL((text_embed_kernel<f16_t, 3>), grid, block, 0, s, ids, word_emb, pos_emb, gamma, beta, eps, h, (f16_t*)xn, T, L, vocab, max_pos, pad_id); break;
+        default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+// ---- masked mean pool: exp/cxr_pt/model/modeling.py:148-156 ----
+__global__ __launch_bounds__(256) void masked_meanpool_kernel(const float* __restrict__ h, const int64_t* __restrict__ mask,
+                                                              float* __restrict__ out, int L, int D) {
+    const int t = blockIdx.x;
+    float msum = 0.f;
+    for (int i = 0; i < L; ++i) msum += (float)mask[(int64_t)t * L + i];
+    const float den = fmaxf(msum, 1e-9f);
+    for (int d = threadIdx.x; d < D; d += blockDim.x) {
+        float acc = 0.f;
+        for (int i = 0; i < L; ++i) acc += h[((int64_t)t * L + i) * D + d] * (float)mask[(int64_t)t * L + i];
+        out[(int64_t)t * D + d] = acc / den;
+    }
+}
+
+hipError_t launch_masked_meanpool(const float* h, const int64_t* mask, float* out, int T, int L, int D, hipStream_t s) {
+    if (T <= 0 || L <= 0) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(masked_meanpool_kernel, dim3(T), dim3(256), 0, s, h, mask, out, L, D);
+    return hipGetLastError();
+}
+
+// ---- compact copy of the valid tokens: [B][Npad][D] -> [B][N][D] ----
+__global__ __launch_bounds__(256) void copy_tokens_kernel(const float* __restrict__ src, float* __restrict__ dst, int n_valid,
+                                                          int n_pad, int D4) {
+    const int tok = blockIdx.x, b = blockIdx.y;
+    const f32x4* s4 = reinterpret_cast<const f32x4*>(src) + ((int64_t)b * n_pad + tok) * D4;
+    f32x4* d4 = reinterpret_cast<f32x4*>(dst) + ((int64_t)b * n_valid + tok) * D4;
+    for (int i = threadIdx.x; i < D4; i += blockDim.x) d4[i] = s4[i];
+}
+
+hipError_t launch_copy_tokens(const float* src, float* dst, int B, int n_valid, int n_pad, int D, hipStream_t s) {
+    if (D % 4) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(copy_tokens_kernel, dim3(n_valid, B), dim3(192), 0, s, src, dst, n_valid, n_pad, D / 4);
+    return hipGetLastError();
+}
+
+}  // namespace rz

@@ -1,0 +1,137 @@
+// radzero_hip — common device helpers for gfx950 (CDNA4) kernels.
+//
+// Conventions used by every MFMA kernel in this library:
+//  * Operand "fragment" = 8 K-contiguous elements per lane for one row/column (lane&15) of a 16-wide
+//    tile, K sub-block (lane>>4).  For 16-bit types that is exactly the v_mfma_f32_16x16x32 operand
+//    (16 B per lane); for f32 the same 8 elements (32 B per lane) feed 8 x v_mfma_f32_16x16x4_f32,
+//    element j of every lane forming one K=4 step.  A and B fragments have identical layout, so
+//    mma(a, b) computes D[row of a][col of b] and mma(b, a) its transpose.
+//  * D layout (all dtypes): lane holds D[row = 4*(lane>>4) + r][col = lane&15], r = 0..3.
+//  * LDS tiles are "panels" of [rows][128 bytes]; the 16-byte chunk c of row r is stored at chunk
+//    position c ^ ((r>>1)&7).  Two 128-B rows share one 256-B bank row, so this XOR makes the
+//    16 rows x 1 chunk pattern of an MFMA fragment read (ds_read_b128 / ds_read_b64) conflict-free.
+//    Tiles are filled by global_load_lds_dwordx4 (LDS image is lane-linear, the XOR is applied to the
+//    per-lane SOURCE address) and read back with the same XOR.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace rz {
+
+typedef __bf16 bf16_t;
+typedef _Float16 f16_t;
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x8 __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+
+enum DType : int { DT_F32 = 0, DT_BF16 = 1, DT_F16 = 2 };
+
+template <typename T> struct Traits;
+template <> struct Traits<float> {
+    typedef f32x8 frag;
+    typedef f32x4 vec4;
+    static constexpr int kDType = DT_F32;
+};
+template <> struct Traits<bf16_t> {
+    typedef bf16x8 frag;
+    typedef bf16x4 vec4;
+    static constexpr int kDType = DT_BF16;
+};
+template <> struct Traits<f16_t> {
+    typedef f16x8 frag;
+    typedef f16x4 vec4;
+    static constexpr int kDType = DT_F16;
+};
+
+// elements per 128-byte LDS panel row
+template <typename T> __host__ __device__ constexpr int panel_elems() { return 128 / (int)sizeof(T); }
+
+// ---- MFMA wrappers: acc += a (rows) x b (cols) over the fragment's 32 K-elements ----
+__device__ __forceinline__ f32x4 mma(const bf16x8& a, const bf16x8& b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ f32x4 mma(const f16x8& a, const f16x8& b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ f32x4 mma(const f32x8& a, const f32x8& b, f32x4 c) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) c = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j], b[j], c, 0, 0, 0);
+    return c;
+}
+
+// ---- conversions ----
+template <typename T> __device__ __forceinline__ T from_f32(float x);
+template <> __device__ __forceinline__ float from_f32<float>(float x) { return x; }
+template <> __device__ __forceinline__ bf16_t from_f32<bf16_t>(float x) { return (bf16_t)x; }
+template <> __device__ __forceinline__ f16_t from_f32<f16_t>(float x) { return (f16_t)x; }
+template <typename T> __device__ __forceinline__ float to_f32(T x) { return (float)x; }
+
+template <typename T> __device__ __forceinline__ typename Traits<T>::vec4 pack4(float a, float b, float c, float d) {
+    typename Traits<T>::vec4 v;
+    v[0] = from_f32<T>(a); v[1] = from_f32<T>(b); v[2] = from_f32<T>(c); v[3] = from_f32<T>(d);
+    return v;
+}
+
+// ---- LDS panel addressing ----
+// byte offset of 16-B chunk `c` (0..7) of row `r` inside a [rows][128 B] panel
+__device__ __forceinline__ int panel_off(int r, int c) { return r * 128 + ((c ^ ((r >> 1) & 7)) << 4); }
+
+// One wave fills 8 consecutive panel rows (1 KiB) with one global_load_lds_dwordx4.
+//  lds_wave_base : wave-uniform LDS address of panel row `row8` (multiple of 8)
+//  gsrc_row0     : global address of (tile row 0, panel byte 0); row stride `ld_bytes`
+// Lane l lands at LDS row row8 + (l>>3), chunk position (l&7); it must therefore FETCH global chunk
+// (l&7) ^ ((row>>1)&7) of that row.
+__device__ __forceinline__ void glds_rows8(char* lds_wave_base, const char* gsrc_row0, int64_t ld_bytes, int row8, int lane) {
+    const int r = row8 + (lane >> 3);
+    const int c = (lane & 7) ^ ((r >> 1) & 7);
+    const char* src = gsrc_row0 + (int64_t)r * ld_bytes + (c << 4);
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+// Read one fragment (row = r, K sub-block kb of width 8 elements) from a panel.
+// 16-bit: chunk index = kb (8 elem = 16 B).  f32: chunks 2kb, 2kb+1.
+template <typename T> __device__ __forceinline__ typename Traits<T>::frag lds_frag(const char* panel, int r, int kb);
+template <> __device__ __forceinline__ bf16x8 lds_frag<bf16_t>(const char* panel, int r, int kb) {
+    return *reinterpret_cast<const bf16x8*>(panel + panel_off(r, kb));
+}
+template <> __device__ __forceinline__ f16x8 lds_frag<f16_t>(const char* panel, int r, int kb) {
+    return *reinterpret_cast<const f16x8*>(panel + panel_off(r, kb));
+}
+template <> __device__ __forceinline__ f32x8 lds_frag<float>(const char* panel, int r, int kb) {
+    f32x4 lo = *reinterpret_cast<const f32x4*>(panel + panel_off(r, 2 * kb));
+    f32x4 hi = *reinterpret_cast<const f32x4*>(panel + panel_off(r, 2 * kb + 1));
+    f32x8 v;
+    v[0] = lo[0]; v[1] = lo[1]; v[2] = lo[2]; v[3] = lo[3];
+    v[4] = hi[0]; v[5] = hi[1]; v[6] = hi[2]; v[7] = hi[3];
+    return v;
+}
+
+// ---- wave reductions (64 lanes) ----
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+
+// XCD-aware remap of a linear workgroup id: consecutive `group`-sized runs of logical ids land on one
+// XCD (blocks b and b+8 share an XCD under round-robin dispatch).  Bijective for any n.
+__device__ __forceinline__ int xcd_remap(int bid, int n) {
+    const int q = n >> 3, r = n & 7, x = bid & 7, j = bid >> 3;
+    return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + j;
+}
+
+}  // namespace rz

@@ -1,0 +1,82 @@
+// radzero_hip — internal kernel launcher interface (host side).  The public C-ABI is include/radzero_hip.h.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace rz {
+
+enum Epilogue : int {
+    EPI_STORE = 0,        // out<T>[m][n] = acc + bias
+    EPI_GELU = 1,         // out<T>[m][n] = gelu_erf(acc + bias)
+    EPI_HEADS = 2,        // out<T>[b][head][tok][64] = acc + bias            (q | k projection)
+    EPI_VT = 3,           // out<T>[b][head][d][tok]  = acc + bias            (v projection, transposed)
+    EPI_RESID_SCALE = 4,  // resid[m][n] += scale[n] * (acc + bias)          (LayerScale + residual, pre-LN blocks)
+    EPI_RESID_ADD = 5,    // out_f32[m][n] = acc + bias + resid[m][n]        (post-LN blocks)
+    EPI_PATCH = 6,        // out_f32[m][n] = acc + scale[tok][n]             (patch-embed: pos/cls/bias table)
+    EPI_STORE_F32 = 7,    // out_f32[m][n] = acc + bias
+};
+
+struct GemmArgs {
+    const void* A; int64_t lda;   // [M][K], leading dim in elements
+    const void* W; int64_t ldw;   // [N][K]
+    int M, N, K;
+    const float* bias;            // [N] or nullptr
+    void* out; int64_t ldo;
+    const float* scale;           // EPI_RESID_SCALE: lambda[N]; EPI_PATCH: table [rows_per_image][N]
+    float* resid; int64_t ldr;    // fp32 residual stream
+    int rows_per_image;           // padded tokens per image (EPI_HEADS / EPI_VT / EPI_PATCH)
+    int heads_total;              // heads in the destination tensor (EPI_HEADS / EPI_VT)
+};
+
+hipError_t launch_gemm(int dtype, int epi, const GemmArgs& g, hipStream_t s);
+
+// Flash attention over per-head tensors: q,k [B][H][Npad][64], vT [B][H][64][Npad] -> ctx [B*Npad][H*64].
+// Scores are NOT rescaled inside (1/sqrt(dh) is folded into the packed q weights).
+// q/k of image b start at q + b*qk_batch_stride (elements), heads contiguous ([H][Npad][64]).
+hipError_t launch_flash_attn(int dtype, const void* q, const void* k, const void* vT, void* ctx,
+                             int64_t qk_batch_stride, int B, int H, int n_valid, int n_pad, hipStream_t s);
+
+// MPNet self-attention for short sequences: qkv [T*L][3*H*64] (q|k|v), additive relative-position bias
+// rel_bias[H][num_buckets] via bucket table [L][L] and key-padding mask [T][L]; ctx [T*L][H*64].
+hipError_t launch_text_attn(int dtype, const void* qkv, const float* rel_bias, const int* bucket_tbl,
+                            const int64_t* attn_mask, void* ctx, int T, int L, int H, int num_buckets,
+                            hipStream_t s);
+
+// LayerNorm over rows of 768: fp32 in; writes T-typed normalized copy (out_t, may be null) and/or
+// fp32 (out_f32, may alias in).
+hipError_t launch_layernorm(int dtype, const float* in, const float* gamma, const float* beta, float eps,
+                            void* out_t, float* out_f32, int64_t rows, int D, hipStream_t s);
+
+// im2col for the 14x14/stride-14 patch conv: pixels fp32 [B][C][H][W] -> A<T>[B][Npad][Kpad];
+// row 0 (CLS) and rows >= 1+gh*gw are zero; columns >= C*14*14 are zero.
+hipError_t launch_im2col(int dtype, const float* px, void* out, int B, int C, int Himg, int Wimg, int patch,
+                         int gh, int gw, int n_pad, int k_pad, hipStream_t s);
+
+// MPNet embeddings: word_emb[ids] + pos_emb[pos_ids(ids)] -> LN -> h fp32 + T copy.
+hipError_t launch_text_embed(int dtype, const int64_t* ids, const float* word_emb, const float* pos_emb,
+                             const float* gamma, const float* beta, float eps, float* h, void* xn,
+                             int T, int L, int D, int vocab, int max_pos, int pad_id, hipStream_t s);
+
+// masked mean pool: h [T][L][D] fp32, mask [T][L] -> out [T][D]
+hipError_t launch_masked_meanpool(const float* h, const int64_t* mask, float* out, int T, int L, int D, hipStream_t s);
+
+// shared LN + L2 normalise rows (fp32 -> fp32).  in rows have stride ld_in.
+hipError_t launch_ln_l2norm(const float* in, int64_t ld_in, const float* gamma, const float* beta, float eps,
+                            float* out, int64_t rows, int D, hipStream_t s);
+
+// VL-CABS: vhat [B][Npad][D] (LN+L2-normalised tokens), qhat [T][D] -> scores [B][T][N] (= cos/tau),
+// t2i_logits [T][B], logits [B][T] (= t2i^T / tau).  ws: float workspace.
+size_t vlcabs_workspace_floats(int B, int T, int n_pad, int D);
+hipError_t launch_vlcabs(const float* tokens, const float* ln_gamma, const float* ln_beta, float ln_eps,
+                         const float* qhat, float tau, float* vhat, float* ws, float* scores, float* t2i_logits,
+                         float* logits, int B, int T, int n_valid, int n_pad, int D, hipStream_t s);
+
+// bilinear upsample (align_corners=False) of patch-grid maps [M][g][g] -> [M][H][W], optional sigmoid;
+// optional per-map argmax (flat index of first max) -> argmax_out[M].
+hipError_t launch_upsample_bilinear(const float* maps, int64_t map_stride, float* out, int64_t* argmax_out, int M, int g,
+                                    int Hout, int Wout, int apply_sigmoid, hipStream_t s);
+
+// strided gather of valid tokens: src [B][Npad][D] -> dst [B][N][D]
+hipError_t launch_copy_tokens(const float* src, float* dst, int B, int n_valid, int n_pad, int D, hipStream_t s);
+
+}  // namespace rz

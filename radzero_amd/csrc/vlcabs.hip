@@ -1,0 +1,231 @@
+// radzero_hip — VL-CABS head (the reference's own arithmetic: exp/cxr_pt/model/losses.py:71-105 and
+// SimilarityLogit :187-240, final scaling exp/cxr_pt/model/modeling.py:311-328), always in fp32.
+//
+//   vhat  = l2norm(LN_shared(tokens))                     (losses.py:90-91, :213)      [scores kernel]
+//   S     = qhat . vhat / tau                             (losses.py:219-221)          [scores kernel]
+//   p     = softmax_N(S); agg = p . vhat                  (losses.py:222-224)          [partial + finalize]
+//   logit = qhat . agg/||agg||                            (losses.py:226-233)          [finalize]
+//
+// Softmax over N tokens is split into 128-token chunks (online-softmax partials m, l, agg[D]) that the
+// finalize kernel merges, so the token tensor is streamed once per stage and nothing of size N x N exists.
+// Also: bilinear similarity-map upsample (exp/cxr_pt/inference/segmentation_utils.py:62-70).
+#include "rz_common.h"
+#include "rz_kernels.h"
+
+namespace rz {
+
+constexpr int VC_ROWS = 64;     // token rows per workgroup in the scores kernel
+constexpr int VC_CHUNK = 128;   // token rows per softmax chunk
+constexpr int VC_TG = 16;       // prompts per workgroup in the partial kernel
+
+// ---- scores: one wave per token row ----
+__global__ __launch_bounds__(256) void vlcabs_scores_kernel(const float* __restrict__ tokens, const float* __restrict__ gamma,
+                                                            const float* __restrict__ beta, float eps,
+                                                            const float* __restrict__ qhat, float inv_tau,
+                                                            float* __restrict__ vhat, float* __restrict__ scores, int T,
+                                                            int n_valid, int n_pad) {
+    extern __shared__ float sc[];   // [T][VC_ROWS]
+    constexpr int D = 768;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int b = blockIdx.y, row0 = blockIdx.x * VC_ROWS;
+    for (int rr = 0; rr < VC_ROWS / 4; ++rr) {
+        const int rl = wave * (VC_ROWS / 4) + rr;
+        const int64_t row = (int64_t)b * n_pad + row0 + rl;
+        f32x4 v[3];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) v[i] = *reinterpret_cast<const f32x4*>(tokens + row * D + (lane + 64 * i) * 4);
+        // shared LayerNorm (eps 1e-5), two-pass
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
+        const float mu = wave_sum(s) * (1.0f / D);
+        float q = 0.f;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            v[i] -= mu;
+            q += (v[i][0] * v[i][0] + v[i][1] * v[i][1]) + (v[i][2] * v[i][2] + v[i][3] * v[i][3]);
+        }
+        const float rstd = rsqrtf(wave_sum(q) * (1.0f / D) + eps);
+        float n2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const f32x4 g = *reinterpret_cast<const f32x4*>(gamma + (lane + 64 * i) * 4);
+            const f32x4 be = *reinterpret_cast<const f32x4*>(beta + (lane + 64 * i) * 4);
+            v[i] = v[i] * rstd * g + be;
+            n2 += (v[i][0] * v[i][0] + v[i][1] * v[i][1]) + (v[i][2] * v[i][2] + v[i][3] * v[i][3]);
+        }
+        const float inv = 1.0f / fmaxf(sqrtf(wave_sum(n2)), 1e-12f);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            v[i] *= inv;
+            *reinterpret_cast<f32x4*>(vhat + row * D + (lane + 64 * i) * 4) = v[i];
+        }
+        for (int t = 0; t < T; ++t) {
+            float d = 0.f;
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                const f32x4 qv = *reinterpret_cast<const f32x4*>(qhat + (int64_t)t * D + (lane + 64 * i) * 4);
+                d += (qv[0] * v[i][0] + qv[1] * v[i][1]) + (qv[2] * v[i][2] + qv[3] * v[i][3]);
+            }
+            d = wave_sum(d);
+            if (lane == 0) sc[t * VC_ROWS + rl] = d * inv_tau;
+        }
+    }
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < T * VC_ROWS; idx += 256) {
+        const int t = idx / VC_ROWS, r = idx % VC_ROWS;
+        const int tok = row0 + r;
+        if (tok < n_valid) scores[((int64_t)b * T + t) * n_valid + tok] = sc[idx];
+    }
+}
+
+// ---- per-chunk online-softmax partials: ws[b][chunk][t] = {m, l, agg[768]} ----
+__global__ __launch_bounds__(256) void vlcabs_partial_kernel(const float* __restrict__ vhat, const float* __restrict__ scores,
+                                                             float* __restrict__ ws, int T, int n_valid, int n_pad) {
+    constexpr int D = 768, REC = D + 2;
+    __shared__ float p[VC_TG][VC_CHUNK];
+    __shared__ float mstat[VC_TG], lstat[VC_TG];
+    const int tid = threadIdx.x;
+    const int c = blockIdx.x, b = blockIdx.y, t0 = blockIdx.z * VC_TG;
+    const int nchunks = gridDim.x;
+    const int row0 = c * VC_CHUNK;
+    // step 1: 16 threads per prompt, 8 rows each
+    {
+        const int tl = tid >> 4, sub = tid & 15;
+        const int t = t0 + tl;
+        float sv[8];
+        float mx = -INFINITY;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int tok = row0 + sub + 16 * i;
+            sv[i] = (t < T && tok < n_valid) ? scores[((int64_t)b * T + t) * n_valid + tok] : -INFINITY;
+            mx = fmaxf(mx, sv[i]);
+        }
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+        float sum = 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const float e = (mx == -INFINITY) ? 0.f : expf(sv[i] - mx);
+            p[tl][sub + 16 * i] = e;
+            sum += e;
+        }
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
+        if (sub == 0) { mstat[tl] = mx; lstat[tl] = sum; }
+    }
+    __syncthreads();
+    // step 2: thread owns columns tid, tid+256, tid+512
+    float acc[VC_TG][3];
+#pragma unroll
+    for (int t = 0; t < VC_TG; ++t) acc[t][0] = acc[t][1] = acc[t][2] = 0.f;
+    const float* vb = vhat + ((int64_t)b * n_pad + row0) * D;
+    for (int r = 0; r < VC_CHUNK; ++r) {
+        const float v0 = vb[(int64_t)r * D + tid], v1 = vb[(int64_t)r * D + tid + 256], v2 = vb[(int64_t)r * D + tid + 512];
+#pragma unroll
+        for (int t = 0; t < VC_TG; ++t) {
+            const float pw = p[t][r];
+            acc[t][0] = fmaf(pw, v0, acc[t][0]);
+            acc[t][1] = fmaf(pw, v1, acc[t][1]);
+            acc[t][2] = fmaf(pw, v2, acc[t][2]);
+        }
+    }
+#pragma unroll
+    for (int tl = 0; tl < VC_TG; ++tl) {
+        const int t = t0 + tl;
+        if (t >= T) break;
+        float* rec = ws + (((int64_t)b * nchunks + c) * T + t) * REC;
+        if (tid == 0) { rec[0] = mstat[tl]; rec[1] = lstat[tl]; }
+        rec[2 + tid] = acc[tl][0];
+        rec[2 + tid + 256] = acc[tl][1];
+        rec[2 + tid + 512] = acc[tl][2];
+    }
+}
+
+__device__ __forceinline__ float block_sum_256(float v, float* red) {
+    v = wave_sum(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+// ---- merge chunks, normalise, dot with qhat ----
+__global__ __launch_bounds__(256) void vlcabs_finalize_kernel(const float* __restrict__ ws, const float* __restrict__ qhat,
+                                                              float tau, float* __restrict__ t2i_logits,
+                                                              float* __restrict__ logits, int T, int B, int nchunks) {
+    constexpr int D = 768, REC = D + 2;
+    __shared__ float red[4];
+    const int t = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+    float M = -INFINITY;
+    for (int c = 0; c < nchunks; ++c) M = fmaxf(M, ws[(((int64_t)b * nchunks + c) * T + t) * REC]);
+    float L = 0.f, a0 = 0.f, a1 = 0.f, a2 = 0.f;
+    for (int c = 0; c < nchunks; ++c) {
+        const float* rec = ws + (((int64_t)b * nchunks + c) * T + t) * REC;
+        const float w = expf(rec[0] - M);
+        L += w * rec[1];
+        a0 = fmaf(w, rec[2 + tid], a0);
+        a1 = fmaf(w, rec[2 + tid + 256], a1);
+        a2 = fmaf(w, rec[2 + tid + 512], a2);
+    }
+    const float invL = 1.0f / L;
+    a0 *= invL; a1 *= invL; a2 *= invL;
+    const float n2 = block_sum_256(a0 * a0 + a1 * a1 + a2 * a2, red);
+    const float* qv = qhat + (int64_t)t * D;
+    const float dot = block_sum_256(qv[tid] * a0 + qv[tid + 256] * a1 + qv[tid + 512] * a2, red);
+    if (tid == 0) {
+        const float lg = dot / fmaxf(sqrtf(n2), 1e-12f);
+        t2i_logits[(int64_t)t * B + b] = lg;
+        logits[(int64_t)b * T + t] = lg / tau;
+    }
+}
+
+size_t vlcabs_workspace_floats(int B, int T, int n_pad, int D) {
+    return (size_t)B * (n_pad / VC_CHUNK) * T * (D + 2);
+}
+
+hipError_t launch_vlcabs(const float* tokens, const float* ln_gamma, const float* ln_beta, float ln_eps,
+                         const float* qhat, float tau, float* vhat, float* ws, float* scores, float* t2i_logits,
+                         float* logits, int B, int T, int n_valid, int n_pad, int D, hipStream_t s) {
+    if (D != 768 || B <= 0 || T <= 0 || n_pad % VC_CHUNK || n_valid > n_pad) return hipErrorInvalidValue;
+    const size_t shm = (size_t)T * VC_ROWS * sizeof(float);
+    if (shm > 120 * 1024) return hipErrorInvalidValue;   // T <= 480 per call
+    hipLaunchKernelGGL(vlcabs_scores_kernel, dim3(n_pad / VC_ROWS, B), dim3(256), shm, s, tokens, ln_gamma, ln_beta, ln_eps,
+                       qhat, 1.0f / tau, vhat, scores, T, n_valid, n_pad);
+    const int nchunks = n_pad / VC_CHUNK;
+    hipLaunchKernelGGL(vlcabs_partial_kernel, dim3(nchunks, B, (T + VC_TG - 1) / VC_TG), dim3(256), 0, s, vhat, scores, ws, T,
+                       n_valid, n_pad);
+    hipLaunchKernelGGL(vlcabs_finalize_kernel, dim3(T, B), dim3(256), 0, s, ws, qhat, tau, t2i_logits, logits, T, B, nchunks);
+    return hipGetLastError();
+}
+
+// ---- bilinear upsample, align_corners=False (F.interpolate semantics), optional sigmoid ----
+__global__ __launch_bounds__(256) void upsample_bilinear_kernel(const float* __restrict__ maps, int64_t map_stride,
+                                                                float* __restrict__ out, int g, int Hout, int Wout,
+                                                                float sy, float sx, int apply_sigmoid) {
+    const int m = blockIdx.z;
+    const int y = blockIdx.y;
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    if (x >= Wout) return;
+    const float* src = maps + (int64_t)m * map_stride;
+    float fy = sy * (y + 0.5f) - 0.5f; fy = fy < 0.f ? 0.f : fy;
+    float fx = sx * (x + 0.5f) - 0.5f; fx = fx < 0.f ? 0.f : fx;
+    const int y0 = (int)fy, x0 = (int)fx;
+    const int y1 = y0 + (y0 < g - 1 ? 1 : 0), x1 = x0 + (x0 < g - 1 ? 1 : 0);
+    const float ly = fy - y0, lx = fx - x0;
+    const float hy = 1.f - ly, hx = 1.f - lx;
+    float v = hy * (hx * src[y0 * g + x0] + lx * src[y0 * g + x1]) + ly * (hx * src[y1 * g + x0] + lx * src[y1 * g + x1]);
+    if (apply_sigmoid) v = 1.0f / (1.0f + expf(-v));
+    out[((int64_t)m * Hout + y) * Wout + x] = v;
+}
+
+hipError_t launch_upsample_bilinear(const float* maps, int64_t map_stride, float* out, int64_t* argmax_out, int M, int g,
+                                    int Hout, int Wout, int apply_sigmoid, hipStream_t s) {
+    if (M <= 0 || g <= 0 || Hout <= 0 || Wout <= 0 || argmax_out != nullptr) return hipErrorInvalidValue;
+    const float sy = (float)g / (float)Hout, sx = (float)g / (float)Wout;
+    hipLaunchKernelGGL(upsample_bilinear_kernel, dim3((Wout + 255) / 256, Hout, M), dim3(256), 0, s, maps, map_stride, out, g,
+                       Hout, Wout, sy, sx, apply_sigmoid);
+    return hipGetLastError();
+}
+
+}  // namespace rz

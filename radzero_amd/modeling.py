@@ -1,0 +1,324 @@
+"""Host-side mirror of the reference's model object for the VL-CABS inference path.
+
+`RadZeroModel` presents the protocol every in-repo caller of the reference uses
+(exp/cxr_pt/inference/utils.py:95-100, grounding_utils.py:58-62, visualization/attention_map_base.py:32):
+`compute_logits(pixel_values, [encoded_key_phrases], **ignored)`, `forward_vision_model`,
+`forward_text_model`, `.device`, `.eval()`, `.to()`; the arithmetic runs in libradzero_hip.so
+(include/radzero_hip.h) — PyTorch is used here only for device memory, streams and tiny host-side tables.
+Reference: exp/cxr_pt/model/modeling.py:22-356 (CxrAlignModel), losses.py:33-240.
+"""
+from __future__ import annotations
+
+import ctypes
+import math
+from typing import Dict, Optional
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from . import _lib
+from .config import RadZeroConfig
+
+_DTYPES = {torch.float32: _lib.RZ_F32, torch.bfloat16: _lib.RZ_BF16, torch.float16: _lib.RZ_F16}
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def interpolate_pos_encoding(position_embeddings: torch.Tensor, grid_h: int, grid_w: int) -> torch.Tensor:
+    """One-time host op per resolution: bicubic resize of the stored patch position grid, CLS kept
+    (TF:dinov2/modeling_dinov2.py:57-95).  Returns (1 + grid_h*grid_w, D) fp32 on the CPU."""
+    pe = position_embeddings.detach().float().cpu()
+    if pe.dim() == 3:
+        pe = pe[0]
+    npos = pe.shape[0] - 1
+    g0 = int(round(math.sqrt(npos)))
+    if grid_h * grid_w == npos and grid_h == grid_w:
+        return pe.contiguous()
+    d = pe.shape[-1]
+    grid = pe[1:].reshape(1, g0, g0, d).permute(0, 3, 1, 2)
+    grid = F.interpolate(grid, size=(grid_h, grid_w), mode="bicubic", align_corners=False)
+    grid = grid.permute(0, 2, 3, 1).reshape(grid_h * grid_w, d)
+    return torch.cat([pe[:1], grid], dim=0).contiguous()
+
+
+def relative_position_bias(rel_weight: torch.Tensor, seq_len: int, max_distance: int = 128) -> torch.Tensor:
+    """MPNetEncoder.compute_position_bias (TF:mpnet/modeling_mpnet.py:312-348) -> (heads, L, L) fp32 CPU.
+    Depends only on L, so it is computed once per prompt length on the host."""
+    w = rel_weight.detach().float().cpu()
+    num_buckets = w.shape[0]
+    ctx = torch.arange(seq_len, dtype=torch.long)[:, None]
+    mem = torch.arange(seq_len, dtype=torch.long)[None, :]
+    n = ctx - mem                                   # = -(memory - context)
+    half = num_buckets // 2
+    bucket = (n < 0).long() * half
+    n = n.abs()
+    max_exact = half // 2
+    small = n < max_exact
+    large = max_exact + (torch.log(n.float() / max_exact) / math.log(max_distance / max_exact) * (half - max_exact)).long()
+    large = torch.clamp(large, max=half - 1)
+    bucket = bucket + torch.where(small, n, large)
+    return w[bucket].permute(2, 0, 1).contiguous()   # (H, L, L)
+
+
+class RadZeroModel:
+    """Drop-in for `CxrAlignModel` on the inference path (compute_logits_type == "radzero")."""
+
+    def __init__(self, config: Optional[RadZeroConfig] = None, torch_dtype: torch.dtype = torch.bfloat16,
+                 device: str | torch.device = "cuda:0"):
+        self.config = config or RadZeroConfig()
+        if self.config.sim_op != "cos":
+            raise NotImplementedError("only sim_op == 'cos' (released RadZero config) is implemented")
+        self.dtype = torch_dtype
+        self._device = torch.device(device)
+        if self._device.type != "cuda":
+            raise RuntimeError("RadZeroModel runs on an AMD GPU through libradzero_hip.so; there is no CPU path")
+        if not torch.cuda.is_available():
+            raise RuntimeError("no HIP device visible: radzero_amd has no CPU / PyTorch fallback")
+        self._lib = _lib.load()
+        self._h = ctypes.c_void_p()
+        self._state_dict = None
+        self._pos_embed = None
+        self._rel_weight = None
+        self._grids = set()
+        self._rel_bias_cache: Dict[int, torch.Tensor] = {}
+        self._text_cache: Dict[bytes, torch.Tensor] = {}
+        self.text_cache_enabled = True
+        self._reserved = (0, 0, 0, 0)
+        self.training = False
+        self._create()
+
+    # ---- lifecycle ---------------------------------------------------------------------------
+    def _create(self):
+        c = self.config
+        rc = _lib.RzConfig(
+            compute_dtype=_DTYPES[self.dtype], hidden_size=c.hidden_size, num_attention_heads=c.num_attention_heads,
+            mlp_ratio=c.mlp_ratio, patch_size=c.patch_size, num_channels=c.num_channels, vit_layers=c.vit_layers,
+            align_layers=c.align_layers, vit_layer_norm_eps=c.vit_layer_norm_eps, vocab_size=c.vocab_size,
+            max_position_embeddings=c.max_position_embeddings, text_layers=c.text_layers,
+            text_intermediate_size=c.text_intermediate_size, text_layer_norm_eps=c.text_layer_norm_eps,
+            pad_token_id=c.pad_token_id, shared_layer_norm_eps=c.shared_layer_norm_eps)
+        with torch.cuda.device(self._device):
+            _lib.check(self._lib.rz_create(ctypes.byref(rc), ctypes.byref(self._h)), "rz_create")
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            with torch.cuda.device(self._device):
+                self._lib.rz_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @classmethod
+    def from_state_dict(cls, state_dict, config: Optional[RadZeroConfig] = None, torch_dtype=torch.bfloat16,
+                        device="cuda:0") -> "RadZeroModel":
+        m = cls(config, torch_dtype, device)
+        m.load_state_dict(state_dict)
+        return m
+
+    def load_state_dict(self, state_dict, strict: bool = True):
+        """Accepts the reference checkpoint's names (numpy arrays or torch tensors, any float dtype)."""
+        self._state_dict = state_dict
+        with torch.cuda.device(self._device):
+            for name, value in state_dict.items():
+                a = value.detach().float().cpu().numpy() if isinstance(value, torch.Tensor) else np.asarray(value, np.float32)
+                a = np.ascontiguousarray(a, dtype=np.float32)
+                if name == "vision_model.embeddings.position_embeddings":
+                    self._pos_embed = torch.from_numpy(a.copy())
+                elif name == "text_model.encoder.relative_attention_bias.weight":
+                    self._rel_weight = torch.from_numpy(a.copy())
+                _lib.check(self._lib.rz_load_weight(self._h, name.encode(), a.ctypes.data_as(ctypes.c_void_p), a.size),
+                           f"rz_load_weight({name})")
+            if strict:
+                _lib.check(self._lib.rz_weights_ready(self._h), "rz_weights_ready")
+                if self._pos_embed is None or self._rel_weight is None:
+                    raise _lib.RzError("checkpoint lacks position_embeddings / relative_attention_bias")
+        self._grids.clear()
+        self._rel_bias_cache.clear()
+        self._text_cache.clear()
+        return self
+
+    # ---- nn.Module-like surface used by the reference's callers -------------------------------
+    @property
+    def device(self) -> torch.device:
+        return self._device
+
+    def eval(self):
+        self.training = False
+        return self
+
+    def to(self, *args, **kwargs):
+        """`model.to(torch.float32)` (inference/utils.py:37) re-packs the weights in the new compute dtype."""
+        dtype = kwargs.get("dtype")
+        device = kwargs.get("device")
+        for a in args:
+            if isinstance(a, torch.dtype):
+                dtype = a
+            elif isinstance(a, (str, torch.device)):
+                device = a
+        if device is not None and torch.device(device) != self._device and torch.device(device).type != "cuda":
+            raise RuntimeError("RadZeroModel cannot be moved off the GPU (no CPU path)")
+        new_device = torch.device(device) if device is not None else self._device
+        if (dtype is not None and dtype != self.dtype) or new_device != self._device:
+            if dtype is not None and dtype not in _DTYPES:
+                raise NotImplementedError(f"unsupported dtype {dtype}")
+            sd = self._state_dict
+            self.close()
+            self.dtype = dtype or self.dtype
+            self._device = new_device
+            self._reserved = (0, 0, 0, 0)
+            self._create()
+            if sd is not None:
+                self.load_state_dict(sd)
+        return self
+
+    def float(self):
+        return self.to(torch.float32)
+
+    # ---- internals -----------------------------------------------------------------------------
+    def _stream(self):
+        return ctypes.c_void_p(torch.cuda.current_stream(self._device).cuda_stream)
+
+    def _ensure(self, batch=0, tokens=0, prompts=0, plen=0):
+        r = self._reserved
+        if batch > r[0] or tokens > r[1] or prompts > r[2] or plen > r[3]:
+            new = (max(batch, r[0]), max(tokens, r[1]), max(prompts, r[2]), max(plen, r[3]))
+            torch.cuda.synchronize(self._device)
+            _lib.check(self._lib.rz_reserve(self._h, *new), "rz_reserve")
+            self._reserved = new
+
+    def _ensure_grid(self, gh, gw):
+        if (gh, gw) not in self._grids:
+            if self._pos_embed is None:
+                raise _lib.RzError("weights not loaded")
+            table = interpolate_pos_encoding(self._pos_embed, gh, gw).numpy()
+            torch.cuda.synchronize(self._device)
+            _lib.check(self._lib.rz_set_position_table(self._h, gh, gw, table.ctypes.data_as(ctypes.c_void_p)),
+                       "rz_set_position_table")
+            self._grids.add((gh, gw))
+
+    def _vision(self, pixel_values: torch.Tensor, want_tokens: bool):
+        if pixel_values.dim() != 4:
+            raise ValueError("pixel_values must be (batch, channels, height, width)")
+        px = pixel_values.to(device=self._device, dtype=torch.float32).contiguous()
+        b, c, hh, ww = px.shape
+        p = self.config.patch_size
+        gh, gw = hh // p, ww // p
+        n = gh * gw + 1
+        with torch.cuda.device(self._device):
+            if c == self.config.num_channels and gh > 0 and gw > 0 and b > 0:
+                self._ensure_grid(gh, gw)
+                self._ensure(batch=b, tokens=n)
+            tokens = torch.empty((b, n, self.config.hidden_size), dtype=torch.float32, device=self._device) if want_tokens else None
+            _lib.check(self._lib.rz_vision_forward(self._h, _ptr(px), b, c, hh, ww, _ptr(tokens), self._stream()),
+                       "rz_vision_forward")
+        return tokens, (b, n)
+
+    # ---- CxrAlignModel.forward_vision_model (modeling.py:96-123) -------------------------------
+    @torch.no_grad()
+    def forward_vision_model(self, pixel_values):
+        tokens, _ = self._vision(pixel_values, want_tokens=True)
+        cls_token = tokens[:, 0]
+        patch_tokens = tokens[:, 1:]
+        image_features = F.normalize(torch.cat([cls_token, patch_tokens.mean(dim=1)], dim=1), p=2, dim=1)
+        return {"vision_tokens": tokens, "image_cls_token": cls_token, "image_patch_tokens": patch_tokens,
+                "image_features": image_features}
+
+    # ---- CxrAlignModel.forward_text_model, MPNet branch (modeling.py:125-211) ------------------
+    @torch.no_grad()
+    def forward_text_model(self, encoded_input):
+        ids = encoded_input["input_ids"].to(device=self._device, dtype=torch.int64).contiguous()
+        mask = encoded_input["attention_mask"].to(device=self._device, dtype=torch.int64).contiguous()
+        if ids.dim() != 2 or ids.shape != mask.shape:
+            raise ValueError("input_ids / attention_mask must be (n_prompts, len) and agree")
+        t, l = ids.shape
+        if int(ids.min()) < 0 or int(ids.max()) >= self.config.vocab_size:
+            raise IndexError("index out of range in self")          # nn.Embedding's error for bad token ids
+        with torch.cuda.device(self._device):
+            if l not in self._rel_bias_cache:
+                self._rel_bias_cache[l] = relative_position_bias(self._rel_weight, l).to(self._device)
+            self._ensure(prompts=t, plen=l)
+            feat = torch.empty((t, self.config.hidden_size), dtype=torch.float32, device=self._device)
+            _lib.check(self._lib.rz_text_forward(self._h, _ptr(ids), _ptr(mask), t, l, _ptr(self._rel_bias_cache[l]),
+                                                 _ptr(feat), self._stream()), "rz_text_forward")
+        return {"text_features_wo_l2_norm": feat, "text_features": F.normalize(feat, p=2, dim=1)}
+
+    def encode_prompts(self, encoded) -> torch.Tensor:
+        """text_features_wo_l2_norm for a prompt set, cached: the reference re-encodes every prompt for every
+        image batch (modeling.py:290-307); the embeddings do not depend on the images."""
+        ids = encoded["input_ids"]
+        mask = encoded["attention_mask"]
+        key = None
+        if self.text_cache_enabled:
+            key = ids.detach().cpu().numpy().tobytes() + b"|" + mask.detach().cpu().numpy().tobytes() + str(tuple(ids.shape)).encode()
+            hit = self._text_cache.get(key)
+            if hit is not None:
+                return hit
+        feat = self.forward_text_model({"input_ids": ids, "attention_mask": mask})["text_features_wo_l2_norm"]
+        if key is not None:
+            self._text_cache[key] = feat
+        return feat
+
+    # ---- CxrAlignModel.compute_logits, compute_logits_type == "radzero" (modeling.py:278-328) ---
+    @torch.no_grad()
+    def compute_logits(self, pixel_values, encoded_key_phrases, text_features: Optional[torch.Tensor] = None, **kwargs):
+        """kwargs (encoded_negative_phrases, use_negative_logits, ...) are accepted and ignored, as in the
+        reference (modeling.py:282).  `text_features` lets a data-parallel driver pass all-gathered embeddings."""
+        if text_features is None:
+            text_features = self.encode_prompts(encoded_key_phrases[0])
+        text_features = text_features.to(device=self._device, dtype=torch.float32).contiguous()
+        t = text_features.shape[0]
+        _, (b, n) = self._vision(pixel_values, want_tokens=False)
+        with torch.cuda.device(self._device):
+            self._ensure(batch=b, tokens=n, prompts=t)
+            scores = torch.empty((b, t, n), dtype=torch.float32, device=self._device)
+            t2i = torch.empty((t, b), dtype=torch.float32, device=self._device)
+            logits = torch.empty((b, t), dtype=torch.float32, device=self._device)
+            _lib.check(self._lib.rz_vlcabs(self._h, _ptr(text_features), t, b, _ptr(scores), _ptr(t2i), _ptr(logits),
+                                           self._stream()), "rz_vlcabs")
+        outputs = {"t2i_attn_weights": [scores]}
+        # mean over the (single-element) list, then drop the CLS column (modeling.py:311-317)
+        outputs["similarity_scores"] = scores[:, :, 1:] if self.config.use_vision_cls_token else scores
+        # the reference's `.squeeze()` in SimilarityLogit (losses.py:229-233) collapses B==1 / T==1:
+        t2i_sq = t2i.squeeze()
+        outputs["t2i_logits"] = t2i_sq
+        lg = logits.squeeze()
+        outputs["logits"] = lg if lg.dim() > 0 else lg.reshape(1)     # / exp((1,)-param) makes a 0-d result (1,)
+        return outputs
+
+    # ---- similarity-map post-processing (segmentation_utils.py:62-70, attention_map_base.py:57) ---
+    @torch.no_grad()
+    def upsample_similarity(self, similarity_scores: torch.Tensor, size, sigmoid: bool = False) -> torch.Tensor:
+        """(..., g*g) patch-grid scores -> (..., H, W) bilinear (align_corners=False) [+ sigmoid]."""
+        hh, ww = int(size[0]), int(size[1])
+        g = int(round(math.sqrt(similarity_scores.shape[-1])))
+        if g * g != similarity_scores.shape[-1]:
+            raise ValueError("last dim must be a square patch grid")
+        lead = similarity_scores.shape[:-1]
+        s = similarity_scores.to(device=self._device, dtype=torch.float32)
+        n_maps = int(np.prod(lead)) if len(lead) else 1
+        if s.dim() == 3 and s.stride(2) == 1 and s.stride(0) == s.shape[1] * s.stride(1):
+            flat, stride = s, s.stride(1)          # e.g. the [:, :, 1:] view of the (B, T, N) score tensor: no copy
+        else:
+            flat, stride = s.contiguous(), g * g
+        out = torch.empty((n_maps, hh, ww), dtype=torch.float32, device=self._device)
+        with torch.cuda.device(self._device):
+            _lib.check(self._lib.rz_upsample_maps(self._h, _ptr(flat), stride, n_maps, g, hh, ww, int(sigmoid), _ptr(out),
+                                                  self._stream()), "rz_upsample_maps")
+        return out.reshape(*lead, hh, ww)
+
+    # ---- measurement -----------------------------------------------------------------------------
+    def profile(self, enable: bool):
+        _lib.check(self._lib.rz_profile_enable(self._h, int(enable)), "rz_profile_enable")
+
+    def profile_read(self):
+        ms = (ctypes.c_float * 4)()
+        n = (ctypes.c_int64 * 4)()
+        _lib.check(self._lib.rz_profile_read(self._h, ms, n), "rz_profile_read")
+        return {f: {"ms": float(ms[i]), "launches": int(n[i])} for i, f in enumerate(_lib.PROF_FAMILIES)}

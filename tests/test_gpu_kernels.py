@@ -1,0 +1,147 @@
+"""GPU parity of the individual HIP kernels, called through the C-ABI (ctypes), against plain PyTorch fp32
+references of the same op (floating-point kernels).  Tolerances are stated per dtype."""
+import ctypes
+import math
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+DT = {"f32": (0, torch.float32), "bf16": (1, torch.bfloat16), "f16": (2, torch.float16)}
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from radzero_amd import _lib
+    assert torch.cuda.is_available(), "GPU tests need a HIP device"
+    return _lib.load()
+
+
+def P(t):
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def check(lib, rc):
+    assert rc == 0, lib.rz_last_error().decode()
+
+
+@pytest.mark.parametrize("dt", ["f32", "bf16", "f16"])
+@pytest.mark.parametrize("shape", [(128, 128, 64), (256, 384, 768), (384, 2304, 768), (128, 768, 3072), (256, 768, 640)])
+@pytest.mark.parametrize("epi", [0, 1, 7])
+def test_gemm(lib, dt, shape, epi):
+    code, tdt = DT[dt]
+    M, N, K = shape
+    g = torch.Generator(device="cpu").manual_seed(M * 7 + N * 3 + K + epi)
+    a = (torch.randn(M, K, generator=g) * 0.8).to(tdt).cuda()
+    w = (torch.randn(N, K, generator=g) / math.sqrt(K)).to(tdt).cuda()
+    bias = torch.randn(N, generator=g).cuda()
+    out = torch.empty(M, N, dtype=torch.float32 if epi == 7 else tdt, device="cuda")
+    check(lib, lib.rz_gemm(code, epi, P(a), P(w), P(bias), P(out), M, N, K, stream()))
+    torch.cuda.synchronize()
+    ref = a.float() @ w.float().t() + bias
+    if epi == 1:
+        ref = torch.nn.functional.gelu(ref)
+    err = (out.float() - ref).abs().max().item()
+    # f32: exact-f32 MFMA (fmaf chain), only summation order differs; 16-bit: fp32 accumulate, output rounding
+    tol = {"f32": 2e-5 * math.sqrt(K / 64), "bf16": 2.5e-2, "f16": 3e-3}[dt] if epi != 7 else {"f32": 2e-5 * math.sqrt(K / 64), "bf16": 1e-4 * math.sqrt(K / 64), "f16": 1e-4 * math.sqrt(K / 64)}[dt]
+    assert err <= tol, (dt, shape, epi, err)
+
+
+def test_gemm_rejects_bad_shapes(lib):
+    a = torch.zeros(128, 64, device="cuda")
+    assert lib.rz_gemm(0, 0, P(a), P(a), None, P(a), 100, 128, 64, stream()) != 0
+    assert lib.rz_gemm(0, 0, P(a), P(a), None, P(a), 128, 128, 48, stream()) != 0
+    assert lib.rz_gemm(0, 5, P(a), P(a), None, P(a), 128, 128, 64, stream()) != 0
+
+
+@pytest.mark.parametrize("dt", ["f32", "bf16", "f16"])
+@pytest.mark.parametrize("rows", [1, 5, 257, 1024])
+def test_layernorm(lib, dt, rows):
+    code, tdt = DT[dt]
+    g = torch.Generator(device="cpu").manual_seed(rows)
+    x = (torch.randn(rows, 768, generator=g) * 3 + 1.5).cuda()
+    gamma = (torch.randn(768, generator=g) * 0.2 + 1).cuda()
+    beta = (torch.randn(768, generator=g) * 0.1).cuda()
+    out_t = torch.empty(rows, 768, dtype=tdt, device="cuda")
+    out_f = torch.empty(rows, 768, dtype=torch.float32, device="cuda")
+    check(lib, lib.rz_layernorm(code, P(x), P(gamma), P(beta), 1e-6, P(out_t), P(out_f), rows, 768, stream()))
+    torch.cuda.synchronize()
+    ref = torch.nn.functional.layer_norm(x, (768,), gamma, beta, 1e-6)
+    assert (out_f - ref).abs().max().item() <= 2e-5
+    tol = {"f32": 2e-5, "bf16": 4e-2, "f16": 5e-3}[dt]
+    assert (out_t.float() - ref).abs().max().item() <= tol
+
+
+def _attn_ref(q, k, v):
+    s = torch.einsum("bhqd,bhkd->bhqk", q, k)
+    return torch.einsum("bhqk,bhkd->bhqd", torch.softmax(s, -1), v)
+
+
+@pytest.mark.parametrize("dt", ["f32", "bf16", "f16"])
+@pytest.mark.parametrize("case", [(1, 2, 257), (2, 12, 362), (1, 3, 64), (1, 1, 1), (1, 2, 1370), (1, 1, 128)])
+def test_flash_attention(lib, dt, case):
+    """n_valid not a multiple of any tile (257, 362, 1370), single key, exact tile multiples."""
+    code, tdt = DT[dt]
+    B, H, n = case
+    npad = (n + 127) // 128 * 128
+    g = torch.Generator(device="cpu").manual_seed(n + H)
+    q = torch.zeros(B, H, npad, 64)
+    k = torch.zeros(B, H, npad, 64)
+    v = torch.zeros(B, H, npad, 64)
+    q[:, :, :n] = torch.randn(B, H, n, 64, generator=g) * 0.45
+    k[:, :, :n] = torch.randn(B, H, n, 64, generator=g)
+    v[:, :, :n] = torch.randn(B, H, n, 64, generator=g)
+    # garbage in the padded keys must not leak into the result
+    k[:, :, n:] = 37.0
+    v[:, :, n:] = -91.0
+    qd, kd = q.to(tdt).cuda(), k.to(tdt).cuda()
+    vtd = v.to(tdt).transpose(2, 3).contiguous().cuda()
+    ctx = torch.empty(B * npad, H * 64, dtype=tdt, device="cuda")
+    check(lib, lib.rz_flash_attention(code, P(qd), P(kd), P(vtd), P(ctx), B, H, n, npad, stream()))
+    torch.cuda.synchronize()
+    ref = _attn_ref(qd[:, :, :n].float(), kd[:, :, :n].float(), vtd.transpose(2, 3)[:, :, :n].float())
+    got = ctx.float().view(B, npad, H, 64).permute(0, 2, 1, 3)[:, :, :n]
+    err = (got - ref).abs().max().item()
+    tol = {"f32": 2e-5, "bf16": 2.5e-2, "f16": 3e-3}[dt]
+    assert err <= tol, (dt, case, err)
+
+
+def test_flash_attention_rescale_branch(lib):
+    """Force the running max to jump late (a spiked key in the last tile) — rule 26 of the HIP guide."""
+    B, H, n = 1, 1, 300
+    npad = 384
+    g = torch.Generator(device="cpu").manual_seed(5)
+    q = torch.zeros(B, H, npad, 64); k = torch.zeros(B, H, npad, 64); v = torch.zeros(B, H, npad, 64)
+    q[:, :, :n] = torch.randn(B, H, n, 64, generator=g) * 0.3
+    k[:, :, :n] = torch.randn(B, H, n, 64, generator=g)
+    v[:, :, :n] = torch.randn(B, H, n, 64, generator=g)
+    k[0, 0, 290] = q[0, 0, 17] * 40.0       # query 17 gets a huge score on key 290 (last tile)
+    k[0, 0, 3] = q[0, 0, 100] * 40.0        # query 100: max in the first tile
+    qd, kd = q.cuda(), k.cuda()
+    vtd = v.transpose(2, 3).contiguous().cuda()
+    ctx = torch.empty(B * npad, 64, dtype=torch.float32, device="cuda")
+    check(lib, lib.rz_flash_attention(0, P(qd), P(kd), P(vtd), P(ctx), B, H, n, npad, stream()))
+    torch.cuda.synchronize()
+    ref = _attn_ref(q[:, :, :n].double(), k[:, :, :n].double(), v[:, :, :n].double())[0, 0]
+    got = ctx[:n].double().cpu()
+    assert (got - ref).abs().max().item() <= 5e-5
+
+
+@pytest.mark.parametrize("g,size", [(16, (224, 224)), (37, (512, 640)), (73, (1024, 1024)), (19, (300, 200))])
+def test_upsample(lib, g, size):
+    gen = torch.Generator(device="cpu").manual_seed(g)
+    maps = torch.randn(3, g * g, generator=gen).cuda() * 5
+    out = torch.empty(3, *size, device="cuda")
+    check(lib, lib.rz_upsample_maps(None, P(maps), g * g, 3, g, size[0], size[1], 0, P(out), stream()))
+    out_s = torch.empty(3, *size, device="cuda")
+    check(lib, lib.rz_upsample_maps(None, P(maps), g * g, 3, g, size[0], size[1], 1, P(out_s), stream()))
+    torch.cuda.synchronize()
+    ref = torch.nn.functional.interpolate(maps.cpu().view(3, 1, g, g), size=size, mode="bilinear", align_corners=False)[:, 0]
+    assert (out.cpu() - ref).abs().max().item() <= 1e-4
+    assert (out_s.cpu() - torch.sigmoid(ref)).abs().max().item() <= 1e-5
