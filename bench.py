@@ -1,0 +1,186 @@
+#!/usr/bin/env python3
+"""Benchmark of the VL-CABS zero-shot classification hot path (BASELINE.json metric):
+images/sec (+ similarity-maps/sec) on synthetic 1024x1024 CXR x 14 prompts, bf16, B=32 per GPU.
+
+  python bench.py --gpus 1 --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+         bench.py --gpus N --steps K --warmup W
+
+One step = one compute_logits-equivalent pass (vision encoder + VL-CABS head) over one batch of B images per
+GPU, pixels already resident in HBM, prompt embeddings cached (encoded once, sharded over ranks + one RCCL
+all_gather, before the timed region: their one-time cost is reported separately).  Prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+from radzero_amd.config import RadZeroConfig, attention_flops_per_image_layer, flops_per_image  # noqa: E402
+from radzero_amd.synthetic import synthetic_prompts  # noqa: E402
+from radzero_amd.weights import make_state_dict  # noqa: E402
+
+PEAK_TFLOPS = {"bf16": 2500.0, "f16": 2500.0, "f32": 157.3}   # dense MFMA peaks, MI355X_MICROARCH.md
+DTYPES = {"bf16": torch.bfloat16, "f16": torch.float16, "f32": torch.float32}
+
+
+def usable_cores():
+    """CPU cores this process may actually use: affinity mask and cgroup quota, not the host's core count."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except (AttributeError, OSError):
+        pass
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    if n > 64:          # unconstrained view of a big host: the GPU box's share is 16 cores per GPU
+        n = 16
+    return n
+
+
+def cpu_baseline(cfg, sd, side, n_prompts, ids, mask):
+    """Oracle (CPU port of the reference path, oracle/radzero_oracle.py) timed on this host's cores on a bounded
+    sample: ONE image of the same workload, prompts encoded once, best of SDPA / eager attention."""
+    from oracle.radzero_oracle import OracleModel      # baseline leg only; never on the product path
+    from radzero_amd.synthetic import synthetic_pixels
+    cores = usable_cores()
+    torch.set_num_threads(cores)
+    px = torch.from_numpy(synthetic_pixels(1, side, 1234))
+    enc = {"input_ids": torch.from_numpy(ids), "attention_mask": torch.from_numpy(mask)}
+    best = None
+    for impl in ("sdpa",):
+        om = OracleModel(sd, cfg, attn_impl=impl)
+        with torch.no_grad():
+            tf = om.text_features(enc, split_rows=False)
+            t0 = time.time()
+            om.compute_logits(px, [enc], text_features=tf)
+            dt = time.time() - t0
+        if best is None or dt < best[0]:
+            best = (dt, impl)
+    return {"value": round(1.0 / best[0], 5), "unit": "images/s", "cores": cores, "kind": "port",
+            "sample": f"1 image {side}x{side} x {n_prompts} cached prompts, fp32, torch CPU ({best[1]} attention), "
+                      f"single call {best[0]:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=32, help="images per GPU per step")
+    ap.add_argument("--side", type=int, default=1024)
+    ap.add_argument("--prompts", type=int, default=14)
+    ap.add_argument("--dtype", default="bf16", choices=list(DTYPES))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-events", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch multi-GPU runs with torch.distributed.run (one rank per GPU)")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group(backend="nccl", device_id=device)
+
+    from radzero_amd.modeling import RadZeroModel
+    from radzero_amd.parallel import sharded_text_features
+
+    cfg = RadZeroConfig()
+    sd = make_state_dict(cfg, 20260103)
+    model = RadZeroModel.from_state_dict(sd, cfg, torch_dtype=DTYPES[args.dtype], device=device).eval()
+
+    B, S, T = args.batch, args.side, args.prompts
+    g = torch.Generator(device=device).manual_seed(1234 + rank)
+    pixels = torch.randn((B, 3, S, S), generator=g, device=device, dtype=torch.float32)   # resident in HBM
+    ids, mask = synthetic_prompts(T, 6, 10, 4321)
+    enc = {"input_ids": torch.from_numpy(ids).to(device), "attention_mask": torch.from_numpy(mask).to(device)}
+
+    # one-time prompt encoding: sharded over ranks + ONE all_gather (RCCL over xGMI), then cached
+    torch.cuda.synchronize()
+    t0 = time.time()
+    text_features = sharded_text_features(lambda e: model.forward_text_model(e)["text_features_wo_l2_norm"], enc)
+    torch.cuda.synchronize()
+    text_ms = (time.time() - t0) * 1e3
+
+    def step():
+        return model.compute_logits(pixels, [enc], text_features=text_features)
+
+    for _ in range(args.warmup):
+        step()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    if not args.no_kernel_events:
+        model.profile(True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    prof = None
+    if not args.no_kernel_events:
+        prof = model.profile_read()
+        model.profile(False)
+    tmax = torch.tensor([elapsed], dtype=torch.float64, device=device)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    elapsed = float(tmax.item())
+    assert bool(torch.isfinite(out["logits"]).all())
+
+    if rank == 0:
+        n_tok = cfg.tokens(S)
+        total_images = world * B * args.steps
+        ips = total_images / elapsed
+        f_img = flops_per_image(cfg, S, T)
+        res = {
+            "metric": "images/sec, zero-shot classification (vision encoder + VL-CABS), 1024x1024 CXR x 14 prompts",
+            "value": round(ips, 3), "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": f"BASELINE configs[1]: batch={B}/GPU {S}x{S} synthetic CXR, {T} prompts, "
+                                   f"N={n_tok} tokens/image, 12 ViT + 2 align blocks, VL-CABS head; text embeddings cached",
+                       "global_batch": world * B, "image_side": S, "n_prompts": T, "parallelism": f"dp{world}"},
+            "similarity_maps_per_s": round(ips * T, 2),
+            "model_tflops_per_s": round(ips * f_img / 1e12, 2),
+            "frac_of_mfma_peak_whole_path": round(ips * f_img / 1e12 / (PEAK_TFLOPS[args.dtype] * world), 4),
+            "text_encode_once_ms": round(text_ms, 2),
+        }
+        if prof is not None and prof["attn"]["launches"] > 0:
+            # dominant kernel: flash attention (54 % of the algorithmic FLOPs at 1024^2).
+            # algorithmic FLOPs per launch = B images x 4*N^2*D (QK^T + PV over all 12 heads), SURVEY.md §8(d)
+            launches = prof["attn"]["launches"]
+            avg_ms = prof["attn"]["ms"] / launches
+            flops_launch = B * attention_flops_per_image_layer(cfg, S)
+            achieved = flops_launch / (avg_ms * 1e-3) / 1e12
+            res["roofline"] = {"kernel": "flash_attn_kernel", "bound": "mfma", "achieved": round(achieved, 2),
+                               "peak": PEAK_TFLOPS[args.dtype], "unit": "TFLOP/s",
+                               "frac": round(achieved / PEAK_TFLOPS[args.dtype], 4), "traffic": None,
+                               "avg_launch_ms": round(avg_ms, 4), "launches": launches}
+            res["kernel_family_ms_per_step"] = {k: round(v["ms"] / args.steps, 3) for k, v in prof.items()}
+        if world == 1 and not args.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline(cfg, sd, S, T, ids, mask)
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

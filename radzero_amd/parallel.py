@@ -1,0 +1,71 @@
+"""Data-parallel inference over the GPUs of one node: one process per GPU (torch.distributed; backend
+"nccl" IS RCCL on ROCm, "gloo" in the CPU tests).
+
+The path shards over images with no data-path collective: each rank runs the vision
+encoder + VL-CABS on its own images.  The only exchange is the one-time prompt encoding: prompts are
+sharded T/W per rank, encoded, and ONE all_gather of the (T/W, 768) fp32 embeddings rebuilds the (T, 768)
+table on every rank (21.5 KB at T=14: latency-bound on xGMI, done once per prompt set and cached).
+The reference has no counterpart (its inference is rank-0 only, exp/cxr_pt/run.py:135).
+"""
+from __future__ import annotations
+
+from typing import Callable, Dict, Tuple
+
+import torch
+import torch.distributed as dist
+
+
+def shard_range(n_items: int, rank: int, world: int) -> Tuple[int, int]:
+    """Contiguous slice [lo, hi) of n_items for `rank`; items are padded to a multiple of world."""
+    per = (n_items + world - 1) // world
+    lo = min(rank * per, n_items)
+    return lo, min(lo + per, n_items)
+
+
+def sharded_text_features(encode_fn: Callable[[Dict[str, torch.Tensor]], torch.Tensor],
+                          encoded: Dict[str, torch.Tensor], group=None) -> torch.Tensor:
+    """Encode this rank's share of the prompts with `encode_fn` ((t,L) ids/mask -> (t, D) fp32) and
+    all_gather the rest.  Every rank returns the full (T, D) table in prompt order."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return encode_fn(encoded)
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    ids, mask = encoded["input_ids"], encoded["attention_mask"]
+    t = ids.shape[0]
+    per = (t + world - 1) // world
+    lo, hi = shard_range(t, rank, world)
+    if hi > lo:
+        local = encode_fn({"input_ids": ids[lo:hi], "attention_mask": mask[lo:hi]}).float()
+        d = local.shape[1]
+    else:                                   # more ranks than prompts: this rank contributes padding only
+        local, d = None, None
+    # agree on D (ranks without prompts do not know it) without an extra collective when avoidable
+    dev = ids.device if ids.is_cuda else torch.device("cpu")
+    if local is None:
+        dim = torch.zeros(1, dtype=torch.int64, device=dev)
+    else:
+        dim = torch.tensor([d], dtype=torch.int64, device=dev)
+    if world > t:
+        dist.all_reduce(dim, op=dist.ReduceOp.MAX, group=group)
+    d = int(dim.item())
+    buf = torch.zeros((per, d), dtype=torch.float32, device=dev)
+    if local is not None:
+        buf[: hi - lo] = local.to(dev)
+    out = torch.empty((world * per, d), dtype=torch.float32, device=dev)
+    dist.all_gather_into_tensor(out, buf, group=group) if dev.type == "cuda" else _all_gather_cpu(out, buf, group)
+    return out[:t].contiguous()
+
+
+def _all_gather_cpu(out, buf, group):
+    parts = [torch.empty_like(buf) for _ in range(dist.get_world_size(group))]
+    dist.all_gather(parts, buf, group=group)
+    out.copy_(torch.cat(parts, dim=0))
+
+
+def gather_logits(local_logits: torch.Tensor, group=None, dst: int = 0):
+    """Optional result gather of the (B_local, T) logits to rank `dst` (similarity maps stay sharded)."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return local_logits
+    world = dist.get_world_size(group)
+    parts = [torch.empty_like(local_logits) for _ in range(world)] if dist.get_rank(group) == dst else None
+    dist.gather(local_logits, parts, dst=dst, group=group)
+    return torch.cat(parts, dim=0) if parts is not None else None
