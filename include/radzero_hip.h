@@ -113,10 +113,17 @@ int rz_upsample_maps(rz_handle_t h, const float* maps_dev, int64_t map_stride, i
 /* C = A[M,K] W[N,K]^T + bias; dtype of A/W/out = rz_dtype; epilogue: 0 store, 1 GELU(erf), 7 store fp32 */
 int rz_gemm(int dtype, int epilogue, const void* a_dev, const void* w_dev, const float* bias_dev, void* out_dev, int m,
             int n, int k, void* stream);
+/* every fused epilogue of the GEMM (radzero_amd/csrc/rz_kernels.h `Epilogue`): 0 store, 1 GELU, 2 per-head q|k layout,
+ * 3 transposed per-head v layout, 4 resid += scale*(acc+bias), 5 out_f32 = acc+bias+resid, 6 patch-embed table add,
+ * 7 store fp32.  Leading dimensions in elements. */
+int rz_gemm_ex(int dtype, int epilogue, const void* a_dev, int64_t lda, const void* w_dev, int64_t ldw, const float* bias_dev,
+               void* out_dev, int64_t ldo, const float* scale_dev, float* resid_dev, int64_t ldr, int rows_per_image,
+               int heads_total, int m, int n, int k, void* stream);
 /* LayerNorm rows of `dim` (=768) fp32 -> out_t_dev (dtype, may be NULL) and/or out_f32_dev (may alias in) */
 int rz_layernorm(int dtype, const float* in_dev, const float* gamma_dev, const float* beta_dev, float eps, void* out_t_dev,
                  float* out_f32_dev, int64_t rows, int dim, void* stream);
-/* softmax(q k^T) v, heads of 64: q,k (B,H,n_pad,64), v_t (B,H,64,n_pad), ctx (B*n_pad, H*64); no scaling inside */
+/* flash attention, heads of 64: q,k (B,H,n_pad,64), v_t (B,H,64,n_pad), ctx (B*n_pad, H*64).  Scores are taken in
+ * log2 units: ctx = softmax2(q k^T) v with softmax2(x) = 2^x / sum 2^x  (the model folds log2(e)/sqrt(64) into q). */
 int rz_flash_attention(int dtype, const void* q_dev, const void* k_dev, const void* v_t_dev, void* ctx_dev, int batch,
                        int heads, int n_valid, int n_pad, void* stream);
 

@@ -14,6 +14,8 @@ PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG_DIR, "csrc")
 LIB_PATH = os.path.join(PKG_DIR, "libradzero_hip.so")
 SOURCES = ["gemm.hip", "attention.hip", "rowops.hip", "vlcabs.hip", "api.hip"]
+# attention.hip: fmaxf chains on MFMA outputs fuse into v_max3_f32 without a canonicalising v_max each
+EXTRA_FLAGS = {"attention.hip": ["-fno-honor-nans"]}
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 ARCH = "gfx950"
 
@@ -41,7 +43,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
 
     def cc(src):
         obj = os.path.join(obj_dir, src.replace(".hip", ".o"))
-        cmd = [HIPCC, *flags, "-c", os.path.join(CSRC, src), "-o", obj]
+        cmd = [HIPCC, *flags, *EXTRA_FLAGS.get(src, []), "-c", os.path.join(CSRC, src), "-o", obj]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"hipcc failed for {src}:\n{r.stderr}")
@@ -85,6 +87,7 @@ SYMBOLS = {
     "rz_vlcabs": (_I, [_P, _P, _I, _I, _P, _P, _P, _P]),
     "rz_upsample_maps": (_I, [_P, _P, _L, _I, _I, _I, _I, _I, _P, _P]),
     "rz_gemm": (_I, [_I, _I, _P, _P, _P, _P, _I, _I, _I, _P]),
+    "rz_gemm_ex": (_I, [_I, _I, _P, _L, _P, _L, _P, _P, _L, _P, _P, _L, _I, _I, _I, _I, _I, _P]),
     "rz_layernorm": (_I, [_I, _P, _P, _P, _F, _P, _P, _L, _I, _P]),
     "rz_flash_attention": (_I, [_I, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "rz_profile_enable": (_I, [_P, _I]),

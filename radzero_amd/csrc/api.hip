@@ -189,7 +189,8 @@ int put_rows(rz_model* m, Tensor& t, size_t total_rows, size_t cols, size_t row_
 
 int load_dino_block(rz_model* m, DinoBlock& b, const char* rest, const float* data, int64_t numel) {
     const size_t D = m->D, F = m->F;
-    const float qscale = 1.0f / sqrtf((float)(m->D / m->H));   // softmax scaling folded into q (exact: power of two for dh=64)
+    // softmax scaling 1/sqrt(dh) AND log2(e) folded into q: the flash kernel works in log2 units (2^x softmax)
+    const float qscale = 1.4426950408889634f / sqrtf((float)(m->D / m->H));
     auto vec = [&](Tensor& t, size_t n) -> int {
         if ((size_t)numel != n) return fail(RZ_ERR_INVALID, std::string("bad numel for ") + rest);
         RZ_HIP(m->upload(t, data, n, false));
@@ -637,6 +638,23 @@ int rz_gemm(int dtype, int epilogue, const void* a, const void* w, const float* 
     memset(&g, 0, sizeof g);
     g.A = a; g.lda = K; g.W = w; g.ldw = K; g.M = M; g.N = N; g.K = K; g.bias = bias; g.out = out; g.ldo = N;
     g.rows_per_image = M;
+    RZ_HIP(launch_gemm(dtype, epilogue, g, (hipStream_t)stream));
+    return 0;
+}
+
+int rz_gemm_ex(int dtype, int epilogue, const void* a, int64_t lda, const void* w, int64_t ldw, const float* bias, void* out,
+               int64_t ldo, const float* scale, float* resid, int64_t ldr, int rows_per_image, int heads_total, int M, int N,
+               int K, void* stream) {
+    if (!a || !w) return fail(RZ_ERR_INVALID, "rz_gemm_ex: null argument");
+    if (epilogue < 0 || epilogue > EPI_STORE_F32) return fail(RZ_ERR_INVALID, "rz_gemm_ex: epilogue");
+    if (epilogue == EPI_RESID_SCALE ? (!scale || !resid) : !out) return fail(RZ_ERR_INVALID, "rz_gemm_ex: missing output / residual / scale");
+    if ((epilogue == EPI_RESID_ADD && !resid) || (epilogue == EPI_PATCH && !scale)) return fail(RZ_ERR_INVALID, "rz_gemm_ex: missing residual / table");
+    if (M % 128 || N % 128) return fail(RZ_ERR_INVALID, "rz_gemm_ex: M and N must be multiples of 128");
+    if ((epilogue == EPI_HEADS || epilogue == EPI_VT || epilogue == EPI_PATCH) && (rows_per_image <= 0 || rows_per_image % 128 || M % rows_per_image))
+        return fail(RZ_ERR_INVALID, "rz_gemm_ex: rows_per_image must be a multiple of 128 dividing M");
+    GemmArgs g;
+    g.A = a; g.lda = lda; g.W = w; g.ldw = ldw; g.M = M; g.N = N; g.K = K; g.bias = bias; g.out = out; g.ldo = ldo;
+    g.scale = scale; g.resid = resid; g.ldr = ldr; g.rows_per_image = rows_per_image > 0 ? rows_per_image : M; g.heads_total = heads_total;
     RZ_HIP(launch_gemm(dtype, epilogue, g, (hipStream_t)stream));
     return 0;
 }

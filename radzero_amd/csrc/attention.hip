@@ -7,14 +7,17 @@
 //   TF:mpnet/modeling_mpnet.py:131-171 (bias computed once per forward, :312-348).
 //
 // Flash kernel data flow (per workgroup = 128 query rows of one (image, head); 4 waves x 32 rows):
-//   S^T = K Q^T   : A = K fragment (row = key), B = Q fragment (col = query, held in registers)
-//                   -> lane (q = lane&15, g = lane>>4) owns keys 16t+4g+r of every 16-key tile t.
+//   S^T = K Q^T   : A = K fragment (row = key), B = Q fragment (col = query, held in registers).  The K ROW fed to
+//                   MFMA row i of 16-key tile kt is key 32(kt>>1) + 8(i>>2) + 4(kt&1) + (i&3), so lane
+//                   (q = lane&15, g = lane>>4), which receives rows 4g..4g+3 of every tile, owns the 8 CONTIGUOUS
+//                   keys 32kk + 8g .. +7 of each 32-key step kk (tiles 2kk and 2kk+1).
 //   softmax       : row statistics are per lane (+2 shuffles across g); no LDS round trip.
-//   O^T += V^T P^T: A = V^T fragment (row = d), B = P^T built in registers from the S^T accumulators.
-//                   The MFMA's K slot (g, j) is mapped to key 32kk+4g+j (j<4) / 32kk+16+4g+(j-4) for BOTH
-//                   operands, so P needs no transpose; V^T rows are key-contiguous because the QKV GEMM
-//                   epilogue already wrote V transposed ([B][H][64][Npad]).
+//   O^T += V^T P^T: A = V^T fragment (row = d, 8 contiguous keys 32kk + 8g..+7: one ds_read_b128),
+//                   B = P^T packed in registers straight from the S^T accumulators (no transpose, no LDS);
+//                   V^T rows are key-contiguous because the QKV GEMM epilogue wrote V transposed ([B][H][64][Npad]).
 //   K and V^T tiles (64 keys) are double-buffered in LDS via global_load_lds_dwordx4 (rz_common.h panels).
+#include <type_traits>
+
 #include "rz_common.h"
 #include "rz_kernels.h"
 
@@ -22,7 +25,7 @@ namespace rz {
 
 constexpr int FA_QROWS = 128;   // query rows per workgroup
 constexpr int FA_KEYS = 64;     // keys per KV tile
-constexpr float LOG2E = 1.4426950408889634f;
+constexpr float FA_DEFER = 8.0f;  // a row is re-centred only when its max grew by more than 2^8 (P <= 256: safe in fp32/bf16/f16)
 
 template <typename T> struct FaCfg {
     static constexpr int NPAN = 64 * (int)sizeof(T) / 128;   // 128-B panels per 64-element row (1 or 2)
@@ -56,12 +59,14 @@ __device__ __forceinline__ typename Traits<T>::frag lds_frag_row(const char* til
 }
 
 template <typename T>
-__global__ __launch_bounds__(256, 2) void flash_attn_kernel(const T* __restrict__ q, const T* __restrict__ k,
+__global__ __launch_bounds__(256, 3) void flash_attn_kernel(const T* __restrict__ q, const T* __restrict__ k,
                                                             const T* __restrict__ vT, T* __restrict__ ctx,
                                                             int64_t qk_batch_stride, int B, int H, int n_valid, int n_pad) {
     typedef typename Traits<T>::frag frag_t;
+    typedef typename Traits<T>::vec4 v4_t;
     constexpr int NPAN = FaCfg<T>::NPAN;
     constexpr int TILE = FaCfg<T>::TILE_BYTES;
+    constexpr int ES = (int)sizeof(T);
     __shared__ __attribute__((aligned(1024))) char lds[4 * TILE];   // K0 K1 V0 V1
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -79,8 +84,8 @@ __global__ __launch_bounds__(256, 2) void flash_attn_kernel(const T* __restrict_
     const T* qbase = q + (int64_t)b * qk_batch_stride + ((int64_t)h * n_pad) * 64;
     const char* kbase = reinterpret_cast<const char*>(k + (int64_t)b * qk_batch_stride + ((int64_t)h * n_pad) * 64);
     const char* vbase = reinterpret_cast<const char*>(vT + ((int64_t)pair * 64) * n_pad);
-    const int64_t k_ld = 64 * (int64_t)sizeof(T);
-    const int64_t v_ld = (int64_t)n_pad * sizeof(T);
+    const int64_t k_ld = 64 * (int64_t)ES;
+    const int64_t v_ld = (int64_t)n_pad * ES;
 
     // Q fragments: qf[qt][ks] = Q[row q0 + qt*16 + l15][d = ks*32 + lg*8 .. +7]
     const int q0 = qb * FA_QROWS + wave * 32;
@@ -91,6 +96,30 @@ __global__ __launch_bounds__(256, 2) void flash_attn_kernel(const T* __restrict_
         for (int ks = 0; ks < 2; ++ks)
             qf[qt][ks] = *reinterpret_cast<const frag_t*>(qbase + (int64_t)(q0 + qt * 16 + l15) * 64 + ks * 32 + lg * 8);
 
+    // ---- per-lane LDS byte offsets, loop invariant (row blocks add immediates) ----
+    // K fragment for tile kt: row = 32(kt>>1) + 4(kt&1) + [8(l15>>2) + (l15&3)], 8 elements at d = 32ks + 8lg.
+    // The K tile uses the swz_k XOR (depends on l15 only for these rows): conflict-free for this row set.
+    const int krow = 8 * (l15 >> 2) + (l15 & 3);
+    const int ksw = swz_k(krow);
+    int koff[2][2];          // [ks][half]  (half: second 16-B chunk of an f32 fragment)
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf) {
+            const int byte = (ks * 32 + lg * 8) * ES + hf * 16;
+            koff[ks][hf] = (byte >> 7) * (64 * 128) + krow * 128 + ((((byte & 127) >> 4) ^ ksw) << 4);
+        }
+    // V^T fragment (row = d 16dt + l15): 8 contiguous keys 32kk + 8lg (standard panel XOR, depends on l15 only)
+    const int sw = (l15 >> 1) & 7;
+    int voff[2][2];          // [kk][half]
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf) {
+            const int byte = (kk * 32 + lg * 8) * ES + hf * 16;
+            voff[kk][hf] = (byte >> 7) * (64 * 128) + l15 * 128 + ((((byte & 127) >> 4) ^ sw) << 4);
+        }
+
     auto stage = [&](int t, int buf) {
         char* sk = lds + buf * TILE;
         char* sv = lds + (2 + buf) * TILE;
@@ -100,8 +129,8 @@ __global__ __launch_bounds__(256, 2) void flash_attn_kernel(const T* __restrict_
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
                 const int row8 = (wave * 2 + i) * 8;
-                glds_rows8(sk + p * (64 * 128) + row8 * 128, kbase + (int64_t)key0 * k_ld + p * 128, k_ld, row8, lane);
-                glds_rows8(sv + p * (64 * 128) + row8 * 128, vbase + (int64_t)key0 * sizeof(T) + p * 128, v_ld, row8, lane);
+                glds_rows8<1>(sk + p * (64 * 128) + row8 * 128, kbase + (int64_t)key0 * k_ld + p * 128, k_ld, row8, lane);
+                glds_rows8(sv + p * (64 * 128) + row8 * 128, vbase + (int64_t)key0 * ES + p * 128, v_ld, row8, lane);
             }
         }
     };
@@ -111,95 +140,172 @@ __global__ __launch_bounds__(256, 2) void flash_attn_kernel(const T* __restrict_
     for (int a = 0; a < 2; ++a)
 #pragma unroll
         for (int c = 0; c < 4; ++c) oacc[a][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    float mrow[2] = {-INFINITY, -INFINITY};   // running max (raw score units)
+    // Scores arrive in log2 units (log2(e)/sqrt(dh) is folded into the packed q weights), so the softmax is
+    // 2^(s - m).  mrow = reference point of the running softmax (>= true running max - FA_DEFER); the score
+    // accumulators are INITIALISED to -mrow, so the MFMA chain leaves s - mrow and the common path is
+    // max -> exp2 -> sum with no subtraction and no rescale of O (re-centre only when a row's max grew by more
+    // than 2^FA_DEFER since the last re-centring; wave-uniform branch).
+    float mrow[2] = {0.f, 0.f};
     float lrow[2] = {0.f, 0.f};               // lane-partial running sum
 
-    const int ntiles = (n_valid + FA_KEYS - 1) / FA_KEYS;
-    stage(0, 0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-
-    for (int t = 0; t < ntiles; ++t) {
+    // one KV tile.  FIRST: tile 0 (establishes the reference point).  MASK: ragged last tile (keys >= n_valid dead).
+    auto tile = [&](int t, auto first_c, auto mask_c) {
+        constexpr bool FIRST = decltype(first_c)::value, MASK = decltype(mask_c)::value;
         const int buf = t & 1;
-        if (t + 1 < ntiles) stage(t + 1, buf ^ 1);
         const char* sk = lds + buf * TILE;
         const char* sv = lds + (2 + buf) * TILE;
-
-        // ---- S^T = K Q^T ----
+        // ---- S' = K Q^T - mrow ----
         f32x4 sacc[2][4];
 #pragma unroll
-        for (int a = 0; a < 2; ++a)
+        for (int a = 0; a < 2; ++a) {
+            const float c0 = FIRST ? 0.f : -mrow[a];
 #pragma unroll
-            for (int c = 0; c < 4; ++c) sacc[a][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            for (int c = 0; c < 4; ++c) sacc[a][c] = (f32x4){c0, c0, c0, c0};
+        }
+        auto load_k = [&](int ks, int kt) -> frag_t {
+            const int krb = (32 * (kt >> 1) + 4 * (kt & 1)) * 128;   // immediate
+            if constexpr (ES == 4) {
+                const f32x4 lo = *reinterpret_cast<const f32x4*>(sk + koff[ks][0] + krb);
+                const f32x4 hi = *reinterpret_cast<const f32x4*>(sk + koff[ks][1] + krb);
+                return pack8<T>(lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]);
+            } else {
+                return *reinterpret_cast<const frag_t*>(sk + koff[ks][0] + krb);
+            }
+        };
+        auto load_v = [&](int kk, int dt) -> frag_t {
+            if constexpr (ES == 4) {
+                const f32x4 lo = *reinterpret_cast<const f32x4*>(sv + voff[kk][0] + dt * 2048);
+                const f32x4 hi = *reinterpret_cast<const f32x4*>(sv + voff[kk][1] + dt * 2048);
+                return pack8<T>(lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]);
+            } else {
+                return *reinterpret_cast<const frag_t*>(sv + voff[kk][0] + dt * 2048);
+            }
+        };
+        // all 8 K fragments are requested before the first MFMA waits (LDS latency overlaps the MFMA chain)
+        frag_t kf[2][4];
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt) kf[ks][kt] = load_k(ks, kt);
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
 #pragma unroll
             for (int kt = 0; kt < 4; ++kt) {
-                const frag_t kf = lds_frag_row<T>(sk, kt * 16 + l15, ks * 32 + lg * 8);
-                sacc[0][kt] = mma(kf, qf[0][ks], sacc[0][kt]);
-                sacc[1][kt] = mma(kf, qf[1][ks], sacc[1][kt]);
+                sacc[0][kt] = mma(kf[ks][kt], qf[0][ks], sacc[0][kt]);
+                sacc[1][kt] = mma(kf[ks][kt], qf[1][ks], sacc[1][kt]);
             }
         }
-        // ---- mask the ragged last tile (keys >= n_valid) ----
-        const int key0 = t * FA_KEYS;
-        if (key0 + FA_KEYS > n_valid) {
+        // V^T fragments of the first 32-key step: requested now, consumed after the softmax
+        frag_t vf0[4];
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) vf0[dt] = load_v(0, dt);
+        asm volatile("" ::: "memory");
+        if constexpr (MASK) {
+            const int key0 = t * FA_KEYS;
 #pragma unroll
             for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const bool dead = key0 + kt * 16 + lg * 4 + r >= n_valid;
+                    const bool dead = key0 + 32 * (kt >> 1) + 8 * lg + 4 * (kt & 1) + r >= n_valid;
                     if (dead) { sacc[0][kt][r] = -INFINITY; sacc[1][kt][r] = -INFINITY; }
                 }
         }
-        // ---- online softmax (per query = per lane column) ----
+        // ---- row maxima of S' (per query = per lane column, + 2 shuffles across the 4 key sub-blocks) ----
+        float mx[2];
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt) {
+            // plain fmaxf chains: hipcc fuses them into v_max3_f32 (this file is built with -fno-honor-nans, so no
+            // canonicalising v_max per MFMA output).  NOT inline asm: an asm VALU op reading an MFMA result gets
+            // none of the MFMA->VALU wait states the compiler inserts for its own instructions.
+            float m0 = fmaxf(fmaxf(sacc[qt][0][0], sacc[qt][0][1]), sacc[qt][0][2]);
+            m0 = fmaxf(fmaxf(m0, sacc[qt][0][3]), sacc[qt][1][0]);
+            m0 = fmaxf(fmaxf(m0, sacc[qt][1][1]), sacc[qt][1][2]);
+            m0 = fmaxf(fmaxf(m0, sacc[qt][1][3]), sacc[qt][2][0]);
+            m0 = fmaxf(fmaxf(m0, sacc[qt][2][1]), sacc[qt][2][2]);
+            m0 = fmaxf(fmaxf(m0, sacc[qt][2][3]), sacc[qt][3][0]);
+            m0 = fmaxf(fmaxf(m0, sacc[qt][3][1]), sacc[qt][3][2]);
+            m0 = fmaxf(m0, sacc[qt][3][3]);
+            m0 = fmaxf(m0, __shfl_xor(m0, 16, 64));
+            mx[qt] = fmaxf(m0, __shfl_xor(m0, 32, 64));
+        }
+        // ---- re-centre ----
+        if constexpr (FIRST) {
+#pragma unroll
+            for (int qt = 0; qt < 2; ++qt) {
+                mrow[qt] = mx[qt];      // tile 0 always holds >= 1 live key: finite
+#pragma unroll
+                for (int kt = 0; kt < 4; ++kt) sacc[qt][kt] -= mx[qt];
+            }
+        } else if (__builtin_expect(__any(fmaxf(mx[0], mx[1]) > FA_DEFER), 0)) {
+            asm volatile("" ::: "memory");   // keeps hipcc from if-converting the rare path into the hot one
+#pragma unroll
+            for (int qt = 0; qt < 2; ++qt) {
+                const float delta = fmaxf(mx[qt], 0.f);
+                const float alpha = __builtin_amdgcn_exp2f(-delta);
+                mrow[qt] += delta;
+                lrow[qt] *= alpha;
+#pragma unroll
+                for (int kt = 0; kt < 4; ++kt) sacc[qt][kt] -= delta;
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) oacc[qt][dt] *= alpha;
+            }
+            asm volatile("" ::: "memory");
+        }
+        // ---- P = 2^S', row sums, pack P^T fragments ----
         frag_t pf[2][2];
 #pragma unroll
         for (int qt = 0; qt < 2; ++qt) {
-            float mx = sacc[qt][0][0];
-#pragma unroll
-            for (int kt = 0; kt < 4; ++kt)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) mx = fmaxf(mx, sacc[qt][kt][r]);
-            mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-            const float mnew = fmaxf(mrow[qt], mx);
-            const float alpha = exp2f((mrow[qt] - mnew) * LOG2E);   // exp2f(-inf) = 0 on the first tile
-            const float mb = mnew * LOG2E;
-            mrow[qt] = mnew;
-            float psum = 0.f;
             float pv[4][4];
+            float psum = 0.f;
 #pragma unroll
             for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const float p = exp2f(fmaf(sacc[qt][kt][r], LOG2E, -mb));
-                    pv[kt][r] = p;
-                    psum += p;
+                    pv[kt][r] = __builtin_amdgcn_exp2f(sacc[qt][kt][r]);
+                    psum += pv[kt][r];
                 }
-            lrow[qt] = lrow[qt] * alpha + psum;
-#pragma unroll
-            for (int dt = 0; dt < 4; ++dt) oacc[qt][dt] *= alpha;
+            lrow[qt] += psum;
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    pf[qt][kk][e] = from_f32<T>(pv[2 * kk][e]);
-                    pf[qt][kk][4 + e] = from_f32<T>(pv[2 * kk + 1][e]);
-                }
+                pf[qt][kk] = pack8<T>(pv[2 * kk][0], pv[2 * kk][1], pv[2 * kk][2], pv[2 * kk][3],
+                                      pv[2 * kk + 1][0], pv[2 * kk + 1][1], pv[2 * kk + 1][2], pv[2 * kk + 1][3]);
         }
         // ---- O^T += V^T P^T ----
+        frag_t vf1[4];
 #pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
+        for (int dt = 0; dt < 4; ++dt) vf1[dt] = load_v(1, dt);
+        asm volatile("" ::: "memory");
 #pragma unroll
-            for (int dt = 0; dt < 4; ++dt) {
-                const frag_t vf = lds_frag_split<T>(sv, dt * 16 + l15, kk * 32 + lg * 4, kk * 32 + 16 + lg * 4);
-                oacc[0][dt] = mma(vf, pf[0][kk], oacc[0][dt]);
-                oacc[1][dt] = mma(vf, pf[1][kk], oacc[1][dt]);
-            }
+        for (int dt = 0; dt < 4; ++dt) {
+            oacc[0][dt] = mma(vf0[dt], pf[0][0], oacc[0][dt]);
+            oacc[1][dt] = mma(vf0[dt], pf[1][0], oacc[1][dt]);
         }
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+            oacc[0][dt] = mma(vf1[dt], pf[0][1], oacc[0][dt]);
+            oacc[1][dt] = mma(vf1[dt], pf[1][1], oacc[1][dt]);
+        }
+    };
+    using TrueT = std::integral_constant<bool, true>;
+    using FalseT = std::integral_constant<bool, false>;
+
+    const int ntiles = (n_valid + FA_KEYS - 1) / FA_KEYS;
+    const bool ragged = (n_valid % FA_KEYS) != 0;
+    const int nplain = ragged ? ntiles - 1 : ntiles;     // tiles [0, nplain) need no masking
+    stage(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (ntiles > 1) stage(1, 1);
+    if (nplain >= 1) tile(0, TrueT{}, FalseT{}); else tile(0, TrueT{}, TrueT{});
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (int t = 1; t < nplain; ++t) {
+        if (t + 1 < ntiles) stage(t + 1, (t + 1) & 1);
+        tile(t, FalseT{}, FalseT{});
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
     }
+    if (ragged && ntiles > 1) tile(ntiles - 1, FalseT{}, TrueT{});
 
     // ---- epilogue: O = O^T / l, ctx[(b*n_pad + q)][h*64 + d] ----
 #pragma unroll

@@ -78,6 +78,24 @@ template <typename T> __device__ __forceinline__ typename Traits<T>::vec4 pack4(
     return v;
 }
 
+// 8 floats -> one operand fragment (pairwise packed converts: v_cvt_pk_bf16_f32 / v_cvt_f16 + pack)
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+template <typename T> __device__ __forceinline__ typename Traits<T>::frag pack8(float a, float b, float c, float d, float e, float f, float g, float h);
+template <> __device__ __forceinline__ f32x8 pack8<float>(float a, float b, float c, float d, float e, float f, float g, float h) {
+    return (f32x8){a, b, c, d, e, f, g, h};
+}
+template <> __device__ __forceinline__ bf16x8 pack8<bf16_t>(float a, float b, float c, float d, float e, float f, float g, float h) {
+    const bf16x2 p0 = __builtin_convertvector((f32x2){a, b}, bf16x2), p1 = __builtin_convertvector((f32x2){c, d}, bf16x2);
+    const bf16x2 p2 = __builtin_convertvector((f32x2){e, f}, bf16x2), p3 = __builtin_convertvector((f32x2){g, h}, bf16x2);
+    return __builtin_shufflevector(__builtin_shufflevector(p0, p1, 0, 1, 2, 3), __builtin_shufflevector(p2, p3, 0, 1, 2, 3), 0, 1, 2, 3, 4, 5, 6, 7);
+}
+template <> __device__ __forceinline__ f16x8 pack8<f16_t>(float a, float b, float c, float d, float e, float f, float g, float h) {
+    const f16x2 p0 = __builtin_convertvector((f32x2){a, b}, f16x2), p1 = __builtin_convertvector((f32x2){c, d}, f16x2);
+    const f16x2 p2 = __builtin_convertvector((f32x2){e, f}, f16x2), p3 = __builtin_convertvector((f32x2){g, h}, f16x2);
+    return __builtin_shufflevector(__builtin_shufflevector(p0, p1, 0, 1, 2, 3), __builtin_shufflevector(p2, p3, 0, 1, 2, 3), 0, 1, 2, 3, 4, 5, 6, 7);
+}
+
 // ---- LDS panel addressing ----
 // byte offset of 16-B chunk `c` (0..7) of row `r` inside a [rows][128 B] panel
 __device__ __forceinline__ int panel_off(int r, int c) { return r * 128 + ((c ^ ((r >> 1) & 7)) << 4); }
@@ -87,9 +105,14 @@ __device__ __forceinline__ int panel_off(int r, int c) { return r * 128 + ((c ^ 
 //  gsrc_row0     : global address of (tile row 0, panel byte 0); row stride `ld_bytes`
 // Lane l lands at LDS row row8 + (l>>3), chunk position (l&7); it must therefore FETCH global chunk
 // (l&7) ^ ((row>>1)&7) of that row.
+// SWZ selects the 3-bit XOR term of the row: 0 = standard ((r>>1)&7), 1 = attention K tile (swz_k below).
+__device__ __forceinline__ int swz_std(int r) { return (r >> 1) & 7; }
+// K tile of the flash kernel: one fragment read touches rows {8a + 4t + b : a,b in 0..3} (t fixed), see attention.hip
+__device__ __forceinline__ int swz_k(int r) { return ((r >> 1) & 1) | (((r >> 3) & 3) << 1); }
+template <int SWZ = 0>
 __device__ __forceinline__ void glds_rows8(char* lds_wave_base, const char* gsrc_row0, int64_t ld_bytes, int row8, int lane) {
     const int r = row8 + (lane >> 3);
-    const int c = (lane & 7) ^ ((r >> 1) & 7);
+    const int c = (lane & 7) ^ (SWZ == 0 ? swz_std(r) : swz_k(r));
     const char* src = gsrc_row0 + (int64_t)r * ld_bytes + (c << 4);
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                      (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);

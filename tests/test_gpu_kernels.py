@@ -79,7 +79,8 @@ def test_layernorm(lib, dt, rows):
 
 
 def _attn_ref(q, k, v):
-    s = torch.einsum("bhqd,bhkd->bhqk", q, k)
+    # the kernel's scores are in log2 units: softmax2(x) = softmax(x * ln 2)
+    s = torch.einsum("bhqd,bhkd->bhqk", q, k) * math.log(2.0)
     return torch.einsum("bhqk,bhkd->bhqd", torch.softmax(s, -1), v)
 
 
@@ -94,7 +95,7 @@ def test_flash_attention(lib, dt, case):
     q = torch.zeros(B, H, npad, 64)
     k = torch.zeros(B, H, npad, 64)
     v = torch.zeros(B, H, npad, 64)
-    q[:, :, :n] = torch.randn(B, H, n, 64, generator=g) * 0.45
+    q[:, :, :n] = torch.randn(B, H, n, 64, generator=g) * 0.65
     k[:, :, :n] = torch.randn(B, H, n, 64, generator=g)
     v[:, :, :n] = torch.randn(B, H, n, 64, generator=g)
     # garbage in the padded keys must not leak into the result
@@ -121,8 +122,8 @@ def test_flash_attention_rescale_branch(lib):
     q[:, :, :n] = torch.randn(B, H, n, 64, generator=g) * 0.3
     k[:, :, :n] = torch.randn(B, H, n, 64, generator=g)
     v[:, :, :n] = torch.randn(B, H, n, 64, generator=g)
-    k[0, 0, 290] = q[0, 0, 17] * 40.0       # query 17 gets a huge score on key 290 (last tile)
-    k[0, 0, 3] = q[0, 0, 100] * 40.0        # query 100: max in the first tile
+    k[0, 0, 290] = q[0, 0, 17] * 60.0       # query 17 gets a huge score on key 290 (last tile)
+    k[0, 0, 3] = q[0, 0, 100] * 60.0        # query 100: max in the first tile
     qd, kd = q.cuda(), k.cuda()
     vtd = v.transpose(2, 3).contiguous().cuda()
     ctx = torch.empty(B * npad, 64, dtype=torch.float32, device="cuda")

@@ -1,0 +1,80 @@
+"""Micro-benchmarks of the two dominant kernels at the bench shapes (GPU box only).
+  python tools/kbench.py attn|gemm|all [--images 8]"""
+import argparse
+import ctypes
+import math
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from radzero_amd import _lib  # noqa: E402
+
+lib = _lib.load()
+P = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None
+ST = lambda: ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def timeit(fn, iters=10, warm=3):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(iters):
+        fn()
+    b.record()
+    torch.cuda.synchronize()
+    return a.elapsed_time(b) / iters
+
+
+def bench_attn(images, n=5330, dt=1):
+    npad = (n + 127) // 128 * 128
+    H = 12
+    tdt = {0: torch.float32, 1: torch.bfloat16, 2: torch.float16}[dt]
+    q = (torch.randn(images, H, npad, 64, device="cuda") * 0.6).to(tdt)
+    k = torch.randn(images, H, npad, 64, device="cuda").to(tdt)
+    vt = torch.randn(images, H, 64, npad, device="cuda").to(tdt)
+    ctx = torch.empty(images * npad, H * 64, device="cuda", dtype=tdt)
+    f = lambda: lib.rz_flash_attention(dt, P(q), P(k), P(vt), P(ctx), images, H, n, npad, ST())
+    assert f() == 0, lib.rz_last_error()
+    ms = timeit(f)
+    fl = images * 4.0 * n * n * 768
+    print(f"attn dt={dt} images={images} n={n}: {ms:.3f} ms  {fl / ms / 1e9:.1f} TFLOP/s (algorithmic)")
+
+
+def bench_gemm(images, n=5330, dt=1):
+    npad = (n + 127) // 128 * 128
+    M = images * npad
+    tdt = {0: torch.float32, 1: torch.bfloat16, 2: torch.float16}[dt]
+    shapes = [("qk    EPI_HEADS", 2, 1536, 768), ("v     EPI_VT", 3, 768, 768), ("out   EPI_RESID_SCALE", 4, 768, 768),
+              ("fc1   EPI_GELU", 1, 3072, 768), ("fc2   EPI_RESID_SCALE", 4, 768, 3072), ("plain EPI_STORE", 0, 3072, 768)]
+    tot = 0.0
+    for name, epi, N, K in shapes:
+        a = torch.randn(M, K, device="cuda").to(tdt)
+        w = (torch.randn(N, K, device="cuda") / math.sqrt(K)).to(tdt)
+        bias = torch.randn(N, device="cuda")
+        scale = torch.rand(N, device="cuda")
+        resid = torch.randn(M, N, device="cuda") if epi == 4 else None
+        out = torch.empty(M, N, device="cuda", dtype=tdt)
+        heads = N // 64
+        f = lambda: lib.rz_gemm_ex(dt, epi, P(a), K, P(w), K, P(bias), P(out), N, P(scale), P(resid), N, npad, heads, M, N, K, ST())
+        assert f() == 0, lib.rz_last_error()
+        ms = timeit(f)
+        if "plain" not in name:
+            tot += ms
+        print(f"gemm {name:24s} M={M} N={N} K={K}: {ms:.3f} ms  {2.0 * M * N * K / ms / 1e9:.1f} TFLOP/s")
+    print(f"gemm per-layer total {tot:.3f} ms for {images} images")
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("what", nargs="?", default="all")
+    ap.add_argument("--images", type=int, default=8)
+    ap.add_argument("--dtype", type=int, default=1)
+    a = ap.parse_args()
+    if a.what in ("attn", "all"):
+        bench_attn(a.images, dt=a.dtype)
+    if a.what in ("gemm", "all"):
+        bench_gemm(a.images, dt=a.dtype)
