@@ -127,6 +127,9 @@ int rz_layernorm(int dtype, const float* in_dev, const float* gamma_dev, const f
 int rz_flash_attention(int dtype, const void* q_dev, const void* k_dev, const void* v_t_dev, void* ctx_dev, int batch,
                        int heads, int n_valid, int n_pad, void* stream);
 
+/* process-wide tuning / A-B switches (measurement only): "gemm_v1_only" = 1 forces the 128x128 two-stage GEMM */
+int rz_set_option(const char* name, int value);
+
 /* ---- measurement: HIP-event timing of kernel families on the launch stream ---- */
 enum rz_prof_family { RZ_PROF_ATTN = 0, RZ_PROF_GEMM = 1, RZ_PROF_ROWOPS = 2, RZ_PROF_VLCABS = 3, RZ_PROF_NFAM = 4 };
 int rz_profile_enable(rz_handle_t h, int enable);

@@ -90,6 +90,7 @@ SYMBOLS = {
     "rz_gemm_ex": (_I, [_I, _I, _P, _L, _P, _L, _P, _P, _L, _P, _P, _L, _I, _I, _I, _I, _I, _P]),
     "rz_layernorm": (_I, [_I, _P, _P, _P, _F, _P, _P, _L, _I, _P]),
     "rz_flash_attention": (_I, [_I, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "rz_set_option": (_I, [ctypes.c_char_p, _I]),
     "rz_profile_enable": (_I, [_P, _I]),
     "rz_profile_read": (_I, [_P, _P, _P]),
 }

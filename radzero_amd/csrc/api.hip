@@ -675,6 +675,13 @@ int rz_flash_attention(int dtype, const void* q, const void* k, const void* vt, 
     return 0;
 }
 
+int rz_set_option(const char* name, int value) {
+    if (!name) return fail(RZ_ERR_INVALID, "rz_set_option: null name");
+    if (!strcmp(name, "gemm_v1_only")) { gemm_force_v1(value != 0); return 0; }
+    if (!strcmp(name, "gemm_variant")) { gemm_set_variant(value); return 0; }
+    return fail(RZ_ERR_INVALID, std::string("rz_set_option: unknown option ") + name);
+}
+
 int rz_profile_enable(rz_handle_t m, int enable) {
     if (!m) return fail(RZ_ERR_INVALID, "null handle");
     m->prof = enable != 0;

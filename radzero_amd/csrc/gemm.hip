@@ -19,6 +19,85 @@ namespace rz {
 constexpr int BM = 128, BN = 128;
 constexpr int PANEL_BYTES = 128 * 128;  // one operand tile in LDS (128 rows x 128 B)
 
+// Tile rasterisation.  Each XCD (private 4 MB L2) runs a contiguous range of logical tile ids (xcd_remap);
+// within that range ids walk GROUP_M m-tiles, then step to the next n-tile, so the ~32-64 tiles in flight
+// on an XCD form a compact (GROUP_M x 8) block that shares its A and W panels through L2 instead of
+// re-fetching them from the Infinity Cache / HBM (128x128 tiles alone are L2-bandwidth bound otherwise).
+template <int GROUP_M>
+__device__ __forceinline__ void tile_coords(int id, int tiles_m, int tiles_n, int& tm, int& tn) {
+    const int per_group = GROUP_M * tiles_n;
+    const int grp = id / per_group;
+    const int first_m = grp * GROUP_M;
+    const int gsz = min(tiles_m - first_m, GROUP_M);
+    const int r = id - grp * per_group;
+    tm = first_m + r % gsz;
+    tn = r / gsz;
+}
+
+// Fused epilogue for one wave's 64x64 accumulator block (4x4 MFMA tiles); (mw, nw) = block origin.
+template <typename T, int EPI>
+__device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, const f32x4 (&acc)[4][4], int mw, int nw, int l15, int lg) {
+    constexpr bool SWAP = (EPI != EPI_VT);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const f32x4 a = acc[i][j];
+            if constexpr (SWAP) {
+                const int m = mw + i * 16 + l15;
+                const int n = nw + j * 16 + 4 * lg;     // 4 consecutive columns n..n+3
+                f32x4 v = a;
+                if (g.bias) {
+                    const f32x4 b = *reinterpret_cast<const f32x4*>(g.bias + n);
+                    v += b;
+                }
+                if constexpr (EPI == EPI_STORE) {
+                    T* o = reinterpret_cast<T*>(g.out) + (int64_t)m * g.ldo + n;
+                    *reinterpret_cast<typename Traits<T>::vec4*>(o) = pack4<T>(v[0], v[1], v[2], v[3]);
+                } else if constexpr (EPI == EPI_GELU) {
+                    T* o = reinterpret_cast<T*>(g.out) + (int64_t)m * g.ldo + n;
+                    *reinterpret_cast<typename Traits<T>::vec4*>(o) =
+                        pack4<T>(gelu_for<T>(v[0]), gelu_for<T>(v[1]), gelu_for<T>(v[2]), gelu_for<T>(v[3]));
+                } else if constexpr (EPI == EPI_HEADS) {
+                    // out[b][head][tok][64], head = n/64 over `heads_total` heads (q heads then k heads)
+                    const int b = m / g.rows_per_image, tok = m - b * g.rows_per_image;
+                    T* o = reinterpret_cast<T*>(g.out) +
+                           (((int64_t)b * g.heads_total + (n >> 6)) * g.rows_per_image + tok) * 64 + (n & 63);
+                    *reinterpret_cast<typename Traits<T>::vec4*>(o) = pack4<T>(v[0], v[1], v[2], v[3]);
+                } else if constexpr (EPI == EPI_RESID_SCALE) {
+                    // h[m][n] += lambda[n] * (acc + bias[n])   (fp32 residual stream, in place)
+                    const f32x4 s = *reinterpret_cast<const f32x4*>(g.scale + n);
+                    float* r = g.resid + (int64_t)m * g.ldr + n;
+                    f32x4 h = *reinterpret_cast<f32x4*>(r);
+                    h += s * v;
+                    *reinterpret_cast<f32x4*>(r) = h;
+                } else if constexpr (EPI == EPI_RESID_ADD) {
+                    // out_f32[m][n] = acc + bias[n] + resid[m][n]   (post-LN blocks: LN applied by the next kernel)
+                    const f32x4 h = *reinterpret_cast<const f32x4*>(g.resid + (int64_t)m * g.ldr + n);
+                    *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(g.out) + (int64_t)m * g.ldo + n) = v + h;
+                } else if constexpr (EPI == EPI_PATCH) {
+                    // h[m][n] = acc + posb[tok][n]; posb = pos-embed + (cls | conv bias), zero on pad rows
+                    const int b = m / g.rows_per_image, tok = m - b * g.rows_per_image;
+                    const f32x4 p = *reinterpret_cast<const f32x4*>(g.scale + (int64_t)tok * g.N + n);
+                    *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(g.out) + (int64_t)m * g.ldo + n) = v + p;
+                } else if constexpr (EPI == EPI_STORE_F32) {
+                    *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(g.out) + (int64_t)m * g.ldo + n) = v;
+                }
+            } else {
+                // EPI_VT: lane owns column n, rows m..m+3 (4 consecutive tokens of one image)
+                const int m = mw + i * 16 + 4 * lg;
+                const int n = nw + j * 16 + l15;
+                const float bv = g.bias ? g.bias[n] : 0.f;
+                const int b = m / g.rows_per_image, tok = m - b * g.rows_per_image;
+                // vT[b][head][d][tok]
+                T* o = reinterpret_cast<T*>(g.out) +
+                       (((int64_t)b * g.heads_total + (n >> 6)) * 64 + (n & 63)) * g.rows_per_image + tok;
+                *reinterpret_cast<typename Traits<T>::vec4*>(o) = pack4<T>(a[0] + bv, a[1] + bv, a[2] + bv, a[3] + bv);
+            }
+        }
+    }
+}
+
 template <typename T, int EPI>
 __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs g) {
     __shared__ __attribute__((aligned(1024))) char lds[4 * PANEL_BYTES];  // A0 A1 B0 B1
@@ -30,12 +109,11 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs g) {
     const int wm = wave >> 1, wn = wave & 1;
     const int l15 = lane & 15, lg = lane >> 4;
 
-    // tile mapping: n-tiles fastest so that the blocks sharing an A row-panel run together;
-    // XCD remap keeps such a run on one XCD's L2.
-    const int tiles_n = g.N / BN;
-    const int ntiles = (g.M / BM) * tiles_n;
-    const int bid = xcd_remap(blockIdx.x, ntiles);
-    const int m0 = (bid / tiles_n) * BM, n0 = (bid % tiles_n) * BN;
+    const int tiles_n = g.N / BN, tiles_m = g.M / BM;
+    const int bid = xcd_remap(blockIdx.x, tiles_m * tiles_n);
+    int tm, tn;
+    tile_coords<8>(bid, tiles_m, tiles_n, tm, tn);
+    const int m0 = tm * BM, n0 = tn * BN;
 
     const char* Ab = reinterpret_cast<const char*>(g.A) + (int64_t)m0 * g.lda * sizeof(T);
     const char* Wb = reinterpret_cast<const char*>(g.W) + (int64_t)n0 * g.ldw * sizeof(T);
@@ -70,6 +148,108 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs g) {
         if (kt + 1 < nk) stage(kt + 1, buf ^ 1);
         const char* sa = lds + buf * PANEL_BYTES;
         const char* sb = lds + (2 + buf) * PANEL_BYTES;
+        // fragments of k-step ks+1 are requested before the 16 MFMAs of k-step ks (register double buffer),
+        // so only the first LDS round trip of a K panel is exposed
+        frag_t fa[2][4], fb[2][4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            fa[0][i] = lds_frag<T>(sa, wm * 64 + i * 16 + l15, lg);
+            fb[0][i] = lds_frag<T>(sb, wn * 64 + i * 16 + l15, lg);
+        }
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            if (ks + 1 < KS) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    fa[(ks + 1) & 1][i] = lds_frag<T>(sa, wm * 64 + i * 16 + l15, (ks + 1) * 4 + lg);
+                    fb[(ks + 1) & 1][i] = lds_frag<T>(sb, wn * 64 + i * 16 + l15, (ks + 1) * 4 + lg);
+                }
+                asm volatile("" ::: "memory");
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    if (SWAP) acc[i][j] = mma(fb[ks & 1][j], fa[ks & 1][i], acc[i][j]);   // D[row=n][col=m]
+                    else acc[i][j] = mma(fa[ks & 1][i], fb[ks & 1][j], acc[i][j]);        // D[row=m][col=n]
+                }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+
+    gemm_epilogue<T, EPI>(g, acc, m0 + wm * 64, n0 + wn * 64, l15, lg);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// v2: 256x128 tile, 8 waves (4x2, 64x64 each), THREE LDS stages of 48 KB and counted vmcnt: tile kt+2 is
+// requested before tile kt is computed, and the end-of-step wait retires only tile kt+1
+// (s_waitcnt vmcnt(6) = the 6 global_load_lds of tile kt+2 may stay in flight across the raw s_barrier).
+// One block per CU (144 KB LDS), 2 waves per SIMD.  Requires M % 256 == 0.
+// ---------------------------------------------------------------------------------------------------
+constexpr int BM2 = 256;
+constexpr int STAGE2_BYTES = (BM2 + BN) * 128;   // A panel 32 KB + B panel 16 KB
+
+template <typename T, int EPI>
+__global__ __launch_bounds__(512, 2) void gemm_kernel_v2(GemmArgs g) {
+    __shared__ __attribute__((aligned(1024))) char lds[3 * STAGE2_BYTES];
+    constexpr bool SWAP = (EPI != EPI_VT);
+    constexpr int KS = 128 / (32 * (int)sizeof(T));
+    typedef typename Traits<T>::frag frag_t;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int l15 = lane & 15, lg = lane >> 4;
+
+    const int tiles_n = g.N / BN, tiles_m = g.M / BM2;
+    const int bid = xcd_remap(blockIdx.x, tiles_m * tiles_n);
+    int tm, tn;
+    tile_coords<4>(bid, tiles_m, tiles_n, tm, tn);
+    const int m0 = tm * BM2, n0 = tn * BN;
+
+    const char* Ab = reinterpret_cast<const char*>(g.A) + (int64_t)m0 * g.lda * sizeof(T);
+    const char* Wb = reinterpret_cast<const char*>(g.W) + (int64_t)n0 * g.ldw * sizeof(T);
+    const int64_t lda_b = g.lda * (int64_t)sizeof(T), ldw_b = g.ldw * (int64_t)sizeof(T);
+    const int nk = (g.K * (int)sizeof(T)) / 128;
+
+    auto stage = [&](int kt, int buf) {      // 6 global_load_lds_dwordx4 per wave
+        char* sa = lds + buf * STAGE2_BYTES;
+        char* sb = sa + BM2 * 128;
+        const char* ga = Ab + (int64_t)kt * 128;
+        const char* gb = Wb + (int64_t)kt * 128;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int row8 = (wave * 4 + i) * 8;
+            glds_rows8(sa + row8 * 128, ga, lda_b, row8, lane);
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int row8 = (wave * 2 + i) * 8;
+            glds_rows8(sb + row8 * 128, gb, ldw_b, row8, lane);
+        }
+    };
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    stage(0, 0);
+    if (nk > 1) {
+        stage(1, 1);
+        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();
+
+    int buf = 0;
+    for (int kt = 0; kt < nk; ++kt) {
+        const bool more = kt + 2 < nk;
+        if (more) stage(kt + 2, buf >= 1 ? buf - 1 : 2);      // (buf + 2) % 3
+        const char* sa = lds + buf * STAGE2_BYTES;
+        const char* sb = sa + BM2 * 128;
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
             frag_t fa[4], fb[4];
@@ -82,81 +262,121 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs g) {
             for (int i = 0; i < 4; ++i)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    if (SWAP) acc[i][j] = mma(fb[j], fa[i], acc[i][j]);   // D[row=n][col=m]
-                    else acc[i][j] = mma(fa[i], fb[j], acc[i][j]);        // D[row=m][col=n]
+                    if (SWAP) acc[i][j] = mma(fb[j], fa[i], acc[i][j]);
+                    else acc[i][j] = mma(fa[i], fb[j], acc[i][j]);
+                }
+        }
+        // retire tile kt+1 (this wave's share); tile kt+2 stays in flight across the barrier
+        if (more) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        buf = buf == 2 ? 0 : buf + 1;
+    }
+    gemm_epilogue<T, EPI>(g, acc, m0 + wm * 64, n0 + wn * 64, l15, lg);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// v3: 256x256 tile, 8 waves (2x4), each wave 128x64 (8x4 MFMA tiles, 128 accumulator VGPRs), two LDS stages
+// of 64 KB.  Halves the L2->LDS operand traffic per FLOP of the 128x128 kernel (which is what bounds it:
+// ~12 TB/s of L2 reads at 86 % hit rate) and lowers LDS reads per MFMA from 0.5 to 0.375.
+// Requires M % 256 == 0 and N % 256 == 0.
+// ---------------------------------------------------------------------------------------------------
+constexpr int BN3 = 256;
+constexpr int STAGE3_BYTES = (BM2 + BN3) * 128;   // 64 KB
+
+template <typename T, int EPI>
+__global__ __launch_bounds__(512, 2) void gemm_kernel_v3(GemmArgs g) {
+    __shared__ __attribute__((aligned(1024))) char lds[2 * STAGE3_BYTES];
+    constexpr bool SWAP = (EPI != EPI_VT);
+    constexpr int KS = 128 / (32 * (int)sizeof(T));
+    typedef typename Traits<T>::frag frag_t;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 2, wn = wave & 3;
+    const int l15 = lane & 15, lg = lane >> 4;
+
+    const int tiles_n = g.N / BN3, tiles_m = g.M / BM2;
+    const int bid = xcd_remap(blockIdx.x, tiles_m * tiles_n);
+    int tm, tn;
+    tile_coords<4>(bid, tiles_m, tiles_n, tm, tn);
+    const int m0 = tm * BM2, n0 = tn * BN3;
+
+    const char* Ab = reinterpret_cast<const char*>(g.A) + (int64_t)m0 * g.lda * sizeof(T);
+    const char* Wb = reinterpret_cast<const char*>(g.W) + (int64_t)n0 * g.ldw * sizeof(T);
+    const int64_t lda_b = g.lda * (int64_t)sizeof(T), ldw_b = g.ldw * (int64_t)sizeof(T);
+    const int nk = (g.K * (int)sizeof(T)) / 128;
+
+    auto stage = [&](int kt, int buf) {      // 8 global_load_lds_dwordx4 per wave
+        char* sa = lds + buf * STAGE3_BYTES;
+        char* sb = sa + BM2 * 128;
+        const char* ga = Ab + (int64_t)kt * 128;
+        const char* gb = Wb + (int64_t)kt * 128;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int row8 = (wave * 4 + i) * 8;
+            glds_rows8(sa + row8 * 128, ga, lda_b, row8, lane);
+            glds_rows8(sb + row8 * 128, gb, ldw_b, row8, lane);
+        }
+    };
+
+    f32x4 acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    stage(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    for (int kt = 0; kt < nk; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < nk) stage(kt + 1, buf ^ 1);
+        const char* sa = lds + buf * STAGE3_BYTES;
+        const char* sb = sa + BM2 * 128;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            frag_t fa[8], fb[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) fb[i] = lds_frag<T>(sb, wn * 64 + i * 16 + l15, ks * 4 + lg);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) fa[i] = lds_frag<T>(sa, wm * 128 + i * 16 + l15, ks * 4 + lg);
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    if (SWAP) acc[i][j] = mma(fb[j], fa[i], acc[i][j]);
+                    else acc[i][j] = mma(fa[i], fb[j], acc[i][j]);
                 }
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
     }
-
-    // ---------------- epilogue ----------------
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const f32x4 a = acc[i][j];
-            if constexpr (SWAP) {
-                const int m = m0 + wm * 64 + i * 16 + l15;
-                const int n = n0 + wn * 64 + j * 16 + 4 * lg;     // 4 consecutive columns n..n+3
-                f32x4 v = a;
-                if (g.bias) {
-                    const f32x4 b = *reinterpret_cast<const f32x4*>(g.bias + n);
-                    v += b;
-                }
-                if constexpr (EPI == EPI_STORE) {
-                    T* o = reinterpret_cast<T*>(g.out) + (int64_t)m * g.ldo + n;
-                    *reinterpret_cast<typename Traits<T>::vec4*>(o) = pack4<T>(v[0], v[1], v[2], v[3]);
-                } else if constexpr (EPI == EPI_GELU) {
-                    T* o = reinterpret_cast<T*>(g.out) + (int64_t)m * g.ldo + n;
-                    *reinterpret_cast<typename Traits<T>::vec4*>(o) =
-                        pack4<T>(gelu_erf(v[0]), gelu_erf(v[1]), gelu_erf(v[2]), gelu_erf(v[3]));
-                } else if constexpr (EPI == EPI_HEADS) {
-                    // out[b][head][tok][64], head = n/64 over `heads_total` heads (q heads then k heads)
-                    const int b = m / g.rows_per_image, tok = m - b * g.rows_per_image;
-                    T* o = reinterpret_cast<T*>(g.out) +
-                           (((int64_t)b * g.heads_total + (n >> 6)) * g.rows_per_image + tok) * 64 + (n & 63);
-                    *reinterpret_cast<typename Traits<T>::vec4*>(o) = pack4<T>(v[0], v[1], v[2], v[3]);
-                } else if constexpr (EPI == EPI_RESID_SCALE) {
-                    // h[m][n] += lambda[n] * (acc + bias[n])   (fp32 residual stream, in place)
-                    const f32x4 s = *reinterpret_cast<const f32x4*>(g.scale + n);
-                    float* r = g.resid + (int64_t)m * g.ldr + n;
-                    f32x4 h = *reinterpret_cast<f32x4*>(r);
-                    h += s * v;
-                    *reinterpret_cast<f32x4*>(r) = h;
-                } else if constexpr (EPI == EPI_RESID_ADD) {
-                    // out_f32[m][n] = acc + bias[n] + resid[m][n]   (post-LN blocks: LN applied by the next kernel)
-                    const f32x4 h = *reinterpret_cast<const f32x4*>(g.resid + (int64_t)m * g.ldr + n);
-                    *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(g.out) + (int64_t)m * g.ldo + n) = v + h;
-                } else if constexpr (EPI == EPI_PATCH) {
-                    // h[m][n] = acc + posb[tok][n]; posb = pos-embed + (cls | conv bias), zero on pad rows
-                    const int b = m / g.rows_per_image, tok = m - b * g.rows_per_image;
-                    const f32x4 p = *reinterpret_cast<const f32x4*>(g.scale + (int64_t)tok * g.N + n);
-                    *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(g.out) + (int64_t)m * g.ldo + n) = v + p;
-                } else if constexpr (EPI == EPI_STORE_F32) {
-                    *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(g.out) + (int64_t)m * g.ldo + n) = v;
-                }
-            } else {
-                // EPI_VT: lane owns column n, rows m..m+3 (4 consecutive tokens of one image)
-                const int m = m0 + wm * 64 + i * 16 + 4 * lg;
-                const int n = n0 + wn * 64 + j * 16 + l15;
-                const float bv = g.bias ? g.bias[n] : 0.f;
-                const int b = m / g.rows_per_image, tok = m - b * g.rows_per_image;
-                // vT[b][head][d][tok]
-                T* o = reinterpret_cast<T*>(g.out) +
-                       (((int64_t)b * g.heads_total + (n >> 6)) * 64 + (n & 63)) * g.rows_per_image + tok;
-                *reinterpret_cast<typename Traits<T>::vec4*>(o) = pack4<T>(a[0] + bv, a[1] + bv, a[2] + bv, a[3] + bv);
-            }
-        }
-    }
+    const f32x4 (&lo)[4][4] = *reinterpret_cast<const f32x4 (*)[4][4]>(&acc[0]);
+    const f32x4 (&hi)[4][4] = *reinterpret_cast<const f32x4 (*)[4][4]>(&acc[4]);
+    gemm_epilogue<T, EPI>(g, lo, m0 + wm * 128, n0 + wn * 64, l15, lg);
+    gemm_epilogue<T, EPI>(g, hi, m0 + wm * 128 + 64, n0 + wn * 64, l15, lg);
 }
+
+static int g_variant = 0;      // 0 = auto, 1/2/3 = force that kernel where its shape constraints hold
+void gemm_force_v1(bool on) { g_variant = on ? 1 : 0; }
+void gemm_set_variant(int v) { g_variant = v; }
 
 template <typename T>
 static hipError_t launch_gemm_t(int epi, const GemmArgs& g, hipStream_t s) {
-    const int ntiles = (g.M / BM) * (g.N / BN);
-    dim3 grid(ntiles), block(256);
+    const bool ok2 = (g.M % BM2 == 0) && (g.M >= 4 * BM2);
+    const bool ok3 = ok2 && (g.N % BN3 == 0);
+    int variant = g_variant;
+    if (variant == 0) variant = ok3 ? 3 : 1;     // measured on MI355X (tools/kbench.py): v3 0.825 ms, v1/v2 0.975 ms per layer of 8 images
+    if (variant == 3 && !ok3) variant = 1;
+    if (variant == 2 && !ok2) variant = 1;
+    const int ntiles = variant == 3 ? (g.M / BM2) * (g.N / BN3) : variant == 2 ? (g.M / BM2) * (g.N / BN) : (g.M / BM) * (g.N / BN);
+    dim3 grid(ntiles), block(variant == 1 ? 256 : 512);
 #define RZ_CASE(E) \
-    case E: hipLaunchKernelGGL((gemm_kernel<T, E>), grid, block, 0, s, g); break;
+    case E: if (variant == 3) hipLaunchKernelGGL((gemm_kernel_v3<T, E>), grid, block, 0, s, g); \
+            else if (variant == 2) hipLaunchKernelGGL((gemm_kernel_v2<T, E>), grid, block, 0, s, g); \
+            else hipLaunchKernelGGL((gemm_kernel<T, E>), grid, block, 0, s, g); break;
     switch (epi) {
         RZ_CASE(EPI_STORE)
         RZ_CASE(EPI_GELU)

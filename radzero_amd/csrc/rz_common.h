@@ -150,6 +150,26 @@ __device__ __forceinline__ float wave_max(float v) {
 
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 
+// exact-erf GELU with erf from Abramowitz-Stegun 7.1.26 (|erf error| <= 1.5e-7, i.e. below bf16/f16 output rounding
+// by 4 orders of magnitude): 1 rcp + 1 exp2 + 9 FMA-class ops instead of libm's branchy erff.
+//   erf(z) = 1 - (a1 t + ... + a5 t^5) e^{-z^2},  t = 1/(1 + p z),  z = |x|/sqrt(2)
+__device__ __forceinline__ float gelu_erf_fast(float x) {
+    const float z = fabsf(x) * 0.70710678118654752440f;
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
+    float poly = fmaf(t, 1.061405429f, -1.453152027f);
+    poly = fmaf(poly, t, 1.421413741f);
+    poly = fmaf(poly, t, -0.284496736f);
+    poly = fmaf(poly, t, 0.254829592f);
+    poly *= t;
+    const float pe = poly * __builtin_amdgcn_exp2f(x * x * -0.72134752044448170368f);   // e^{-x^2/2}
+    const float r = 0.5f * x * pe;          // = 0.5 x (1 - erf(z))
+    return x > 0.f ? x - r : r;
+}
+template <typename T> __device__ __forceinline__ float gelu_for(float x) {
+    if constexpr (sizeof(T) == 4) return gelu_erf(x);      // fp32 parity mode: libm erff
+    else return gelu_erf_fast(x);
+}
+
 // XCD-aware remap of a linear workgroup id: consecutive `group`-sized runs of logical ids land on one
 // XCD (blocks b and b+8 share an XCD under round-robin dispatch).  Bijective for any n.
 __device__ __forceinline__ int xcd_remap(int bid, int n) {

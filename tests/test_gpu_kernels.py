@@ -146,3 +146,31 @@ def test_upsample(lib, g, size):
     ref = torch.nn.functional.interpolate(maps.cpu().view(3, 1, g, g), size=size, mode="bilinear", align_corners=False)[:, 0]
     assert (out.cpu() - ref).abs().max().item() <= 1e-4
     assert (out_s.cpu() - torch.sigmoid(ref)).abs().max().item() <= 1e-5
+
+
+@pytest.mark.parametrize("variant", [1, 2, 3])
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
+def test_gemm_variants_agree(lib, variant, dt):
+    """All tile variants (128x128x2-stage, 256x128x3-stage counted-vmcnt, 256x256) against the fp32 reference,
+    on a shape every variant accepts, with each epilogue family that matters (store / GELU / residual+LayerScale)."""
+    code, tdt = DT[dt]
+    M, N, K = 1024, 768, 3072 if variant == 2 else 768
+    g = torch.Generator(device="cpu").manual_seed(variant)
+    a = (torch.randn(M, K, generator=g) * 0.7).to(tdt).cuda()
+    w = (torch.randn(N, K, generator=g) / math.sqrt(K)).to(tdt).cuda()
+    bias = torch.randn(N, generator=g).cuda()
+    scale = torch.rand(N, generator=g).cuda()
+    resid0 = torch.randn(M, N, generator=g).cuda()
+    check(lib, lib.rz_set_option(b"gemm_variant", variant))
+    try:
+        out = torch.empty(M, N, dtype=tdt, device="cuda")
+        check(lib, lib.rz_gemm_ex(code, 1, P(a), K, P(w), K, P(bias), P(out), N, None, None, 0, M, 0, M, N, K, stream()))
+        resid = resid0.clone()
+        check(lib, lib.rz_gemm_ex(code, 4, P(a), K, P(w), K, P(bias), None, 0, P(scale), P(resid), N, M, 0, M, N, K, stream()))
+        torch.cuda.synchronize()
+    finally:
+        lib.rz_set_option(b"gemm_variant", 0)
+    ref = a.float() @ w.float().t() + bias
+    tol = {"f32": 1e-4, "bf16": 2.5e-2}[dt]
+    assert (out.float() - torch.nn.functional.gelu(ref)).abs().max().item() <= tol
+    assert (resid - (resid0 + scale * ref)).abs().max().item() <= 2e-4 * math.sqrt(K / 64)

@@ -73,7 +73,13 @@ if __name__ == "__main__":
     ap.add_argument("what", nargs="?", default="all")
     ap.add_argument("--images", type=int, default=8)
     ap.add_argument("--dtype", type=int, default=1)
+    ap.add_argument("--v1", action="store_true")
+    ap.add_argument("--variant", type=int, default=0)
     a = ap.parse_args()
+    if a.v1:
+        lib.rz_set_option(b"gemm_v1_only", 1)
+    if a.variant:
+        lib.rz_set_option(b"gemm_variant", a.variant)
     if a.what in ("attn", "all"):
         bench_attn(a.images, dt=a.dtype)
     if a.what in ("gemm", "all"):
