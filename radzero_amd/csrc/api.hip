@@ -23,6 +23,14 @@ int fail(int code, const std::string& msg) {
     g_err = msg;
     return code;
 }
+int g_attn_variant = 0;   // 0 = 32x32x16 kernel (default), 1 = 16x16x32 kernel
+
+hipError_t flash_attn(int dt, const void* q, const void* k, const void* vt, void* ctx, int64_t bs, int B, int H, int nv, int np,
+                      hipStream_t s) {
+    return g_attn_variant == 1 ? launch_flash_attn(dt, q, k, vt, ctx, bs, B, H, nv, np, s)
+                               : launch_flash_attn32(dt, q, k, vt, ctx, bs, B, H, nv, np, s);
+}
+
 int hip_fail(hipError_t e, const char* what) {
     g_err = std::string(what) + ": " + hipGetErrorString(e);
     return (int)e;
@@ -526,7 +534,7 @@ int rz_vision_forward(rz_handle_t m, const float* px, int B, int C, int Himg, in
             const size_t es = dsize(m->dt);
             const char* qb = (const char*)m->qk.p;
             const char* kb = qb + (size_t)H * np * 64 * es;
-            RZ_HIP(launch_flash_attn(m->dt, qb, kb, m->vt.p, m->ctx.p, (int64_t)2 * H * np * 64, B, H, nv, np, s));
+            RZ_HIP(flash_attn(m->dt, qb, kb, m->vt.p, m->ctx.p, (int64_t)2 * H * np * 64, B, H, nv, np, s));
         }
         if ((rc = gemm(m, EPI_RESID_SCALE, m->ctx.p, D, b.wo.p, D, M, D, D, (const float*)b.bo.p, nullptr, 0, (const float*)b.ls1.p, h, D, np, 0, s))) return rc;
         {
@@ -638,6 +646,7 @@ int rz_gemm(int dtype, int epilogue, const void* a, const void* w, const float* 
     memset(&g, 0, sizeof g);
     g.A = a; g.lda = K; g.W = w; g.ldw = K; g.M = M; g.N = N; g.K = K; g.bias = bias; g.out = out; g.ldo = N;
     g.rows_per_image = M;
+    g.debug_flags = 0;
     RZ_HIP(launch_gemm(dtype, epilogue, g, (hipStream_t)stream));
     return 0;
 }
@@ -671,7 +680,7 @@ int rz_flash_attention(int dtype, const void* q, const void* k, const void* vt, 
                        void* stream) {
     if (!q || !k || !vt || !ctx) return fail(RZ_ERR_INVALID, "rz_flash_attention: null argument");
     if (n_pad % 128 || n_valid <= 0 || n_valid > n_pad) return fail(RZ_ERR_INVALID, "rz_flash_attention: n_pad must be a multiple of 128 >= n_valid > 0");
-    RZ_HIP(launch_flash_attn(dtype, q, k, vt, ctx, (int64_t)H * n_pad * 64, B, H, n_valid, n_pad, (hipStream_t)stream));
+    RZ_HIP(flash_attn(dtype, q, k, vt, ctx, (int64_t)H * n_pad * 64, B, H, n_valid, n_pad, (hipStream_t)stream));
     return 0;
 }
 
@@ -679,6 +688,8 @@ int rz_set_option(const char* name, int value) {
     if (!name) return fail(RZ_ERR_INVALID, "rz_set_option: null name");
     if (!strcmp(name, "gemm_v1_only")) { gemm_force_v1(value != 0); return 0; }
     if (!strcmp(name, "gemm_variant")) { gemm_set_variant(value); return 0; }
+    if (!strcmp(name, "gemm_debug_flags")) { gemm_set_debug_flags(value); return 0; }
+    if (!strcmp(name, "attn_variant")) { g_attn_variant = value; return 0; }
     return fail(RZ_ERR_INVALID, std::string("rz_set_option: unknown option ") + name);
 }
 

@@ -316,7 +316,7 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel_v3(GemmArgs g) {
         for (int i = 0; i < 4; ++i) {
             const int row8 = (wave * 4 + i) * 8;
             glds_rows8(sa + row8 * 128, ga, lda_b, row8, lane);
-            glds_rows8(sb + row8 * 128, gb, ldw_b, row8, lane);
+            if (!(g.debug_flags & 2)) glds_rows8(sb + row8 * 128, gb, ldw_b, row8, lane);
         }
     };
 
@@ -335,6 +335,7 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel_v3(GemmArgs g) {
         if (kt + 1 < nk) stage(kt + 1, buf ^ 1);
         const char* sa = lds + buf * STAGE3_BYTES;
         const char* sb = sa + BM2 * 128;
+        if (!(g.debug_flags & 1))
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
             frag_t fa[8], fb[4];
@@ -359,6 +360,119 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel_v3(GemmArgs g) {
     gemm_epilogue<T, EPI>(g, hi, m0 + wm * 128 + 64, n0 + wn * 64, l15, lg);
 }
 
+// ---------------------------------------------------------------------------------------------------
+// v4 (16-bit operands): 256x256 tile, 8 waves (2x4, 128x64 each), K step of 32 elements (64-byte rows) and a
+// FOUR-stage LDS ring (4 x 32 KB) with counted vmcnt: three stages are in flight while one is computed and the
+// stream never drains inside a tile.  Why: measured on MI355X (tools/mb_ldsdma.hip) one CU moves at most
+// ~45-50 GB/s L2->LDS by global_load_lds whatever the ring depth, so operand staging (64 KB per 64-deep K step of
+// a 256x256 tile = 1.29 us) is the real bound of these GEMMs; it has to overlap the MFMA work completely.
+// LDS image: two 64-B tile rows per 128-B line; 16-B chunk c of row r sits at chunk position
+// (((r&1)<<2)|c) ^ f(r), f(r) = ((r&1)<<1) | (((r>>2)&1)<<2)  — conflict-free for the ds_read_b128 fragment
+// pattern (16 rows x 1 chunk per lane group; found by exhaustive search over XOR-linear maps).
+// ---------------------------------------------------------------------------------------------------
+constexpr int STAGE4_BYTES = (BM2 + BN3) * 64;   // 32 KB
+constexpr int RING4 = 4;
+
+__device__ __forceinline__ int half_off(int r, int c) {   // byte offset of chunk c (0..3) of 64-B row r
+    const int f = ((r & 1) << 1) | (((r >> 2) & 1) << 2);
+    return (r >> 1) * 128 + (((((r & 1) << 2) | c) ^ f) << 4);
+}
+// one wave fills 16 consecutive 64-B rows (1 KiB); row16 multiple of 16
+__device__ __forceinline__ void glds_rows16_half(char* lds_wave_base, const char* gsrc_row0, int64_t ld_bytes, int row16, int lane) {
+    const int R = (row16 >> 1) + (lane >> 3);
+    const int hb = (R >> 1) & 1;
+    const int b = ((lane >> 2) & 1) ^ hb;
+    const int r = 2 * R + b;
+    const int f = (b << 1) | (hb << 2);
+    const int c = ((lane & 7) ^ f) & 3;
+    const char* src = gsrc_row0 + (int64_t)r * ld_bytes + (c << 4);
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+template <typename T, int EPI>
+__global__ __launch_bounds__(512, 2) void gemm_kernel_v4(GemmArgs g) {
+    static_assert(sizeof(T) == 2, "v4 is for 16-bit operands");
+    __shared__ __attribute__((aligned(1024))) char lds[RING4 * STAGE4_BYTES];
+    constexpr bool SWAP = (EPI != EPI_VT);
+    typedef typename Traits<T>::frag frag_t;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 2, wn = wave & 3;
+    const int l15 = lane & 15, lg = lane >> 4;
+
+    const int tiles_n = g.N / BN3, tiles_m = g.M / BM2;
+    const int bid = xcd_remap(blockIdx.x, tiles_m * tiles_n);
+    int tm, tn;
+    tile_coords<4>(bid, tiles_m, tiles_n, tm, tn);
+    const int m0 = tm * BM2, n0 = tn * BN3;
+
+    const char* Ab = reinterpret_cast<const char*>(g.A) + (int64_t)m0 * g.lda * 2;
+    const char* Wb = reinterpret_cast<const char*>(g.W) + (int64_t)n0 * g.ldw * 2;
+    const int64_t lda_b = g.lda * 2, ldw_b = g.ldw * 2;
+    const int nk = g.K / 32;
+
+    auto stage = [&](int kt, int slot) {      // 4 global_load_lds_dwordx4 per wave: 2 for A, 2 for W
+        char* sa = lds + slot * STAGE4_BYTES;
+        char* sb = sa + BM2 * 64;
+        const char* ga = Ab + (int64_t)kt * 64;
+        const char* gb = Wb + (int64_t)kt * 64;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int row16 = (wave * 2 + i) * 16;
+            glds_rows16_half(sa + row16 * 64, ga, lda_b, row16, lane);
+            glds_rows16_half(sb + row16 * 64, gb, ldw_b, row16, lane);
+        }
+    };
+    // per-lane fragment offsets (row = 16*i + l15 -> only l15 enters the swizzle)
+    const int foff = half_off(l15, lg);
+
+    f32x4 acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    // prologue: three stages in flight
+    stage(0, 0);
+    if (nk > 1) stage(1, 1);
+    if (nk > 2) stage(2, 2);
+
+    int slot = 0;
+    for (int kt = 0; kt < nk; ++kt) {
+        // retire stage kt: the (up to two) younger stages stay in flight across the barrier
+        const int younger = nk - 1 - kt;
+        if (younger >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else if (younger == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (kt + 3 < nk) stage(kt + 3, (slot + 3) & 3);      // slot of stage kt-1: every wave is past it
+        const char* sa = lds + slot * STAGE4_BYTES + wm * (128 * 64);
+        const char* sb = lds + slot * STAGE4_BYTES + BM2 * 64 + wn * (64 * 64);
+        if (!(g.debug_flags & 1)) {
+            frag_t fa[8], fb[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) fb[i] = *reinterpret_cast<const frag_t*>(sb + i * (16 * 64) + foff);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) fa[i] = *reinterpret_cast<const frag_t*>(sa + i * (16 * 64) + foff);
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    if (SWAP) acc[i][j] = mma(fb[j], fa[i], acc[i][j]);
+                    else acc[i][j] = mma(fa[i], fb[j], acc[i][j]);
+                }
+        }
+        slot = (slot + 1) & 3;
+    }
+    const f32x4 (&lo)[4][4] = *reinterpret_cast<const f32x4 (*)[4][4]>(&acc[0]);
+    const f32x4 (&hi)[4][4] = *reinterpret_cast<const f32x4 (*)[4][4]>(&acc[4]);
+    gemm_epilogue<T, EPI>(g, lo, m0 + wm * 128, n0 + wn * 64, l15, lg);
+    gemm_epilogue<T, EPI>(g, hi, m0 + wm * 128 + 64, n0 + wn * 64, l15, lg);
+}
+
+static int g_debug_flags = 0;
+void gemm_set_debug_flags(int f) { g_debug_flags = f; }
 static int g_variant = 0;      // 0 = auto, 1/2/3 = force that kernel where its shape constraints hold
 void gemm_force_v1(bool on) { g_variant = on ? 1 : 0; }
 void gemm_set_variant(int v) { g_variant = v; }
@@ -367,14 +481,17 @@ template <typename T>
 static hipError_t launch_gemm_t(int epi, const GemmArgs& g, hipStream_t s) {
     const bool ok2 = (g.M % BM2 == 0) && (g.M >= 4 * BM2);
     const bool ok3 = ok2 && (g.N % BN3 == 0);
+    const bool ok4 = ok3 && sizeof(T) == 2 && (g.K % 32 == 0);
     int variant = g_variant;
     if (variant == 0) variant = ok3 ? 3 : 1;     // measured on MI355X (tools/kbench.py): v3 0.825 ms, v1/v2 0.975 ms per layer of 8 images
+    if (variant == 4 && !ok4) variant = ok3 ? 3 : 1;
     if (variant == 3 && !ok3) variant = 1;
     if (variant == 2 && !ok2) variant = 1;
-    const int ntiles = variant == 3 ? (g.M / BM2) * (g.N / BN3) : variant == 2 ? (g.M / BM2) * (g.N / BN) : (g.M / BM) * (g.N / BN);
+    const int ntiles = variant >= 3 ? (g.M / BM2) * (g.N / BN3) : variant == 2 ? (g.M / BM2) * (g.N / BN) : (g.M / BM) * (g.N / BN);
     dim3 grid(ntiles), block(variant == 1 ? 256 : 512);
 #define RZ_CASE(E) \
-    case E: if (variant == 3) hipLaunchKernelGGL((gemm_kernel_v3<T, E>), grid, block, 0, s, g); \
+    case E: if (variant == 4) { if constexpr (sizeof(T) == 2) hipLaunchKernelGGL((gemm_kernel_v4<T, E>), grid, block, 0, s, g); } \
+            else if (variant == 3) hipLaunchKernelGGL((gemm_kernel_v3<T, E>), grid, block, 0, s, g); \
             else if (variant == 2) hipLaunchKernelGGL((gemm_kernel_v2<T, E>), grid, block, 0, s, g); \
             else hipLaunchKernelGGL((gemm_kernel<T, E>), grid, block, 0, s, g); break;
     switch (epi) {
@@ -392,7 +509,9 @@ static hipError_t launch_gemm_t(int epi, const GemmArgs& g, hipStream_t s) {
     return hipGetLastError();
 }
 
-hipError_t launch_gemm(int dtype, int epi, const GemmArgs& g, hipStream_t s) {
+hipError_t launch_gemm(int dtype, int epi, const GemmArgs& g_in, hipStream_t s) {
+    GemmArgs g = g_in;
+    g.debug_flags = g_debug_flags;
     if (g.M <= 0 || g.N <= 0 || g.K <= 0) return hipErrorInvalidValue;
     if (g.M % BM || g.N % BN) return hipErrorInvalidValue;
     const int esz = dtype == DT_F32 ? 4 : 2;

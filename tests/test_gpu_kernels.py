@@ -84,9 +84,17 @@ def _attn_ref(q, k, v):
     return torch.einsum("bhqk,bhkd->bhqd", torch.softmax(s, -1), v)
 
 
+@pytest.fixture(params=[0, 1], ids=["mfma32", "mfma16"])
+def attn_variant(request, lib):
+    """Both flash-attention kernels (32x32x16 default, 16x16x32) must pass every attention test."""
+    lib.rz_set_option(b"attn_variant", request.param)
+    yield request.param
+    lib.rz_set_option(b"attn_variant", 0)
+
+
 @pytest.mark.parametrize("dt", ["f32", "bf16", "f16"])
 @pytest.mark.parametrize("case", [(1, 2, 257), (2, 12, 362), (1, 3, 64), (1, 1, 1), (1, 2, 1370), (1, 1, 128)])
-def test_flash_attention(lib, dt, case):
+def test_flash_attention(lib, dt, case, attn_variant):
     """n_valid not a multiple of any tile (257, 362, 1370), single key, exact tile multiples."""
     code, tdt = DT[dt]
     B, H, n = case
@@ -113,7 +121,7 @@ def test_flash_attention(lib, dt, case):
     assert err <= tol, (dt, case, err)
 
 
-def test_flash_attention_rescale_branch(lib):
+def test_flash_attention_rescale_branch(lib, attn_variant):
     """Force the running max to jump late (a spiked key in the last tile) — rule 26 of the HIP guide."""
     B, H, n = 1, 1, 300
     npad = 384
@@ -148,8 +156,8 @@ def test_upsample(lib, g, size):
     assert (out_s.cpu() - torch.sigmoid(ref)).abs().max().item() <= 1e-5
 
 
-@pytest.mark.parametrize("variant", [1, 2, 3])
-@pytest.mark.parametrize("dt", ["f32", "bf16"])
+@pytest.mark.parametrize("variant", [1, 2, 3, 4])
+@pytest.mark.parametrize("dt", ["f32", "bf16", "f16"])
 def test_gemm_variants_agree(lib, variant, dt):
     """All tile variants (128x128x2-stage, 256x128x3-stage counted-vmcnt, 256x256) against the fp32 reference,
     on a shape every variant accepts, with each epilogue family that matters (store / GELU / residual+LayerScale)."""
@@ -171,6 +179,6 @@ def test_gemm_variants_agree(lib, variant, dt):
     finally:
         lib.rz_set_option(b"gemm_variant", 0)
     ref = a.float() @ w.float().t() + bias
-    tol = {"f32": 1e-4, "bf16": 2.5e-2}[dt]
+    tol = {"f32": 1e-4, "bf16": 2.5e-2, "f16": 3e-3}[dt]
     assert (out.float() - torch.nn.functional.gelu(ref)).abs().max().item() <= tol
     assert (resid - (resid0 + scale * ref)).abs().max().item() <= 2e-4 * math.sqrt(K / 64)
