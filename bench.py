@@ -83,6 +83,8 @@ def main():
     ap.add_argument("--dtype", default="bf16", choices=list(DTYPES))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true")
+    ap.add_argument("--attn-variant", type=int, default=None, help="A/B switch (rz_set_option): 1 = 16x16x32 4 waves, 8 = 8 waves, 2/3 = 32x32x16 kernel")
+    ap.add_argument("--gemm-variant", type=int, default=None, help="A/B switch: 0 auto, 1..4 force a GEMM tile variant")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -99,6 +101,12 @@ def main():
 
     from radzero_amd.modeling import RadZeroModel
     from radzero_amd.parallel import sharded_text_features
+
+    from radzero_amd import _lib
+    if args.attn_variant is not None:
+        _lib.check(_lib.load().rz_set_option(b"attn_variant", args.attn_variant), "rz_set_option")
+    if args.gemm_variant is not None:
+        _lib.check(_lib.load().rz_set_option(b"gemm_variant", args.gemm_variant), "rz_set_option")
 
     cfg = RadZeroConfig()
     sd = make_state_dict(cfg, 20260103)

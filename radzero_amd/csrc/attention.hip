@@ -23,7 +23,7 @@
 
 namespace rz {
 
-constexpr int FA_QROWS = 128;   // query rows per workgroup
+constexpr int FA_QROWS = 128;   // query rows per 4-wave workgroup (the 8-wave variant covers 256)
 constexpr int FA_KEYS = 64;     // keys per KV tile
 constexpr float FA_DEFER = 8.0f;  // a row is re-centred only when its max grew by more than 2^8 (P <= 256: safe in fp32/bf16/f16)
 
@@ -58,8 +58,10 @@ __device__ __forceinline__ typename Traits<T>::frag lds_frag_row(const char* til
     return lds_frag<T>(tile + pan * (64 * 128), row, kb);
 }
 
-template <typename T>
-__global__ __launch_bounds__(256, 3) void flash_attn_kernel(const T* __restrict__ q, const T* __restrict__ k,
+// NW = waves per workgroup (4 or 8): 8 waves share each K/V tile -> half the L2->LDS staging bytes per FLOP
+// (one CU sustains only ~50 GB/s of global_load_lds traffic, tools/mb_ldsdma.hip), at <=128 VGPRs for 2 WGs/CU.
+template <typename T, int NW>
+__global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 3) void flash_attn_kernel(const T* __restrict__ q, const T* __restrict__ k,
                                                             const T* __restrict__ vT, T* __restrict__ ctx,
                                                             int64_t qk_batch_stride, int B, int H, int n_valid, int n_pad) {
     typedef typename Traits<T>::frag frag_t;
@@ -73,7 +75,8 @@ __global__ __launch_bounds__(256, 3) void flash_attn_kernel(const T* __restrict_
     const int l15 = lane & 15, lg = lane >> 4;
 
     // XCD-aware mapping: all query blocks of one (image, head) pair run on one XCD (its K/V stay in that L2)
-    const int nq = n_pad / FA_QROWS;
+    constexpr int QROWS = 32 * NW;
+    const int nq = n_pad / QROWS;
     const int pairs = B * H;
     const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
     const int pair = (j / nq) * 8 + xcd;
@@ -88,7 +91,7 @@ __global__ __launch_bounds__(256, 3) void flash_attn_kernel(const T* __restrict_
     const int64_t v_ld = (int64_t)n_pad * ES;
 
     // Q fragments: qf[qt][ks] = Q[row q0 + qt*16 + l15][d = ks*32 + lg*8 .. +7]
-    const int q0 = qb * FA_QROWS + wave * 32;
+    const int q0 = qb * QROWS + wave * 32;
     frag_t qf[2][2];
 #pragma unroll
     for (int qt = 0; qt < 2; ++qt)
@@ -127,8 +130,8 @@ __global__ __launch_bounds__(256, 3) void flash_attn_kernel(const T* __restrict_
 #pragma unroll
         for (int p = 0; p < NPAN; ++p) {
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const int row8 = (wave * 2 + i) * 8;
+            for (int i = 0; i < 8 / NW; ++i) {
+                const int row8 = (wave * (8 / NW) + i) * 8;
                 glds_rows8<1>(sk + p * (64 * 128) + row8 * 128, kbase + (int64_t)key0 * k_ld + p * 128, k_ld, row8, lane);
                 glds_rows8(sv + p * (64 * 128) + row8 * 128, vbase + (int64_t)key0 * ES + p * 128, v_ld, row8, lane);
             }
@@ -325,26 +328,21 @@ __global__ __launch_bounds__(256, 3) void flash_attn_kernel(const T* __restrict_
 }
 
 hipError_t launch_flash_attn(int dtype, const void* q, const void* k, const void* vT, void* ctx,
-                             int64_t qk_batch_stride, int B, int H, int n_valid, int n_pad, hipStream_t s) {
+                             int64_t qk_batch_stride, int B, int H, int n_valid, int n_pad, int waves, hipStream_t s) {
     if (n_pad % FA_QROWS || n_valid <= 0 || n_valid > n_pad || B <= 0 || H <= 0) return hipErrorInvalidValue;
-    const int nq = n_pad / FA_QROWS;
+    if (waves == 8 && (n_pad % 256 || dtype == DT_F32)) waves = 4;      // 8-wave variant: 256-row q blocks, 16-bit operands
+    const int nq = n_pad / (32 * waves);
     const int pairs = B * H;
-    dim3 grid(((pairs + 7) / 8) * 8 * nq), block(256);
+    dim3 grid(((pairs + 7) / 8) * 8 * nq), block(64 * waves);
+#define RZ_FA(TT, NWV) hipLaunchKernelGGL((flash_attn_kernel<TT, NWV>), grid, block, 0, s, (const TT*)q, (const TT*)k, \
+                                          (const TT*)vT, (TT*)ctx, qk_batch_stride, B, H, n_valid, n_pad)
     switch (dtype) {
-        case DT_F32:
-            hipLaunchKernelGGL(flash_attn_kernel<float>, grid, block, 0, s, (const float*)q, (const float*)k,
-                               (const float*)vT, (float*)ctx, qk_batch_stride, B, H, n_valid, n_pad);
-            break;
-        case DT_BF16:
-            hipLaunchKernelGGL(flash_attn_kernel<bf16_t>, grid, block, 0, s, (const bf16_t*)q, (const bf16_t*)k,
-                               (const bf16_t*)vT, (bf16_t*)ctx, qk_batch_stride, B, H, n_valid, n_pad);
-            break;
-        case DT_F16:
-            hipLaunchKernelGGL(flash_attn_kernel<f16_t>, grid, block, 0, s, (const f16_t*)q, (const f16_t*)k,
-                               (const f16_t*)vT, (f16_t*)ctx, qk_batch_stride, B, H, n_valid, n_pad);
-            break;
+        case DT_F32: RZ_FA(float, 4); break;
+        case DT_BF16: if (waves == 8) RZ_FA(bf16_t, 8); else RZ_FA(bf16_t, 4); break;
+        case DT_F16: if (waves == 8) RZ_FA(f16_t, 8); else RZ_FA(f16_t, 4); break;
         default: return hipErrorInvalidValue;
     }
+#undef RZ_FA
     return hipGetLastError();
 }
 

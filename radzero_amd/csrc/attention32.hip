@@ -45,7 +45,7 @@ constexpr float FB_PSUM_LIMIT = 4096.0f;
 #define FB_PRIO 2
 #endif
 
-template <typename T>
+template <typename T, int NST>
 __global__ __launch_bounds__(256, 3) void flash_attn32_kernel(const T* __restrict__ q, const T* __restrict__ k,
                                                               const T* __restrict__ vT, T* __restrict__ ctx,
                                                               int64_t qk_batch_stride, int B, int H, int n_valid, int n_pad) {
@@ -53,7 +53,6 @@ __global__ __launch_bounds__(256, 3) void flash_attn32_kernel(const T* __restric
     constexpr int ES = (int)sizeof(T);
     constexpr int NPAN = 64 * ES / 128;
     constexpr int TILE = NPAN * 64 * 128;
-    constexpr int NST = 3;                                          // LDS ring depth (tiles t, t+1, t+2)
     constexpr int CNT = NPAN * 4;                                   // global_load_lds per wave per stage
     __shared__ __attribute__((aligned(1024))) char lds[2 * NST * TILE];   // K ring | V ring
 
@@ -243,10 +242,11 @@ __global__ __launch_bounds__(256, 3) void flash_attn32_kernel(const T* __restric
     const int ntiles = (n_valid + FB_KEYS - 1) / FB_KEYS;
     const bool ragged = (n_valid % FB_KEYS) != 0;
     const int nplain = ragged ? ntiles - 1 : ntiles;     // tiles [0, nplain) need no masking
-    // Ring of NST stages with counted vmcnt: tile t+2 is requested before tile t is computed, the end-of-tile
-    // wait retires only tile t+1 (CNT loads of tile t+2 stay in flight across the raw s_barrier).
-    auto wait_tile = [&](bool one_in_flight) {
-        if (one_in_flight) {
+    // Ring of NST LDS stages with counted vmcnt: tiles up to t+NST-1 are requested before tile t is computed; the
+    // end-of-tile wait retires only tile t+1 (the younger ones stay in flight across the raw s_barrier).
+    auto wait_keep = [&](int younger) {      // wait until at most `younger` whole stages are outstanding
+        younger = younger < 0 ? 0 : (younger > NST - 2 ? NST - 2 : younger);
+        if (NST >= 3 && younger == 1) {
             if constexpr (CNT == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
         } else {
@@ -254,21 +254,24 @@ __global__ __launch_bounds__(256, 3) void flash_attn32_kernel(const T* __restric
         }
         __builtin_amdgcn_s_barrier();
     };
-    stage(0, 0);
-    if (ntiles > 1) stage(1, 1);
-    wait_tile(ntiles > 1);
-    if (ntiles > 2) stage(2, 2);
-    if (nplain >= 1) tile(0, 0, TrueT{}, FalseT{}); else tile(0, 0, TrueT{}, TrueT{});
-    wait_tile(ntiles > 2);
-    int buf = 1;
-    for (int t = 1; t < nplain; ++t) {
-        const bool more = t + 2 < ntiles;
-        if (more) stage(t + 2, buf == 0 ? 2 : buf - 1);      // (buf + 2) % 3
-        tile(t, buf, FalseT{}, FalseT{});
-        wait_tile(more);
-        buf = buf == 2 ? 0 : buf + 1;
-    }
-    if (ragged && ntiles > 1) tile(ntiles - 1, buf, FalseT{}, TrueT{});
+    static_assert(NST == 2 || NST == 3, "ring depth");
+#pragma unroll
+    for (int d = 0; d < NST - 1; ++d)
+        if (d < ntiles) stage(d, d);
+    wait_keep(ntiles - 1);                    // tile 0 landed
+    int buf = 0;
+    // the three tile flavours are separate call sites (peeled first tile, plain loop, masked last tile): one merged
+    // loop body makes hipcc keep all of them live at once and spill (87 VGPRs, 4x slower)
+    auto step = [&](int t, auto first_c, auto mask_c) {
+        const int ahead = t + NST - 1;
+        if (ahead < ntiles) stage(ahead, buf == 0 ? NST - 1 : buf - 1);      // slot of tile t-1: every wave is past it
+        tile(t, buf, first_c, mask_c);
+        if (t + 1 < ntiles) wait_keep(ntiles - 2 - t);
+        buf = buf == NST - 1 ? 0 : buf + 1;
+    };
+    if (nplain >= 1) step(0, TrueT{}, FalseT{}); else step(0, TrueT{}, TrueT{});
+    for (int t = 1; t < nplain; ++t) step(t, FalseT{}, FalseT{});
+    if (ragged && ntiles > 1) step(ntiles - 1, FalseT{}, TrueT{});
 
     // ---- epilogue: O = O^T / l, ctx[(b*n_pad + q)][h*64 + d], d = 32dt + 8i + 4hh + r ----
     float l = lrow + __shfl_xor(lrow, 32, 64);
@@ -283,26 +286,20 @@ __global__ __launch_bounds__(256, 3) void flash_attn32_kernel(const T* __restric
 }
 
 hipError_t launch_flash_attn32(int dtype, const void* q, const void* k, const void* vT, void* ctx,
-                               int64_t qk_batch_stride, int B, int H, int n_valid, int n_pad, hipStream_t s) {
+                               int64_t qk_batch_stride, int B, int H, int n_valid, int n_pad, int ring, hipStream_t s) {
     if (n_pad % FB_QROWS || n_valid <= 0 || n_valid > n_pad || B <= 0 || H <= 0) return hipErrorInvalidValue;
     const int nq = n_pad / FB_QROWS;
     const int pairs = B * H;
     dim3 grid(((pairs + 7) / 8) * 8 * nq), block(256);
+#define RZ_FA32(TT, NS) hipLaunchKernelGGL((flash_attn32_kernel<TT, NS>), grid, block, 0, s, (const TT*)q, (const TT*)k, \
+                                            (const TT*)vT, (TT*)ctx, qk_batch_stride, B, H, n_valid, n_pad)
     switch (dtype) {
-        case DT_F32:
-            hipLaunchKernelGGL(flash_attn32_kernel<float>, grid, block, 0, s, (const float*)q, (const float*)k,
-                               (const float*)vT, (float*)ctx, qk_batch_stride, B, H, n_valid, n_pad);
-            break;
-        case DT_BF16:
-            hipLaunchKernelGGL(flash_attn32_kernel<bf16_t>, grid, block, 0, s, (const bf16_t*)q, (const bf16_t*)k,
-                               (const bf16_t*)vT, (bf16_t*)ctx, qk_batch_stride, B, H, n_valid, n_pad);
-            break;
-        case DT_F16:
-            hipLaunchKernelGGL(flash_attn32_kernel<f16_t>, grid, block, 0, s, (const f16_t*)q, (const f16_t*)k,
-                               (const f16_t*)vT, (f16_t*)ctx, qk_batch_stride, B, H, n_valid, n_pad);
-            break;
+        case DT_F32: RZ_FA32(float, 2); break;
+        case DT_BF16: if (ring == 3) RZ_FA32(bf16_t, 3); else RZ_FA32(bf16_t, 2); break;
+        case DT_F16: if (ring == 3) RZ_FA32(f16_t, 3); else RZ_FA32(f16_t, 2); break;
         default: return hipErrorInvalidValue;
     }
+#undef RZ_FA32
     return hipGetLastError();
 }
 

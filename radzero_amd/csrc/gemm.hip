@@ -98,6 +98,72 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, const f32x4 (&a
     }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// LDS-staged epilogue (256x256 kernels).  Measured with the debug flags of tools/kbench.py: the direct epilogue above
+// (8/16-byte pieces, 32-64 B per row per instruction) costs 31 % of a K=768 GEMM and nothing overlaps it (one
+// workgroup per CU).  Here each wave drops a 64x64 fp32 block of accumulators into its private 16 KB LDS region
+// (XOR-swizzled 16-B chunks), reads it back row-major and touches global memory in full lines:
+// 4 rows x 256 B (fp32 read-modify-write) or 4 rows x 128 B (16-bit stores) per wave instruction.
+// `outer`/`inner`: SWAP epilogues outer = m, inner = n; EPI_VT outer = n, inner = m (so V^T rows are written whole).
+// ---------------------------------------------------------------------------------------------------
+template <typename T, int EPI>
+__device__ __forceinline__ void gemm_epilogue_lds(const GemmArgs& g, const f32x4 (&acc)[4][4], char* wlds, int mw, int nw, int lane) {
+    constexpr bool SWAP = (EPI != EPI_VT);
+    const int l15 = lane & 15, lg = lane >> 4;
+    // write: lane holds, for tile (i, j), 4 consecutive inner indices of one outer index
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int outer = (SWAP ? i : j) * 16 + l15;
+            const int chunk = (SWAP ? j : i) * 4 + lg;                 // 16-B chunk index along inner (0..15)
+            *reinterpret_cast<f32x4*>(wlds + outer * 256 + ((chunk ^ (outer & 15)) << 4)) = acc[i][j];
+        }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                  // same wave, in-order LDS queue; keeps hipcc from reordering
+    const int c = lane & 15;                                           // chunk read by this lane
+#pragma unroll 4
+    for (int it = 0; it < 16; ++it) {
+        const int outer = it * 4 + (lane >> 4);
+        f32x4 v = *reinterpret_cast<const f32x4*>(wlds + outer * 256 + ((c ^ (outer & 15)) << 4));
+        const int inner = c * 4;
+        const int m = mw + (SWAP ? outer : inner);
+        const int n = nw + (SWAP ? inner : outer);
+        if constexpr (SWAP) {
+            if (g.bias) v += *reinterpret_cast<const f32x4*>(g.bias + n);
+            if constexpr (EPI == EPI_STORE) {
+                *reinterpret_cast<typename Traits<T>::vec4*>(reinterpret_cast<T*>(g.out) + (int64_t)m * g.ldo + n) = pack4<T>(v[0], v[1], v[2], v[3]);
+            } else if constexpr (EPI == EPI_GELU) {
+                *reinterpret_cast<typename Traits<T>::vec4*>(reinterpret_cast<T*>(g.out) + (int64_t)m * g.ldo + n) =
+                    pack4<T>(gelu_for<T>(v[0]), gelu_for<T>(v[1]), gelu_for<T>(v[2]), gelu_for<T>(v[3]));
+            } else if constexpr (EPI == EPI_HEADS) {
+                const int b = m / g.rows_per_image, tok = m - b * g.rows_per_image;
+                T* o = reinterpret_cast<T*>(g.out) + (((int64_t)b * g.heads_total + (n >> 6)) * g.rows_per_image + tok) * 64 + (n & 63);
+                *reinterpret_cast<typename Traits<T>::vec4*>(o) = pack4<T>(v[0], v[1], v[2], v[3]);
+            } else if constexpr (EPI == EPI_RESID_SCALE) {
+                const f32x4 sc = *reinterpret_cast<const f32x4*>(g.scale + n);
+                float* r = g.resid + (int64_t)m * g.ldr + n;
+                *reinterpret_cast<f32x4*>(r) = *reinterpret_cast<const f32x4*>(r) + sc * v;
+            } else if constexpr (EPI == EPI_RESID_ADD) {
+                const f32x4 h = *reinterpret_cast<const f32x4*>(g.resid + (int64_t)m * g.ldr + n);
+                *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(g.out) + (int64_t)m * g.ldo + n) = v + h;
+            } else if constexpr (EPI == EPI_PATCH) {
+                const int b = m / g.rows_per_image, tok = m - b * g.rows_per_image;
+                const f32x4 p = *reinterpret_cast<const f32x4*>(g.scale + (int64_t)tok * g.N + n);
+                *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(g.out) + (int64_t)m * g.ldo + n) = v + p;
+            } else if constexpr (EPI == EPI_STORE_F32) {
+                *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(g.out) + (int64_t)m * g.ldo + n) = v;
+            }
+        } else {
+            // EPI_VT: one feature n, tokens m..m+3 of one image: vT[b][head][d][tok]
+            const float bv = g.bias ? g.bias[n] : 0.f;
+            const int b = m / g.rows_per_image, tok = m - b * g.rows_per_image;
+            T* o = reinterpret_cast<T*>(g.out) + (((int64_t)b * g.heads_total + (n >> 6)) * 64 + (n & 63)) * g.rows_per_image + tok;
+            *reinterpret_cast<typename Traits<T>::vec4*>(o) = pack4<T>(v[0] + bv, v[1] + bv, v[2] + bv, v[3] + bv);
+        }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+}
+
 template <typename T, int EPI>
 __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs g) {
     __shared__ __attribute__((aligned(1024))) char lds[4 * PANEL_BYTES];  // A0 A1 B0 B1
@@ -354,10 +420,18 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel_v3(GemmArgs g) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
     }
+    if (g.debug_flags & 4) return;      // measurement only: no epilogue
     const f32x4 (&lo)[4][4] = *reinterpret_cast<const f32x4 (*)[4][4]>(&acc[0]);
     const f32x4 (&hi)[4][4] = *reinterpret_cast<const f32x4 (*)[4][4]>(&acc[4]);
-    gemm_epilogue<T, EPI>(g, lo, m0 + wm * 128, n0 + wn * 64, l15, lg);
-    gemm_epilogue<T, EPI>(g, hi, m0 + wm * 128 + 64, n0 + wn * 64, l15, lg);
+    if (!(g.debug_flags & 8)) {         // default: direct epilogue (bit3 selects the LDS-staged one; measured equal within noise)
+        gemm_epilogue<T, EPI>(g, lo, m0 + wm * 128, n0 + wn * 64, l15, lg);
+        gemm_epilogue<T, EPI>(g, hi, m0 + wm * 128 + 64, n0 + wn * 64, l15, lg);
+        return;
+    }
+    __syncthreads();                    // every wave is done reading operand stages: LDS is free
+    char* wlds = lds + wave * (64 * 256);
+    gemm_epilogue_lds<T, EPI>(g, lo, wlds, m0 + wm * 128, n0 + wn * 64, lane);
+    gemm_epilogue_lds<T, EPI>(g, hi, wlds, m0 + wm * 128 + 64, n0 + wn * 64, lane);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -467,8 +541,15 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel_v4(GemmArgs g) {
     }
     const f32x4 (&lo)[4][4] = *reinterpret_cast<const f32x4 (*)[4][4]>(&acc[0]);
     const f32x4 (&hi)[4][4] = *reinterpret_cast<const f32x4 (*)[4][4]>(&acc[4]);
-    gemm_epilogue<T, EPI>(g, lo, m0 + wm * 128, n0 + wn * 64, l15, lg);
-    gemm_epilogue<T, EPI>(g, hi, m0 + wm * 128 + 64, n0 + wn * 64, l15, lg);
+    if (!(g.debug_flags & 8)) {         // default: direct epilogue (bit3 selects the LDS-staged one; measured equal within noise)
+        gemm_epilogue<T, EPI>(g, lo, m0 + wm * 128, n0 + wn * 64, l15, lg);
+        gemm_epilogue<T, EPI>(g, hi, m0 + wm * 128 + 64, n0 + wn * 64, l15, lg);
+        return;
+    }
+    __syncthreads();                    // every wave is done reading operand stages: LDS is free
+    char* wlds = lds + wave * (64 * 256);
+    gemm_epilogue_lds<T, EPI>(g, lo, wlds, m0 + wm * 128, n0 + wn * 64, lane);
+    gemm_epilogue_lds<T, EPI>(g, hi, wlds, m0 + wm * 128 + 64, n0 + wn * 64, lane);
 }
 
 static int g_debug_flags = 0;

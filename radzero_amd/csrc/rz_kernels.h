@@ -26,7 +26,8 @@ struct GemmArgs {
     float* resid; int64_t ldr;    // fp32 residual stream
     int rows_per_image;           // padded tokens per image (EPI_HEADS / EPI_VT / EPI_PATCH)
     int heads_total;              // heads in the destination tensor (EPI_HEADS / EPI_VT)
-    int debug_flags;              // measurement only: bit0 = skip the MFMA/ds_read body (staging-only timing)
+    int debug_flags;              // measurement only: bit0 skip MFMA/ds_read body, bit1 skip W staging, bit2 skip epilogue,
+                                  // bit3 use the LDS-staged full-line epilogue (256x256 kernels)
 };
 
 hipError_t launch_gemm(int dtype, int epi, const GemmArgs& g, hipStream_t s);
@@ -38,11 +39,11 @@ void gemm_set_variant(int v);  // 0 auto, 1 = 128x128x2stage, 2 = 256x128x3stage
 // Scores are NOT rescaled inside (1/sqrt(dh) is folded into the packed q weights).
 // q/k of image b start at q + b*qk_batch_stride (elements), heads contiguous ([H][Npad][64]).
 hipError_t launch_flash_attn(int dtype, const void* q, const void* k, const void* vT, void* ctx,
-                             int64_t qk_batch_stride, int B, int H, int n_valid, int n_pad, hipStream_t s);
+                             int64_t qk_batch_stride, int B, int H, int n_valid, int n_pad, int waves, hipStream_t s);
 
 // Same contract, 32x32x16-MFMA formulation (attention32.hip) — the default; launch_flash_attn is kept for A/B.
 hipError_t launch_flash_attn32(int dtype, const void* q, const void* k, const void* vT, void* ctx,
-                               int64_t qk_batch_stride, int B, int H, int n_valid, int n_pad, hipStream_t s);
+                               int64_t qk_batch_stride, int B, int H, int n_valid, int n_pad, int ring, hipStream_t s);
 
 // MPNet self-attention for short sequences: qkv [T*L][3*H*64] (q|k|v), additive relative-position bias
 // rel_bias[H][num_buckets] via bucket table [L][L] and key-padding mask [T][L]; ctx [T*L][H*64].
