@@ -30,6 +30,19 @@ PEAK_TFLOPS = {"bf16": 2500.0, "f16": 2500.0, "f32": 157.3}   # dense MFMA peaks
 DTYPES = {"bf16": torch.bfloat16, "f16": torch.float16, "f32": torch.float32}
 
 
+def pmc_traffic(kernel, batch, side, dtype):
+    """HBM bytes per launch of `kernel` from the committed PMC passes (a separate rocprofv3 --pmc run cannot happen inside
+    this process); null unless the passes were taken on exactly this workload."""
+    try:
+        rec = json.load(open(os.path.join(ROOT, "profiles", "r01", "hbm_traffic_pmc.json")))
+        c = rec["config"]
+        if (c["batch"], c["image_side"], c["dtype"]) == (batch, side, dtype):
+            return rec["kernels"][kernel]["hbm_bytes_per_launch"]
+    except (OSError, KeyError, ValueError):
+        pass
+    return None
+
+
 def usable_cores():
     """CPU cores this process may actually use: affinity mask and cgroup quota, not the host's core count."""
     n = os.cpu_count() or 1
@@ -81,6 +94,10 @@ def main():
     ap.add_argument("--side", type=int, default=1024)
     ap.add_argument("--prompts", type=int, default=14)
     ap.add_argument("--dtype", default="bf16", choices=list(DTYPES))
+    ap.add_argument("--maps", default="none", choices=["none", "upsample", "points"],
+                    help="similarity-map post-processing inside the step (BASELINE cfg 4): per-pixel bilinear maps or fused grounding points")
+    ap.add_argument("--min-len", type=int, default=6)
+    ap.add_argument("--max-len", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true")
     ap.add_argument("--attn-variant", type=int, default=None, help="A/B switch (rz_set_option): 1 = 16x16x32 4 waves, 8 = 8 waves, 2/3 = 32x32x16 kernel")
@@ -115,7 +132,7 @@ def main():
     B, S, T = args.batch, args.side, args.prompts
     g = torch.Generator(device=device).manual_seed(1234 + rank)
     pixels = torch.randn((B, 3, S, S), generator=g, device=device, dtype=torch.float32)   # resident in HBM
-    ids, mask = synthetic_prompts(T, 6, 10, 4321)
+    ids, mask = synthetic_prompts(T, args.min_len, args.max_len, 4321)
     enc = {"input_ids": torch.from_numpy(ids).to(device), "attention_mask": torch.from_numpy(mask).to(device)}
 
     # one-time prompt encoding: sharded over ranks + ONE all_gather (RCCL over xGMI), then cached
@@ -126,7 +143,12 @@ def main():
     text_ms = (time.time() - t0) * 1e3
 
     def step():
-        return model.compute_logits(pixels, [enc], text_features=text_features)
+        out = model.compute_logits(pixels, [enc], text_features=text_features)
+        if args.maps == "upsample":      # (B, T, S, S) fp32 per-pixel maps (interpolate_similarity_scores semantics)
+            out["similarity_maps"] = model.upsample_similarity(out["similarity_scores"], (S, S))
+        elif args.maps == "points":      # fused upsample + argmax (get_grounding_point semantics), map never written
+            out["grounding_points"] = model.grounding_points(out["similarity_scores"], (S, S))
+        return out
 
     for _ in range(args.warmup):
         step()
@@ -165,7 +187,8 @@ def main():
             "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": f"BASELINE configs[1]: batch={B}/GPU {S}x{S} synthetic CXR, {T} prompts, "
                                    f"N={n_tok} tokens/image, 12 ViT + 2 align blocks, VL-CABS head; text embeddings cached",
-                       "global_batch": world * B, "image_side": S, "n_prompts": T, "parallelism": f"dp{world}"},
+                       "global_batch": world * B, "image_side": S, "n_prompts": T, "parallelism": f"dp{world}",
+                       "map_postprocessing": args.maps},
             "similarity_maps_per_s": round(ips * T, 2),
             "model_tflops_per_s": round(ips * f_img / 1e12, 2),
             "frac_of_mfma_peak_whole_path": round(ips * f_img / 1e12 / (PEAK_TFLOPS[args.dtype] * world), 4),
@@ -180,7 +203,10 @@ def main():
             achieved = flops_launch / (avg_ms * 1e-3) / 1e12
             res["roofline"] = {"kernel": "flash_attn_kernel", "bound": "mfma", "achieved": round(achieved, 2),
                                "peak": PEAK_TFLOPS[args.dtype], "unit": "TFLOP/s",
-                               "frac": round(achieved / PEAK_TFLOPS[args.dtype], 4), "traffic": None,
+                               "frac": round(achieved / PEAK_TFLOPS[args.dtype], 4),
+                               "traffic": pmc_traffic("flash_attn_kernel", B, S, args.dtype),
+                               "traffic_unit": "HBM bytes per launch (rocprofv3 PMC: 2*FETCH_SIZE + WRITE_SIZE, KiB -> B; profiles/r01/hbm_traffic_pmc.json)",
+                               "algorithmic_bytes": int(B * cfg.tokens(S) * 768 * 2 * 4),
                                "avg_launch_ms": round(avg_ms, 4), "launches": launches}
             res["kernel_family_ms_per_step"] = {k: round(v["ms"] / args.steps, 3) for k, v in prof.items()}
         if world == 1 and not args.no_cpu_baseline:

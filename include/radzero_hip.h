@@ -109,6 +109,12 @@ int rz_vlcabs(rz_handle_t h, const float* text_features_dev, int n_prompts, int 
 int rz_upsample_maps(rz_handle_t h, const float* maps_dev, int64_t map_stride, int n_maps, int grid, int out_h, int out_w,
                      int apply_sigmoid, float* out_dev, void* stream);
 
+/* ---- get_grounding_point, BlipImageProcessor branch (inference/grounding_utils.py:166-261): flat argmax of the
+ *      bilinear-upsampled map -> (x, y), fused (the n_maps x H x W map is never written: 4.3 GB at BASELINE cfg 4) ----
+ * xy_out_dev: int32 (n_maps, 2) = (x_index, y_index); keys_ws_dev: scratch of n_maps x 8 bytes. */
+int rz_grounding_points(rz_handle_t h, const float* maps_dev, int64_t map_stride, int n_maps, int grid, int out_h, int out_w,
+                        int32_t* xy_out_dev, void* keys_ws_dev, void* stream);
+
 /* ---- per-kernel entry points (used by the parity tests; all pointers device) ---- */
 /* C = A[M,K] W[N,K]^T + bias; dtype of A/W/out = rz_dtype; epilogue: 0 store, 1 GELU(erf), 7 store fp32 */
 int rz_gemm(int dtype, int epilogue, const void* a_dev, const void* w_dev, const float* bias_dev, void* out_dev, int m,

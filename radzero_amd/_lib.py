@@ -86,6 +86,7 @@ SYMBOLS = {
     "rz_text_forward": (_I, [_P, _P, _P, _I, _I, _P, _P, _P]),
     "rz_vlcabs": (_I, [_P, _P, _I, _I, _P, _P, _P, _P]),
     "rz_upsample_maps": (_I, [_P, _P, _L, _I, _I, _I, _I, _I, _P, _P]),
+    "rz_grounding_points": (_I, [_P, _P, _L, _I, _I, _I, _I, _P, _P, _P]),
     "rz_gemm": (_I, [_I, _I, _P, _P, _P, _P, _I, _I, _I, _P]),
     "rz_gemm_ex": (_I, [_I, _I, _P, _L, _P, _L, _P, _P, _L, _P, _P, _L, _I, _I, _I, _I, _I, _P]),
     "rz_layernorm": (_I, [_I, _P, _P, _P, _F, _P, _P, _L, _I, _P]),

@@ -640,6 +640,16 @@ int rz_upsample_maps(rz_handle_t m, const float* maps, int64_t map_stride, int n
     return 0;
 }
 
+int rz_grounding_points(rz_handle_t m, const float* maps, int64_t map_stride, int n_maps, int grid, int out_h, int out_w,
+                        int32_t* xy_out, void* keys_ws, void* stream) {
+    if (!maps || !xy_out || !keys_ws || n_maps <= 0 || grid <= 0 || out_h <= 0 || out_w <= 0 || map_stride < (int64_t)grid * grid)
+        return fail(RZ_ERR_INVALID, "rz_grounding_points: bad argument");
+    hipStream_t s = (hipStream_t)stream;
+    (void)m;
+    RZ_HIP(launch_grounding_points(maps, map_stride, (unsigned long long*)keys_ws, xy_out, n_maps, grid, out_h, out_w, s));
+    return 0;
+}
+
 int rz_gemm(int dtype, int epilogue, const void* a, const void* w, const float* bias, void* out, int M, int N, int K, void* stream) {
     if (!a || !w || !out) return fail(RZ_ERR_INVALID, "rz_gemm: null argument");
     if (epilogue != EPI_STORE && epilogue != EPI_GELU && epilogue != EPI_STORE_F32) return fail(RZ_ERR_INVALID, "rz_gemm: epilogue");

@@ -85,6 +85,10 @@ hipError_t launch_vlcabs(const float* tokens, const float* ln_gamma, const float
 hipError_t launch_upsample_bilinear(const float* maps, int64_t map_stride, float* out, int64_t* argmax_out, int M, int g,
                                     int Hout, int Wout, int apply_sigmoid, hipStream_t s);
 
+// argmax (x, y) of the bilinear-upsampled map, without materialising it; keys_ws: M x u64 scratch
+hipError_t launch_grounding_points(const float* maps, int64_t map_stride, unsigned long long* keys_ws, int* xy_out, int M, int g,
+                                   int Hout, int Wout, hipStream_t s);
+
 // strided gather of valid tokens: src [B][Npad][D] -> dst [B][N][D]
 hipError_t launch_copy_tokens(const float* src, float* dst, int B, int n_valid, int n_pad, int D, hipStream_t s);
 

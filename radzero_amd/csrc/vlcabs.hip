@@ -219,6 +219,72 @@ __global__ __launch_bounds__(256) void upsample_bilinear_kernel(const float* __r
     out[((int64_t)m * Hout + y) * Wout + x] = v;
 }
 
+// ---- fused grounding point: argmax over the bilinear-upsampled map WITHOUT writing the map ----
+// exp/cxr_pt/inference/grounding_utils.py:166-261 (BlipImageProcessor branch :185-191, flat max + unravel_index :254-259).
+// key = (order-preserving float bits << 32) | ~flat_index: atomicMax picks the largest value, lowest index on ties
+// (torch.max over the flattened map returns the first maximum).
+__device__ __forceinline__ unsigned long long pack_key(float v, unsigned idx) {
+    unsigned u = __float_as_uint(v);
+    u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+    return ((unsigned long long)u << 32) | (unsigned long long)(0xFFFFFFFFu - idx);
+}
+
+__global__ __launch_bounds__(256) void grounding_argmax_kernel(const float* __restrict__ maps, int64_t map_stride,
+                                                               unsigned long long* __restrict__ keys, int g, int Hout, int Wout,
+                                                               float sy, float sx) {
+    __shared__ unsigned long long red[4];
+    const int m = blockIdx.y;
+    const float* src = maps + (int64_t)m * map_stride;
+    const unsigned total = (unsigned)Hout * (unsigned)Wout;
+    unsigned long long best = 0ull;
+    for (unsigned idx = blockIdx.x * 256u + threadIdx.x; idx < total; idx += gridDim.x * 256u) {
+        const int y = idx / Wout, x = idx - y * Wout;
+        float fy = sy * (y + 0.5f) - 0.5f; fy = fy < 0.f ? 0.f : fy;
+        float fx = sx * (x + 0.5f) - 0.5f; fx = fx < 0.f ? 0.f : fx;
+        const int y0 = (int)fy, x0 = (int)fx;
+        const int y1 = y0 + (y0 < g - 1 ? 1 : 0), x1 = x0 + (x0 < g - 1 ? 1 : 0);
+        const float ly = fy - y0, lx = fx - x0;
+        const float hy = 1.f - ly, hx = 1.f - lx;
+        const float v = hy * (hx * src[y0 * g + x0] + lx * src[y0 * g + x1]) + ly * (hx * src[y1 * g + x0] + lx * src[y1 * g + x1]);
+        const unsigned long long k = pack_key(v, idx);
+        best = k > best ? k : best;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const unsigned long long other = __shfl_xor(best, o, 64);
+        best = other > best ? other : best;
+    }
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = best;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long b = red[0];
+        for (int i = 1; i < 4; ++i) b = red[i] > b ? red[i] : b;
+        atomicMax(keys + m, b);
+    }
+}
+
+__global__ void grounding_decode_kernel(const unsigned long long* __restrict__ keys, int* __restrict__ xy, int n, int Wout) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const unsigned idx = 0xFFFFFFFFu - (unsigned)(keys[i] & 0xFFFFFFFFull);
+    xy[2 * i] = (int)(idx % (unsigned)Wout);       // x = w_index
+    xy[2 * i + 1] = (int)(idx / (unsigned)Wout);   // y = h_index
+}
+
+hipError_t launch_grounding_points(const float* maps, int64_t map_stride, unsigned long long* keys_ws, int* xy_out, int M, int g,
+                                   int Hout, int Wout, hipStream_t s) {
+    if (M <= 0 || g <= 0 || Hout <= 0 || Wout <= 0 || (int64_t)Hout * Wout > 0x7FFFFFFFll) return hipErrorInvalidValue;
+    hipError_t e = hipMemsetAsync(keys_ws, 0, (size_t)M * sizeof(unsigned long long), s);
+    if (e != hipSuccess) return e;
+    const float sy = (float)g / (float)Hout, sx = (float)g / (float)Wout;
+    const int64_t total = (int64_t)Hout * Wout;
+    int nblk = (int)((total + 256 * 16 - 1) / (256 * 16));
+    nblk = nblk < 1 ? 1 : (nblk > 256 ? 256 : nblk);
+    hipLaunchKernelGGL(grounding_argmax_kernel, dim3(nblk, M), dim3(256), 0, s, maps, map_stride, keys_ws, g, Hout, Wout, sy, sx);
+    hipLaunchKernelGGL(grounding_decode_kernel, dim3((M + 255) / 256), dim3(256), 0, s, keys_ws, xy_out, M, Wout);
+    return hipGetLastError();
+}
+
 hipError_t launch_upsample_bilinear(const float* maps, int64_t map_stride, float* out, int64_t* argmax_out, int M, int g,
                                     int Hout, int Wout, int apply_sigmoid, hipStream_t s) {
     if (M <= 0 || g <= 0 || Hout <= 0 || Wout <= 0 || argmax_out != nullptr) return hipErrorInvalidValue;

@@ -313,6 +313,28 @@ class RadZeroModel:
                                                   self._stream()), "rz_upsample_maps")
         return out.reshape(*lead, hh, ww)
 
+    @torch.no_grad()
+    def grounding_points(self, similarity_scores: torch.Tensor, size) -> torch.Tensor:
+        """get_grounding_point (grounding_utils.py:166-261) for every map: (..., g*g) -> (..., 2) int32 (x, y) of the
+        first maximum of the bilinear-upsampled map; the (H, W) map itself is never materialised."""
+        hh, ww = int(size[0]), int(size[1])
+        g = int(round(math.sqrt(similarity_scores.shape[-1])))
+        if g * g != similarity_scores.shape[-1]:
+            raise ValueError("last dim must be a square patch grid")
+        lead = similarity_scores.shape[:-1]
+        s = similarity_scores.to(device=self._device, dtype=torch.float32)
+        n_maps = int(np.prod(lead)) if len(lead) else 1
+        if s.dim() == 3 and s.stride(2) == 1 and s.stride(0) == s.shape[1] * s.stride(1):
+            flat, stride = s, s.stride(1)
+        else:
+            flat, stride = s.contiguous(), g * g
+        xy = torch.empty((n_maps, 2), dtype=torch.int32, device=self._device)
+        ws = torch.empty((n_maps,), dtype=torch.int64, device=self._device)
+        with torch.cuda.device(self._device):
+            _lib.check(self._lib.rz_grounding_points(self._h, _ptr(flat), stride, n_maps, g, hh, ww, _ptr(xy), _ptr(ws),
+                                                     self._stream()), "rz_grounding_points")
+        return xy.reshape(*lead, 2)
+
     # ---- measurement -----------------------------------------------------------------------------
     def profile(self, enable: bool):
         _lib.check(self._lib.rz_profile_enable(self._h, int(enable)), "rz_profile_enable")
