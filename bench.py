@@ -101,6 +101,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true")
     ap.add_argument("--attn-variant", type=int, default=None, help="A/B switch (rz_set_option): 1 = 16x16x32 4 waves, 8 = 8 waves, 2/3 = 32x32x16 kernel")
+    ap.add_argument("--vision-chunk", type=int, default=None, help="images per internal pass of the vision encoder (0 = whole batch)")
     ap.add_argument("--gemm-variant", type=int, default=None, help="A/B switch: 0 auto, 1..4 force a GEMM tile variant")
     args = ap.parse_args()
 
@@ -122,6 +123,8 @@ def main():
     from radzero_amd import _lib
     if args.attn_variant is not None:
         _lib.check(_lib.load().rz_set_option(b"attn_variant", args.attn_variant), "rz_set_option")
+    if args.vision_chunk is not None:
+        _lib.check(_lib.load().rz_set_option(b"vision_chunk", args.vision_chunk), "rz_set_option")
     if args.gemm_variant is not None:
         _lib.check(_lib.load().rz_set_option(b"gemm_variant", args.gemm_variant), "rz_set_option")
 
@@ -199,7 +202,8 @@ def main():
             # algorithmic FLOPs per launch = B images x 4*N^2*D (QK^T + PV over all 12 heads), SURVEY.md §8(d)
             launches = prof["attn"]["launches"]
             avg_ms = prof["attn"]["ms"] / launches
-            flops_launch = B * attention_flops_per_image_layer(cfg, S)
+            # (robust to --vision-chunk: total attention FLOPs of the timed region / number of launches)
+            flops_launch = args.steps * cfg.num_blocks * B * attention_flops_per_image_layer(cfg, S) / launches
             achieved = flops_launch / (avg_ms * 1e-3) / 1e12
             res["roofline"] = {"kernel": "flash_attn_kernel", "bound": "mfma", "achieved": round(achieved, 2),
                                "peak": PEAK_TFLOPS[args.dtype], "unit": "TFLOP/s",

@@ -25,6 +25,7 @@ int fail(int code, const std::string& msg) {
 }
 // 0 = auto (= 1: measured fastest in bench.py, 1000 TFLOP/s); 1 = 16x16x32 kernel, 4 waves/128 q rows; 8 = same kernel, 8 waves/256 q rows;
 // 2 = 32x32x16 kernel, 2-stage ring; 3 = 32x32x16 kernel, 3-stage ring
+int g_vision_chunk = 0;   // images per pass of rz_vision_forward (0 = whole batch)
 int g_attn_variant = 0;
 
 hipError_t flash_attn(int dt, const void* q, const void* k, const void* vt, void* ctx, int64_t bs, int B, int H, int nv, int np,
@@ -510,13 +511,20 @@ int rz_vision_forward(rz_handle_t m, const float* px, int B, int C, int Himg, in
     const int nv = it->second.n_valid, np = it->second.n_pad;
     if (B > m->cap_batch || np > m->cap_npad || (size_t)B * np > (size_t)m->cap_batch * m->cap_npad)
         return fail(RZ_ERR_STATE, "rz_vision_forward: workspace too small (rz_reserve)");
-    const int D = m->D, H = m->H, F = m->F, M = B * np;
+    const int D = m->D, H = m->H, F = m->F;
     const float eps = m->cfg.vit_layer_norm_eps;
-    float* h = (float*)m->h.p;
+    // Images are independent on this path: process them in chunks so that the per-layer intermediates (xn, qk, vT, ctx,
+    // mid) are reused from a smaller, cache-friendlier footprint; the residual stream keeps all B images for VL-CABS.
+    const int chunk = (g_vision_chunk > 0 && g_vision_chunk < B) ? g_vision_chunk : B;
+    for (int c0 = 0; c0 < B; c0 += chunk) {
+    const int Bc = std::min(chunk, B - c0);
+    const int M = Bc * np;
+    float* h = (float*)m->h.p + (size_t)c0 * np * D;
+    const float* pxc = px + (size_t)c0 * C * Himg * Wimg;
 
     {   // patch embedding: im2col + GEMM with (pos | cls | bias) table epilogue
         ProfScope ps(m, RZ_PROF_ROWOPS, s);
-        RZ_HIP(launch_im2col(m->dt, px, m->mid.p, B, C, Himg, Wimg, P, gh, gw, np, m->KPAD, s));
+        RZ_HIP(launch_im2col(m->dt, pxc, m->mid.p, Bc, C, Himg, Wimg, P, gh, gw, np, m->KPAD, s));
     }
     if ((rc = gemm(m, EPI_PATCH, m->mid.p, m->KPAD, m->patch_w.p, m->KPAD, M, D, m->KPAD, nullptr, h, D,
                    (const float*)it->second.buf.p, nullptr, 0, np, 0, s))) return rc;
@@ -536,7 +544,7 @@ int rz_vision_forward(rz_handle_t m, const float* px, int B, int C, int Himg, in
             const size_t es = dsize(m->dt);
             const char* qb = (const char*)m->qk.p;
             const char* kb = qb + (size_t)H * np * 64 * es;
-            RZ_HIP(flash_attn(m->dt, qb, kb, m->vt.p, m->ctx.p, (int64_t)2 * H * np * 64, B, H, nv, np, s));
+            RZ_HIP(flash_attn(m->dt, qb, kb, m->vt.p, m->ctx.p, (int64_t)2 * H * np * 64, Bc, H, nv, np, s));
         }
         if ((rc = gemm(m, EPI_RESID_SCALE, m->ctx.p, D, b.wo.p, D, M, D, D, (const float*)b.bo.p, nullptr, 0, (const float*)b.ls1.p, h, D, np, 0, s))) return rc;
         {
@@ -554,12 +562,13 @@ int rz_vision_forward(rz_handle_t m, const float* px, int B, int C, int Himg, in
         ProfScope ps(m, RZ_PROF_ROWOPS, s);
         RZ_HIP(launch_layernorm(m->dt, h, (const float*)m->vit_ln_g.p, (const float*)m->vit_ln_b.p, eps, nullptr, h, M, D, s));
     }
+    }   // chunk loop
     m->last_batch = B;
     m->last_nvalid = nv;
     m->last_npad = np;
     if (tokens_out) {
         ProfScope ps(m, RZ_PROF_ROWOPS, s);
-        RZ_HIP(launch_copy_tokens(h, tokens_out, B, nv, np, D, s));
+        RZ_HIP(launch_copy_tokens((const float*)m->h.p, tokens_out, B, nv, np, D, s));
     }
     return 0;
 }
@@ -701,6 +710,7 @@ int rz_set_option(const char* name, int value) {
     if (!strcmp(name, "gemm_v1_only")) { gemm_force_v1(value != 0); return 0; }
     if (!strcmp(name, "gemm_variant")) { gemm_set_variant(value); return 0; }
     if (!strcmp(name, "gemm_debug_flags")) { gemm_set_debug_flags(value); return 0; }
+    if (!strcmp(name, "vision_chunk")) { g_vision_chunk = value; return 0; }
     if (!strcmp(name, "attn_variant")) { g_attn_variant = value; return 0; }
     return fail(RZ_ERR_INVALID, std::string("rz_set_option: unknown option ") + name);
 }

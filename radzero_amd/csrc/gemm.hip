@@ -552,6 +552,97 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel_v4(GemmArgs g) {
     gemm_epilogue_lds<T, EPI>(g, hi, wlds, m0 + wm * 128 + 64, n0 + wn * 64, lane);
 }
 
+// ---------------------------------------------------------------------------------------------------
+// v5 (16-bit operands): 256x128 tile, FOUR waves (2x2, 128x64 each), K step of 32 (64-byte rows), three-stage ring
+// (3 x 24 KB) with counted vmcnt — sized so that TWO workgroups share a CU (72 KB LDS, <=256 VGPRs at 2 waves/SIMD).
+// Why: the phase decomposition of v3 (debug flags, tools/kbench.py) shows staging (0.10 ms), MFMA work (0.08 ms) and
+// epilogue (0.08 ms) of a K=768 GEMM adding up serially because ONE workgroup owns the CU; with two independent
+// workgroups one's epilogue / load waits overlap the other's MFMA work.
+// ---------------------------------------------------------------------------------------------------
+constexpr int STAGE5_BYTES = (BM2 + BN) * 64;   // 24 KB
+constexpr int RING5 = 3;
+
+template <typename T, int EPI>
+__global__ __launch_bounds__(256, 2) void gemm_kernel_v5(GemmArgs g) {
+    static_assert(sizeof(T) == 2, "v5 is for 16-bit operands");
+    __shared__ __attribute__((aligned(1024))) char lds[RING5 * STAGE5_BYTES];
+    constexpr bool SWAP = (EPI != EPI_VT);
+    typedef typename Traits<T>::frag frag_t;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int l15 = lane & 15, lg = lane >> 4;
+
+    const int tiles_n = g.N / BN, tiles_m = g.M / BM2;
+    const int bid = xcd_remap(blockIdx.x, tiles_m * tiles_n);
+    int tm, tn;
+    tile_coords<4>(bid, tiles_m, tiles_n, tm, tn);
+    const int m0 = tm * BM2, n0 = tn * BN;
+
+    const char* Ab = reinterpret_cast<const char*>(g.A) + (int64_t)m0 * g.lda * 2;
+    const char* Wb = reinterpret_cast<const char*>(g.W) + (int64_t)n0 * g.ldw * 2;
+    const int64_t lda_b = g.lda * 2, ldw_b = g.ldw * 2;
+    const int nk = g.K / 32;
+
+    auto stage = [&](int kt, int slot) {      // 6 global_load_lds_dwordx4 per wave: 4 for A (256 rows), 2 for W (128 rows)
+        char* sa = lds + slot * STAGE5_BYTES;
+        char* sb = sa + BM2 * 64;
+        const char* ga = Ab + (int64_t)kt * 64;
+        const char* gb = Wb + (int64_t)kt * 64;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int row16 = (wave * 4 + i) * 16;
+            glds_rows16_half(sa + row16 * 64, ga, lda_b, row16, lane);
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int row16 = (wave * 2 + i) * 16;
+            glds_rows16_half(sb + row16 * 64, gb, ldw_b, row16, lane);
+        }
+    };
+    const int foff = half_off(l15, lg);
+
+    f32x4 acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    stage(0, 0);
+    if (nk > 1) stage(1, 1);
+
+    int slot = 0;
+    for (int kt = 0; kt < nk; ++kt) {
+        // retire stage kt; the younger stage (if any) stays in flight across the barrier
+        if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (kt + 2 < nk) stage(kt + 2, slot == 0 ? 2 : slot - 1);      // slot of stage kt-1: every wave is past it
+        const char* sa = lds + slot * STAGE5_BYTES + wm * (128 * 64);
+        const char* sb = lds + slot * STAGE5_BYTES + BM2 * 64 + wn * (64 * 64);
+        if (!(g.debug_flags & 1)) {
+            frag_t fa[8], fb[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) fb[i] = *reinterpret_cast<const frag_t*>(sb + i * (16 * 64) + foff);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) fa[i] = *reinterpret_cast<const frag_t*>(sa + i * (16 * 64) + foff);
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    if (SWAP) acc[i][j] = mma(fb[j], fa[i], acc[i][j]);
+                    else acc[i][j] = mma(fa[i], fb[j], acc[i][j]);
+                }
+        }
+        slot = slot == 2 ? 0 : slot + 1;
+    }
+    if (g.debug_flags & 4) return;
+    const f32x4 (&lo)[4][4] = *reinterpret_cast<const f32x4 (*)[4][4]>(&acc[0]);
+    const f32x4 (&hi)[4][4] = *reinterpret_cast<const f32x4 (*)[4][4]>(&acc[4]);
+    gemm_epilogue<T, EPI>(g, lo, m0 + wm * 128, n0 + wn * 64, l15, lg);
+    gemm_epilogue<T, EPI>(g, hi, m0 + wm * 128 + 64, n0 + wn * 64, l15, lg);
+}
+
 static int g_debug_flags = 0;
 void gemm_set_debug_flags(int f) { g_debug_flags = f; }
 static int g_variant = 0;      // 0 = auto, 1/2/3 = force that kernel where its shape constraints hold
@@ -563,15 +654,19 @@ static hipError_t launch_gemm_t(int epi, const GemmArgs& g, hipStream_t s) {
     const bool ok2 = (g.M % BM2 == 0) && (g.M >= 4 * BM2);
     const bool ok3 = ok2 && (g.N % BN3 == 0);
     const bool ok4 = ok3 && sizeof(T) == 2 && (g.K % 32 == 0);
+    const bool ok5 = ok2 && sizeof(T) == 2 && (g.K % 32 == 0);
     int variant = g_variant;
     if (variant == 0) variant = ok3 ? 3 : 1;     // measured on MI355X (tools/kbench.py): v3 0.825 ms, v1/v2 0.975 ms per layer of 8 images
+    if (variant == 5 && !ok5) variant = ok3 ? 3 : 1;
     if (variant == 4 && !ok4) variant = ok3 ? 3 : 1;
     if (variant == 3 && !ok3) variant = 1;
     if (variant == 2 && !ok2) variant = 1;
-    const int ntiles = variant >= 3 ? (g.M / BM2) * (g.N / BN3) : variant == 2 ? (g.M / BM2) * (g.N / BN) : (g.M / BM) * (g.N / BN);
-    dim3 grid(ntiles), block(variant == 1 ? 256 : 512);
+    const int ntiles = (variant == 3 || variant == 4) ? (g.M / BM2) * (g.N / BN3)
+                       : (variant == 2 || variant == 5) ? (g.M / BM2) * (g.N / BN) : (g.M / BM) * (g.N / BN);
+    dim3 grid(ntiles), block((variant == 1 || variant == 5) ? 256 : 512);
 #define RZ_CASE(E) \
-    case E: if (variant == 4) { if constexpr (sizeof(T) == 2) hipLaunchKernelGGL((gemm_kernel_v4<T, E>), grid, block, 0, s, g); } \
+    case E: if (variant == 5) { if constexpr (sizeof(T) == 2) hipLaunchKernelGGL((gemm_kernel_v5<T, E>), grid, block, 0, s, g); } \
+            else if (variant == 4) { if constexpr (sizeof(T) == 2) hipLaunchKernelGGL((gemm_kernel_v4<T, E>), grid, block, 0, s, g); } \
             else if (variant == 3) hipLaunchKernelGGL((gemm_kernel_v3<T, E>), grid, block, 0, s, g); \
             else if (variant == 2) hipLaunchKernelGGL((gemm_kernel_v2<T, E>), grid, block, 0, s, g); \
             else hipLaunchKernelGGL((gemm_kernel<T, E>), grid, block, 0, s, g); break;

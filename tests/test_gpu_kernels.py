@@ -156,7 +156,7 @@ def test_upsample(lib, g, size):
     assert (out_s.cpu() - torch.sigmoid(ref)).abs().max().item() <= 1e-5
 
 
-@pytest.mark.parametrize("variant", [1, 2, 3, 4])
+@pytest.mark.parametrize("variant", [1, 2, 3, 4, 5])
 @pytest.mark.parametrize("dt", ["f32", "bf16", "f16"])
 def test_gemm_variants_agree(lib, variant, dt):
     """All tile variants (128x128x2-stage, 256x128x3-stage counted-vmcnt, 256x256) against the fp32 reference,
