@@ -39,7 +39,8 @@ def build(force: bool = False, verbose: bool = False) -> str:
         raise RuntimeError(f"hipcc not found at {HIPCC}; cannot build libradzero_hip.so")
     obj_dir = os.path.join(PKG_DIR, "build")
     os.makedirs(obj_dir, exist_ok=True)
-    flags = [f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
+    flags = [f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "-Werror=uninitialized",
+             "-Werror=return-type"]
 
     def cc(src):
         obj = os.path.join(obj_dir, src.replace(".hip", ".o"))
@@ -47,8 +48,8 @@ def build(force: bool = False, verbose: bool = False) -> str:
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"hipcc failed for {src}:\n{r.stderr}")
-        if verbose and r.stderr:
-            print(r.stderr, file=sys.stderr)
+        if r.stderr and (verbose or "-Wuninitialized" in r.stderr or "-Wreturn-type" in r.stderr or "-Wsometimes-uninitialized" in r.stderr):
+            print(r.stderr, file=sys.stderr)         # these warnings have been real bugs: never hide them
         return obj
 
     with ThreadPoolExecutor(max_workers=min(6, os.cpu_count() or 1)) as ex:

@@ -26,6 +26,7 @@ int fail(int code, const std::string& msg) {
 // 0 = auto (= 1: measured fastest in bench.py, 1000 TFLOP/s); 1 = 16x16x32 kernel, 4 waves/128 q rows; 8 = same kernel, 8 waves/256 q rows;
 // 2 = 32x32x16 kernel, 2-stage ring; 3 = 32x32x16 kernel, 3-stage ring
 int g_vision_chunk = 0;   // images per pass of rz_vision_forward (0 = whole batch)
+int g_vision_streams = 1; // 2 = split the batch over two internal HIP streams
 int g_attn_variant = 0;
 
 hipError_t flash_attn(int dt, const void* q, const void* k, const void* vt, void* ctx, int64_t bs, int B, int H, int nv, int np,
@@ -125,6 +126,9 @@ struct rz_model {
     float prof_ms[RZ_PROF_NFAM] = {0, 0, 0, 0};
     int64_t prof_n[RZ_PROF_NFAM] = {0, 0, 0, 0};
     std::vector<void*> allocs;
+    hipStream_t side[2] = {nullptr, nullptr};
+    hipEvent_t side_done[2] = {nullptr, nullptr}, fork = nullptr;
+    bool side_ready = false;
 
     hipError_t upload(Tensor& t, const float* src, size_t n, bool as_compute) {
         size_t es = as_compute ? dsize(dt) : 4;
@@ -350,6 +354,10 @@ int rz_destroy(rz_handle_t m) {
                       &m->th, &m->txn, &m->tqkv, &m->tctx, &m->tmid, &m->tsum};
     for (DevBuf* b : bufs) b->release();
     for (auto& e : m->ev_pool) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
+    if (m->side_ready) {
+        for (int i = 0; i < 2; ++i) { (void)hipStreamDestroy(m->side[i]); (void)hipEventDestroy(m->side_done[i]); }
+        (void)hipEventDestroy(m->fork);
+    }
     delete m;
     return 0;
 }
@@ -513,56 +521,87 @@ int rz_vision_forward(rz_handle_t m, const float* px, int B, int C, int Himg, in
         return fail(RZ_ERR_STATE, "rz_vision_forward: workspace too small (rz_reserve)");
     const int D = m->D, H = m->H, F = m->F;
     const float eps = m->cfg.vit_layer_norm_eps;
-    // Images are independent on this path: process them in chunks so that the per-layer intermediates (xn, qk, vT, ctx,
-    // mid) are reused from a smaller, cache-friendlier footprint; the residual stream keeps all B images for VL-CABS.
-    const int chunk = (g_vision_chunk > 0 && g_vision_chunk < B) ? g_vision_chunk : B;
-    for (int c0 = 0; c0 < B; c0 += chunk) {
-    const int Bc = std::min(chunk, B - c0);
-    const int M = Bc * np;
-    float* h = (float*)m->h.p + (size_t)c0 * np * D;
-    const float* pxc = px + (size_t)c0 * C * Himg * Wimg;
+    // Images are independent on this path.  The batch can be split into chunks, each with its own slice of every
+    // intermediate buffer; with vision_streams = 2 the two halves run on two internal streams (fork/join by events on
+    // the caller's stream) so that one half's MFMA-bound attention overlaps the other half's memory-bound GEMMs / LNs.
+    auto run_chunk = [&](int c0, int Bc, hipStream_t s) -> int {
+        int rc = 0;
+        const int M = Bc * np;
+        const size_t es = dsize(m->dt);
+        const size_t row0 = (size_t)c0 * np;                                   // first token row of this chunk
+        float* h = (float*)m->h.p + row0 * D;
+        const float* pxc = px + (size_t)c0 * C * Himg * Wimg;
+        char* xn = (char*)m->xn.p + row0 * D * es;
+        char* qkb = (char*)m->qk.p + row0 * 2 * D * es;
+        char* vtb = (char*)m->vt.p + row0 * D * es;
+        char* ctxb = (char*)m->ctx.p + row0 * D * es;
+        char* mid = (char*)m->mid.p + row0 * std::max((size_t)F, (size_t)m->KPAD) * es;
 
-    {   // patch embedding: im2col + GEMM with (pos | cls | bias) table epilogue
-        ProfScope ps(m, RZ_PROF_ROWOPS, s);
-        RZ_HIP(launch_im2col(m->dt, pxc, m->mid.p, Bc, C, Himg, Wimg, P, gh, gw, np, m->KPAD, s));
-    }
-    if ((rc = gemm(m, EPI_PATCH, m->mid.p, m->KPAD, m->patch_w.p, m->KPAD, M, D, m->KPAD, nullptr, h, D,
-                   (const float*)it->second.buf.p, nullptr, 0, np, 0, s))) return rc;
+        {   // patch embedding: im2col + GEMM with (pos | cls | bias) table epilogue
+            ProfScope ps(m, RZ_PROF_ROWOPS, s);
+            RZ_HIP(launch_im2col(m->dt, pxc, mid, Bc, C, Himg, Wimg, P, gh, gw, np, m->KPAD, s));
+        }
+        if ((rc = gemm(m, EPI_PATCH, mid, m->KPAD, m->patch_w.p, m->KPAD, M, D, m->KPAD, nullptr, h, D,
+                       (const float*)it->second.buf.p, nullptr, 0, np, 0, s))) return rc;
 
-    const int nblocks = (int)m->blocks.size();
-    for (int li = 0; li < nblocks; ++li) {
-        const DinoBlock& b = m->blocks[li];
-        {
-            ProfScope ps(m, RZ_PROF_ROWOPS, s);
-            RZ_HIP(launch_layernorm(m->dt, h, (const float*)b.ln1_g.p, (const float*)b.ln1_b.p, eps, m->xn.p, nullptr, M, D, s));
+        const int nblocks = (int)m->blocks.size();
+        for (int li = 0; li < nblocks; ++li) {
+            const DinoBlock& b = m->blocks[li];
+            {
+                ProfScope ps(m, RZ_PROF_ROWOPS, s);
+                RZ_HIP(launch_layernorm(m->dt, h, (const float*)b.ln1_g.p, (const float*)b.ln1_b.p, eps, xn, nullptr, M, D, s));
+            }
+            if ((rc = gemm(m, EPI_HEADS, xn, D, b.wqk.p, D, M, 2 * D, D, (const float*)b.bqk.p, qkb, 0, nullptr, nullptr, 0, np, 2 * H, s))) return rc;
+            if ((rc = gemm(m, EPI_VT, xn, D, b.wv.p, D, M, D, D, (const float*)b.bv.p, vtb, 0, nullptr, nullptr, 0, np, H, s))) return rc;
+            {
+                ProfScope ps(m, RZ_PROF_ATTN, s);
+                // q heads are heads [0,H) and k heads [H,2H) of the [B][2H][np][64] tensor
+                const char* qb = (const char*)qkb;
+                const char* kb = qb + (size_t)H * np * 64 * es;
+                RZ_HIP(flash_attn(m->dt, qb, kb, vtb, ctxb, (int64_t)2 * H * np * 64, Bc, H, nv, np, s));
+            }
+            if ((rc = gemm(m, EPI_RESID_SCALE, ctxb, D, b.wo.p, D, M, D, D, (const float*)b.bo.p, nullptr, 0, (const float*)b.ls1.p, h, D, np, 0, s))) return rc;
+            {
+                ProfScope ps(m, RZ_PROF_ROWOPS, s);
+                RZ_HIP(launch_layernorm(m->dt, h, (const float*)b.ln2_g.p, (const float*)b.ln2_b.p, eps, xn, nullptr, M, D, s));
+            }
+            if ((rc = gemm(m, EPI_GELU, xn, D, b.w1.p, D, M, F, D, (const float*)b.b1.p, mid, F, nullptr, nullptr, 0, np, 0, s))) return rc;
+            if ((rc = gemm(m, EPI_RESID_SCALE, mid, F, b.w2.p, F, M, D, F, (const float*)b.b2.p, nullptr, 0, (const float*)b.ls2.p, h, D, np, 0, s))) return rc;
+            if (li == m->cfg.vit_layers - 1) {   // Dinov2Model.layernorm (TF:dinov2/modeling_dinov2.py:469); align blocks follow
+                ProfScope ps(m, RZ_PROF_ROWOPS, s);
+                RZ_HIP(launch_layernorm(m->dt, h, (const float*)m->vit_ln_g.p, (const float*)m->vit_ln_b.p, eps, nullptr, h, M, D, s));
+            }
         }
-        if ((rc = gemm(m, EPI_HEADS, m->xn.p, D, b.wqk.p, D, M, 2 * D, D, (const float*)b.bqk.p, m->qk.p, 0, nullptr, nullptr, 0, np, 2 * H, s))) return rc;
-        if ((rc = gemm(m, EPI_VT, m->xn.p, D, b.wv.p, D, M, D, D, (const float*)b.bv.p, m->vt.p, 0, nullptr, nullptr, 0, np, H, s))) return rc;
-        {
-            ProfScope ps(m, RZ_PROF_ATTN, s);
-            // q heads are heads [0,H) and k heads [H,2H) of the [B][2H][np][64] tensor
-            const size_t es = dsize(m->dt);
-            const char* qb = (const char*)m->qk.p;
-            const char* kb = qb + (size_t)H * np * 64 * es;
-            RZ_HIP(flash_attn(m->dt, qb, kb, m->vt.p, m->ctx.p, (int64_t)2 * H * np * 64, Bc, H, nv, np, s));
-        }
-        if ((rc = gemm(m, EPI_RESID_SCALE, m->ctx.p, D, b.wo.p, D, M, D, D, (const float*)b.bo.p, nullptr, 0, (const float*)b.ls1.p, h, D, np, 0, s))) return rc;
-        {
-            ProfScope ps(m, RZ_PROF_ROWOPS, s);
-            RZ_HIP(launch_layernorm(m->dt, h, (const float*)b.ln2_g.p, (const float*)b.ln2_b.p, eps, m->xn.p, nullptr, M, D, s));
-        }
-        if ((rc = gemm(m, EPI_GELU, m->xn.p, D, b.w1.p, D, M, F, D, (const float*)b.b1.p, m->mid.p, F, nullptr, nullptr, 0, np, 0, s))) return rc;
-        if ((rc = gemm(m, EPI_RESID_SCALE, m->mid.p, F, b.w2.p, F, M, D, F, (const float*)b.b2.p, nullptr, 0, (const float*)b.ls2.p, h, D, np, 0, s))) return rc;
-        if (li == m->cfg.vit_layers - 1) {   // Dinov2Model.layernorm (TF:dinov2/modeling_dinov2.py:469); align blocks follow
+        if (m->cfg.vit_layers == 0) {
             ProfScope ps(m, RZ_PROF_ROWOPS, s);
             RZ_HIP(launch_layernorm(m->dt, h, (const float*)m->vit_ln_g.p, (const float*)m->vit_ln_b.p, eps, nullptr, h, M, D, s));
         }
+        return 0;
+    };
+    const int nstreams = (g_vision_streams == 2 && B >= 2) ? 2 : 1;
+    if (nstreams == 2) {
+        if (!m->side_ready) {
+            for (int i = 0; i < 2; ++i) {
+                RZ_HIP(hipStreamCreateWithFlags(&m->side[i], hipStreamNonBlocking));
+                RZ_HIP(hipEventCreateWithFlags(&m->side_done[i], hipEventDisableTiming));
+            }
+            RZ_HIP(hipEventCreateWithFlags(&m->fork, hipEventDisableTiming));
+            m->side_ready = true;
+        }
+        RZ_HIP(hipEventRecord(m->fork, s));
+        const int half = (B + 1) / 2;
+        for (int i = 0; i < 2; ++i) {
+            RZ_HIP(hipStreamWaitEvent(m->side[i], m->fork, 0));
+            const int c0 = i * half, Bc = i == 0 ? half : B - half;
+            if ((rc = run_chunk(c0, Bc, m->side[i]))) return rc;
+            RZ_HIP(hipEventRecord(m->side_done[i], m->side[i]));
+            RZ_HIP(hipStreamWaitEvent(s, m->side_done[i], 0));
+        }
+    } else {
+        const int chunk = (g_vision_chunk > 0 && g_vision_chunk < B) ? g_vision_chunk : B;
+        for (int c0 = 0; c0 < B; c0 += chunk)
+            if ((rc = run_chunk(c0, std::min(chunk, B - c0), s))) return rc;
     }
-    if (m->cfg.vit_layers == 0) {
-        ProfScope ps(m, RZ_PROF_ROWOPS, s);
-        RZ_HIP(launch_layernorm(m->dt, h, (const float*)m->vit_ln_g.p, (const float*)m->vit_ln_b.p, eps, nullptr, h, M, D, s));
-    }
-    }   // chunk loop
     m->last_batch = B;
     m->last_nvalid = nv;
     m->last_npad = np;
@@ -711,6 +750,7 @@ int rz_set_option(const char* name, int value) {
     if (!strcmp(name, "gemm_variant")) { gemm_set_variant(value); return 0; }
     if (!strcmp(name, "gemm_debug_flags")) { gemm_set_debug_flags(value); return 0; }
     if (!strcmp(name, "vision_chunk")) { g_vision_chunk = value; return 0; }
+    if (!strcmp(name, "vision_streams")) { g_vision_streams = value; return 0; }
     if (!strcmp(name, "attn_variant")) { g_attn_variant = value; return 0; }
     return fail(RZ_ERR_INVALID, std::string("rz_set_option: unknown option ") + name);
 }

@@ -200,23 +200,44 @@ hipError_t launch_vlcabs(const float* tokens, const float* ln_gamma, const float
 }
 
 // ---- bilinear upsample, align_corners=False (F.interpolate semantics), optional sigmoid ----
+// One thread produces 4 consecutive pixels of a row (16-byte store); the two source rows of an output row are the
+// same for the whole row, so their addresses/weights are computed once per thread.  HBM-write bound:
+// n_maps*H*W*4 bytes (4.29 GB at BASELINE cfg 4).
 __global__ __launch_bounds__(256) void upsample_bilinear_kernel(const float* __restrict__ maps, int64_t map_stride,
                                                                 float* __restrict__ out, int g, int Hout, int Wout,
                                                                 float sy, float sx, int apply_sigmoid) {
     const int m = blockIdx.z;
     const int y = blockIdx.y;
-    const int x = blockIdx.x * blockDim.x + threadIdx.x;
-    if (x >= Wout) return;
+    const int x4 = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    if (x4 >= Wout) return;
     const float* src = maps + (int64_t)m * map_stride;
     float fy = sy * (y + 0.5f) - 0.5f; fy = fy < 0.f ? 0.f : fy;
-    float fx = sx * (x + 0.5f) - 0.5f; fx = fx < 0.f ? 0.f : fx;
-    const int y0 = (int)fy, x0 = (int)fx;
-    const int y1 = y0 + (y0 < g - 1 ? 1 : 0), x1 = x0 + (x0 < g - 1 ? 1 : 0);
-    const float ly = fy - y0, lx = fx - x0;
-    const float hy = 1.f - ly, hx = 1.f - lx;
-    float v = hy * (hx * src[y0 * g + x0] + lx * src[y0 * g + x1]) + ly * (hx * src[y1 * g + x0] + lx * src[y1 * g + x1]);
-    if (apply_sigmoid) v = 1.0f / (1.0f + expf(-v));
-    out[((int64_t)m * Hout + y) * Wout + x] = v;
+    const int y0 = (int)fy;
+    const int y1 = y0 + (y0 < g - 1 ? 1 : 0);
+    const float ly = fy - y0, hy = 1.f - ly;
+    const float* r0 = src + y0 * g;
+    const float* r1 = src + y1 * g;
+    float v[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int x = x4 + i;
+        float fx = sx * (x + 0.5f) - 0.5f; fx = fx < 0.f ? 0.f : fx;
+        int x0 = (int)fx;
+        x0 = x0 > g - 1 ? g - 1 : x0;                         // only reachable for x >= Wout (masked below)
+        const int x1 = x0 + (x0 < g - 1 ? 1 : 0);
+        const float lx = fx - x0, hx = 1.f - lx;
+        float t = hy * (hx * r0[x0] + lx * r0[x1]) + ly * (hx * r1[x0] + lx * r1[x1]);
+        if (apply_sigmoid) t = 1.0f / (1.0f + expf(-t));
+        v[i] = t;
+    }
+    float* o = out + ((int64_t)m * Hout + y) * Wout + x4;
+    if (x4 + 3 < Wout && ((((int64_t)m * Hout + y) * Wout + x4) & 3) == 0) {
+        *reinterpret_cast<f32x4*>(o) = (f32x4){v[0], v[1], v[2], v[3]};
+    } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            if (x4 + i < Wout) o[i] = v[i];
+    }
 }
 
 // ---- fused grounding point: argmax over the bilinear-upsampled map WITHOUT writing the map ----
@@ -289,7 +310,7 @@ hipError_t launch_upsample_bilinear(const float* maps, int64_t map_stride, float
                                     int Hout, int Wout, int apply_sigmoid, hipStream_t s) {
     if (M <= 0 || g <= 0 || Hout <= 0 || Wout <= 0 || argmax_out != nullptr) return hipErrorInvalidValue;
     const float sy = (float)g / (float)Hout, sx = (float)g / (float)Wout;
-    hipLaunchKernelGGL(upsample_bilinear_kernel, dim3((Wout + 255) / 256, Hout, M), dim3(256), 0, s, maps, map_stride, out, g,
+    hipLaunchKernelGGL(upsample_bilinear_kernel, dim3((Wout + 1023) / 1024, Hout, M), dim3(256), 0, s, maps, map_stride, out, g,
                        Hout, Wout, sy, sx, apply_sigmoid);
     return hipGetLastError();
 }
