@@ -115,6 +115,17 @@ int rz_upsample_maps(rz_handle_t h, const float* maps_dev, int64_t map_stride, i
 int rz_grounding_points(rz_handle_t h, const float* maps_dev, int64_t map_stride, int n_maps, int grid, int out_h, int out_w,
                         int32_t* xy_out_dev, void* keys_ws_dev, void* stream);
 
+/* ---- InferDataset collate_fn + Blip image processor (inference/dataset.py:31-51; processing.py:31-49, :90-91) on the device:
+ *      cv2.normalize(NORM_MINMAX) to 8 bit (optional) -> grey->RGB -> Pillow bicubic resize of the uint8 image (same 22-bit
+ *      fixed-point tables, built by the host: radzero_amd/preprocess.py) -> * rescale -> (x - mean) / std ----
+ * image_dev: (height, width, channels) of src_dtype 0 = uint8, 1 = uint16, 2 = float32; channels 1 or 3.
+ * bounds_*_dev int32 (out, 2) = (first input index, count); coeffs_*_dev int32 (out, ksize).
+ * workspace_dev: 16 + H*W*C + H*S*C + S*S*C bytes.  pixel_values_out_dev: fp32 (3, out_side, out_side). */
+int rz_preprocess_image(const void* image_dev, int src_dtype, int height, int width, int channels, int out_side,
+                        const int32_t* bounds_h_dev, const int32_t* coeffs_h_dev, int ksize_h, const int32_t* bounds_v_dev,
+                        const int32_t* coeffs_v_dev, int ksize_v, const float* mean3_host, const float* std3_host, float rescale,
+                        int minmax_normalize, void* workspace_dev, float* pixel_values_out_dev, void* stream);
+
 /* ---- per-kernel entry points (used by the parity tests; all pointers device) ---- */
 /* C = A[M,K] W[N,K]^T + bias; dtype of A/W/out = rz_dtype; epilogue: 0 store, 1 GELU(erf), 7 store fp32 */
 int rz_gemm(int dtype, int epilogue, const void* a_dev, const void* w_dev, const float* bias_dev, void* out_dev, int m,

@@ -1,0 +1,116 @@
+"""Checkpoint import: read a RadZero / CxrAlignModel checkpoint directory (or file) written by
+HF `save_pretrained` (`model.safetensors` / `pytorch_model.bin`, optionally sharded with an index json) into the
+name -> fp32 array dict `RadZeroModel.load_state_dict` takes.  The tensor names are the reference's own
+(exp/cxr_pt/model/modeling.py:55-86); a leading "model." / "module." prefix (Trainer / DDP wrappers) is stripped.
+`config_from_hf` reads the hyper-parameters the kernels need from the checkpoint's config.json
+(exp/cxr_pt/model/configuration.py:107-129) instead of assuming the released values.
+"""
+from __future__ import annotations
+
+import json
+import os
+from typing import Dict
+
+import numpy as np
+
+from .config import RadZeroConfig
+
+_PREFIXES = ("model.", "module.", "base_model.model.")
+
+
+def _strip(name: str) -> str:
+    changed = True
+    while changed:
+        changed = False
+        for p in _PREFIXES:
+            if name.startswith(p):
+                name, changed = name[len(p):], True
+    return name
+
+
+def _read_file(path: str) -> Dict[str, np.ndarray]:
+    if path.endswith(".safetensors"):
+        from safetensors import safe_open
+        out = {}
+        with safe_open(path, framework="pt") as f:           # "pt": bf16 checkpoints have no numpy dtype
+            for k in f.keys():
+                out[k] = f.get_tensor(k).float().numpy()
+        return out
+    import torch
+    sd = torch.load(path, map_location="cpu", weights_only=True)
+    if "state_dict" in sd and isinstance(sd["state_dict"], dict):
+        sd = sd["state_dict"]
+    return {k: v.float().numpy() for k, v in sd.items() if hasattr(v, "float")}
+
+
+def load_checkpoint(path: str) -> Dict[str, np.ndarray]:
+    """`path`: a checkpoint directory, or a .safetensors / .bin / .pt file."""
+    files = []
+    if os.path.isdir(path):
+        for index in ("model.safetensors.index.json", "pytorch_model.bin.index.json"):
+            ip = os.path.join(path, index)
+            if os.path.exists(ip):
+                shards = sorted(set(json.load(open(ip))["weight_map"].values()))
+                files = [os.path.join(path, s) for s in shards]
+                break
+        if not files:
+            for single in ("model.safetensors", "pytorch_model.bin"):
+                if os.path.exists(os.path.join(path, single)):
+                    files = [os.path.join(path, single)]
+                    break
+        if not files:
+            raise FileNotFoundError(f"no model.safetensors / pytorch_model.bin (or index) under {path}")
+    else:
+        files = [path]
+    out: Dict[str, np.ndarray] = {}
+    for f in files:
+        for k, v in _read_file(f).items():
+            out[_strip(k)] = np.ascontiguousarray(v, dtype=np.float32)
+    return out
+
+
+def save_checkpoint(state_dict, path: str) -> str:
+    """Write `model.safetensors` under `path` with the reference's tensor names (round-trip / test helper)."""
+    from safetensors.numpy import save_file
+    os.makedirs(path, exist_ok=True)
+    f = os.path.join(path, "model.safetensors")
+    save_file({k: np.ascontiguousarray(np.asarray(v, np.float32)) for k, v in state_dict.items()}, f)
+    return f
+
+
+def config_from_hf(path_or_dict) -> RadZeroConfig:
+    """RadZeroConfig from a CxrAlignConfig config.json (nested vision_config / text_config /
+    align_transformer_config / loss kwargs); absent fields keep the released defaults."""
+    d = path_or_dict
+    if isinstance(d, str):
+        p = os.path.join(d, "config.json") if os.path.isdir(d) else d
+        d = json.load(open(p))
+    v = d.get("vision_config", {}) or {}
+    t = d.get("text_config", {}) or {}
+    a = d.get("align_transformer_config", {}) or {}
+    loss = ((d.get("kwargs", d).get("loss", {}) or {}).get("RadZeroLoss", {}) or {})
+    base = RadZeroConfig()
+    cfg = RadZeroConfig(
+        hidden_size=v.get("hidden_size", base.hidden_size),
+        num_attention_heads=v.get("num_attention_heads", base.num_attention_heads),
+        mlp_ratio=v.get("mlp_ratio", base.mlp_ratio),
+        patch_size=v.get("patch_size", base.patch_size),
+        num_channels=v.get("num_channels", base.num_channels),
+        pretrain_image_size=v.get("image_size", base.pretrain_image_size),
+        vit_layers=v.get("num_hidden_layers", base.vit_layers),
+        vit_layer_norm_eps=v.get("layer_norm_eps", base.vit_layer_norm_eps),
+        align_layers=a.get("num_hidden_layers", base.align_layers),
+        vocab_size=t.get("vocab_size", base.vocab_size),
+        max_position_embeddings=t.get("max_position_embeddings", base.max_position_embeddings),
+        text_layers=t.get("num_hidden_layers", base.text_layers),
+        text_intermediate_size=t.get("intermediate_size", base.text_intermediate_size),
+        text_layer_norm_eps=t.get("layer_norm_eps", base.text_layer_norm_eps),
+        relative_attention_num_buckets=t.get("relative_attention_num_buckets", base.relative_attention_num_buckets),
+        loss_temperature=loss.get("loss_temperature", base.loss_temperature),
+        sim_op=loss.get("sim_op", base.sim_op),
+    )
+    if a.get("use_layer_norm"):
+        raise NotImplementedError("align_transformer_config.use_layer_norm=True is not part of the released model")
+    if (d.get("kwargs", d).get("compute_logits_type", "radzero")) != "radzero":
+        raise NotImplementedError("only compute_logits_type == 'radzero' is implemented")
+    return cfg

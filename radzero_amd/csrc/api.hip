@@ -698,6 +698,23 @@ int rz_grounding_points(rz_handle_t m, const float* maps, int64_t map_stride, in
     return 0;
 }
 
+int rz_preprocess_image(const void* image, int src_dtype, int height, int width, int channels, int out_side, const int32_t* bounds_h,
+                        const int32_t* coeffs_h, int ksize_h, const int32_t* bounds_v, const int32_t* coeffs_v, int ksize_v,
+                        const float* mean3_host, const float* std3_host, float rescale, int minmax_normalize, void* workspace,
+                        float* pixel_values_out, void* stream) {
+    if (!image || !bounds_h || !coeffs_h || !bounds_v || !coeffs_v || !mean3_host || !std3_host || !workspace || !pixel_values_out)
+        return fail(RZ_ERR_INVALID, "rz_preprocess_image: null argument");
+    if (height <= 0 || width <= 0 || out_side <= 0 || (channels != 1 && channels != 3) || ksize_h <= 0 || ksize_v <= 0)
+        return fail(RZ_ERR_INVALID, "rz_preprocess_image: bad shape");
+    if (src_dtype < 0 || src_dtype > 2 || (!minmax_normalize && src_dtype != 0))
+        return fail(RZ_ERR_INVALID, "rz_preprocess_image: source dtype (without min-max normalisation the image must be uint8)");
+    unsigned* mm = (unsigned*)workspace;                            // first 16 bytes: min/max scratch
+    unsigned char* ws8 = (unsigned char*)workspace + 16;
+    RZ_HIP(launch_preprocess(image, src_dtype, height, width, channels, out_side, bounds_h, coeffs_h, ksize_h, bounds_v, coeffs_v, ksize_v,
+                             mean3_host, std3_host, rescale, ws8, mm, pixel_values_out, minmax_normalize, (hipStream_t)stream));
+    return 0;
+}
+
 int rz_gemm(int dtype, int epilogue, const void* a, const void* w, const float* bias, void* out, int M, int N, int K, void* stream) {
     if (!a || !w || !out) return fail(RZ_ERR_INVALID, "rz_gemm: null argument");
     if (epilogue != EPI_STORE && epilogue != EPI_GELU && epilogue != EPI_STORE_F32) return fail(RZ_ERR_INVALID, "rz_gemm: epilogue");

@@ -1,0 +1,130 @@
+// radzero_hip — device-side image preprocessing, integer/byte work, gfx950.
+// Replaces the CPU DataLoader path exp/cxr_pt/inference/dataset.py:31-51 (cv2 NORM_MINMAX -> 8 bit) followed by the Blip
+// image processor (convert RGB, PIL bicubic resize of the uint8 image, rescale 1/255, normalise; processing.py:31-49, :90-91).
+//   minmax_kernel   : global min / max of the raw pixels (any of u8 / u16 / f32), all channels together (cv2.normalize)
+//   to8_kernel      : v8 = round_half_even(v * scale + shift), saturated to [0, 255]
+//   resample_h/v    : Pillow's 8-bit separable resampling (ImagingResample): coefficient tables in 22-bit fixed point are
+//                     built on the host exactly as Pillow builds them; horizontal pass first, uint8 intermediate
+//   normalize_kernel: out[c][y][x] = (v8 / 255 - mean[c]) / std[c], grey replicated to 3 channels
+#include "rz_common.h"
+#include "rz_kernels.h"
+
+namespace rz {
+
+__device__ __forceinline__ unsigned f2ord(float f) { unsigned u = __float_as_uint(f); return (u & 0x80000000u) ? ~u : (u | 0x80000000u); }
+__device__ __forceinline__ float ord2f(unsigned u) { return __uint_as_float((u & 0x80000000u) ? (u & 0x7FFFFFFFu) : ~u); }
+
+template <typename S> __device__ __forceinline__ float load_px(const S* p, int64_t i) { return (float)p[i]; }
+
+template <typename S>
+__global__ __launch_bounds__(256) void minmax_kernel(const S* __restrict__ img, int64_t n, unsigned* __restrict__ mm) {
+    float lo = INFINITY, hi = -INFINITY;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const float v = load_px(img, i);
+        lo = fminf(lo, v);
+        hi = fmaxf(hi, v);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { lo = fminf(lo, __shfl_xor(lo, o, 64)); hi = fmaxf(hi, __shfl_xor(hi, o, 64)); }
+    if ((threadIdx.x & 63) == 0) { atomicMin(mm, f2ord(lo)); atomicMax(mm + 1, f2ord(hi)); }
+}
+
+template <typename S>
+__global__ __launch_bounds__(256) void to8_kernel(const S* __restrict__ img, int64_t n, const unsigned* __restrict__ mm,
+                                                  unsigned char* __restrict__ out) {
+    const float smin = ord2f(mm[0]), smax = ord2f(mm[1]);
+    // cv2.normalize(NORM_MINMAX, alpha=0, beta=255): scale = 255 / (smax - smin) (0 when the image is constant), shift = -smin*scale
+    const double scale = (double)(smax - smin) > 2.220446049250313e-16 ? 255.0 / (double)(smax - smin) : 0.0;
+    const double shift = -(double)smin * scale;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const double v = (double)load_px(img, i) * scale + shift;
+        int r = (int)rint(v);                          // round half to even (cvRound)
+        r = r < 0 ? 0 : (r > 255 ? 255 : r);
+        out[i] = (unsigned char)r;
+    }
+}
+
+// horizontal pass: in [rows][in_w][C] u8 -> out [rows][out_w][C] u8
+__global__ __launch_bounds__(256) void resample_h_kernel(const unsigned char* __restrict__ in, unsigned char* __restrict__ out,
+                                                         const int* __restrict__ bounds, const int* __restrict__ kk, int ksize, int rows,
+                                                         int in_w, int out_w, int C) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= out_w * C) return;
+    const int xx = idx / C, c = idx - xx * C;
+    const int y = blockIdx.y;
+    const int xmin = bounds[2 * xx], xcnt = bounds[2 * xx + 1];
+    const int* k = kk + xx * ksize;
+    int ss = 1 << 21;
+    const unsigned char* row = in + ((int64_t)y * in_w + xmin) * C + c;
+    for (int x = 0; x < xcnt; ++x) ss += (int)row[(int64_t)x * C] * k[x];
+    ss >>= 22;
+    out[((int64_t)y * out_w + xx) * C + c] = (unsigned char)(ss < 0 ? 0 : (ss > 255 ? 255 : ss));
+}
+
+// vertical pass: in [in_h][w][C] -> out [out_h][w][C]
+__global__ __launch_bounds__(256) void resample_v_kernel(const unsigned char* __restrict__ in, unsigned char* __restrict__ out,
+                                                         const int* __restrict__ bounds, const int* __restrict__ kk, int ksize, int w, int C) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= w * C) return;
+    const int yy = blockIdx.y;
+    const int ymin = bounds[2 * yy], ycnt = bounds[2 * yy + 1];
+    const int* k = kk + yy * ksize;
+    int ss = 1 << 21;
+    const unsigned char* col = in + (int64_t)ymin * w * C + idx;
+    for (int y = 0; y < ycnt; ++y) ss += (int)col[(int64_t)y * w * C] * k[y];
+    ss >>= 22;
+    out[(int64_t)yy * w * C + idx] = (unsigned char)(ss < 0 ? 0 : (ss > 255 ? 255 : ss));
+}
+
+// u8 [S][S][C] -> fp32 [3][S][S]
+__global__ __launch_bounds__(256) void normalize_kernel(const unsigned char* __restrict__ in, float* __restrict__ out, int n_px, int C,
+                                                        float rescale, float m0, float m1, float m2, float s0, float s1, float s2) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n_px) return;
+    const float mean[3] = {m0, m1, m2}, sd[3] = {s0, s1, s2};
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const float v = (float)in[(int64_t)i * C + (C == 3 ? c : 0)] * rescale;
+        out[(int64_t)c * n_px + i] = (v - mean[c]) / sd[c];
+    }
+}
+
+template <typename S>
+static hipError_t minmax_to8(const S* img, int64_t n, unsigned* mm, unsigned char* out8, hipStream_t s) {
+    const unsigned init[2] = {0xFFFFFFFFu, 0u};
+    hipError_t e = hipMemcpyAsync(mm, init, sizeof init, hipMemcpyHostToDevice, s);
+    if (e != hipSuccess) return e;
+    const int nb = (int)std::min<int64_t>((n + 255) / 256, 2048);
+    hipLaunchKernelGGL(minmax_kernel<S>, dim3(nb), dim3(256), 0, s, img, n, mm);
+    hipLaunchKernelGGL(to8_kernel<S>, dim3(nb), dim3(256), 0, s, img, n, mm, out8);
+    return hipGetLastError();
+}
+
+hipError_t launch_preprocess(const void* img, int src_dtype, int H, int W, int C, int S, const int* bounds_h, const int* kk_h, int ksize_h,
+                             const int* bounds_v, const int* kk_v, int ksize_v, const float* mean, const float* stdv, float rescale,
+                             unsigned char* ws8, unsigned* mm, float* out, int minmax_normalize, hipStream_t s) {
+    if (!img || !out || !ws8 || H <= 0 || W <= 0 || (C != 1 && C != 3) || S <= 0) return hipErrorInvalidValue;
+    const int64_t n = (int64_t)H * W * C;
+    unsigned char* a8 = ws8;                       // [H][W][C]
+    unsigned char* b8 = a8 + n;                    // [H][S][C]
+    unsigned char* c8 = b8 + (int64_t)H * S * C;   // [S][S][C]
+    hipError_t e = hipSuccess;
+    if (minmax_normalize) {
+        if (src_dtype == 0) e = minmax_to8((const unsigned char*)img, n, mm, a8, s);
+        else if (src_dtype == 1) e = minmax_to8((const unsigned short*)img, n, mm, a8, s);
+        else if (src_dtype == 2) e = minmax_to8((const float*)img, n, mm, a8, s);
+        else return hipErrorInvalidValue;
+        if (e != hipSuccess) return e;
+    } else {
+        if (src_dtype != 0) return hipErrorInvalidValue;
+        e = hipMemcpyAsync(a8, img, n, hipMemcpyDeviceToDevice, s);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(resample_h_kernel, dim3((S * C + 255) / 256, H), dim3(256), 0, s, a8, b8, bounds_h, kk_h, ksize_h, H, W, S, C);
+    hipLaunchKernelGGL(resample_v_kernel, dim3((S * C + 255) / 256, S), dim3(256), 0, s, b8, c8, bounds_v, kk_v, ksize_v, S, C);
+    hipLaunchKernelGGL(normalize_kernel, dim3((S * S + 255) / 256), dim3(256), 0, s, c8, out, S * S, C, rescale, mean[0], mean[1], mean[2],
+                       stdv[0], stdv[1], stdv[2]);
+    return hipGetLastError();
+}
+
+}  // namespace rz

@@ -89,6 +89,13 @@ hipError_t launch_upsample_bilinear(const float* maps, int64_t map_stride, float
 hipError_t launch_grounding_points(const float* maps, int64_t map_stride, unsigned long long* keys_ws, int* xy_out, int M, int g,
                                    int Hout, int Wout, hipStream_t s);
 
+// device-side image preprocessing (preprocess.hip): raw image [H][W][C] (src_dtype 0 u8 / 1 u16 / 2 f32) -> fp32 [3][S][S].
+// bounds_*/kk_*: Pillow resampling tables (device, int32): bounds [out][2] = (first, count), kk [out][ksize] 22-bit fixed point.
+// ws8: scratch of H*W*C + H*S*C + S*S*C bytes; mm: 2 x u32 scratch.
+hipError_t launch_preprocess(const void* img, int src_dtype, int H, int W, int C, int S, const int* bounds_h, const int* kk_h, int ksize_h,
+                             const int* bounds_v, const int* kk_v, int ksize_v, const float* mean, const float* stdv, float rescale,
+                             unsigned char* ws8, unsigned* mm, float* out, int minmax_normalize, hipStream_t s);
+
 // strided gather of valid tokens: src [B][Npad][D] -> dst [B][N][D]
 hipError_t launch_copy_tokens(const float* src, float* dst, int B, int n_valid, int n_pad, int D, hipStream_t s);
 

@@ -122,6 +122,18 @@ class RadZeroModel:
         m.load_state_dict(state_dict)
         return m
 
+    @classmethod
+    def from_pretrained(cls, path: str, torch_dtype=torch.bfloat16, device="cuda:0", config: Optional[RadZeroConfig] = None,
+                        **_ignored) -> "RadZeroModel":
+        """`AutoModel.from_pretrained("Deepnoid/RadZero", trust_remote_code=True, torch_dtype=..., device_map=...)`
+        analogue (README.md:77-82) for a LOCAL checkpoint directory / file (there is no network here)."""
+        from .checkpoint import config_from_hf, load_checkpoint
+        import os
+        if config is None:
+            has_cfg = os.path.isdir(path) and os.path.exists(os.path.join(path, "config.json"))
+            config = config_from_hf(path) if has_cfg else RadZeroConfig()
+        return cls.from_state_dict(load_checkpoint(path), config, torch_dtype=torch_dtype, device=device)
+
     def load_state_dict(self, state_dict, strict: bool = True):
         """Accepts the reference checkpoint's names (numpy arrays or torch tensors, any float dtype)."""
         self._state_dict = state_dict
