@@ -68,21 +68,23 @@ def cpu_baseline(cfg, sd, side, n_prompts, ids, mask):
     from radzero_amd.synthetic import synthetic_pixels
     cores = usable_cores()
     torch.set_num_threads(cores)
-    px = torch.from_numpy(synthetic_pixels(1, side, 1234))
+    nimg = 4                                      # bounded sample: ~10-20 s of CPU work on the box's 16-core share
+    px = torch.from_numpy(synthetic_pixels(nimg, side, 1234))
     enc = {"input_ids": torch.from_numpy(ids), "attention_mask": torch.from_numpy(mask)}
     best = None
-    for impl in ("sdpa",):
+    for impl in ("sdpa",):                        # faster than the eager path of the pinned transformers 4.39.3
         om = OracleModel(sd, cfg, attn_impl=impl)
         with torch.no_grad():
             tf = om.text_features(enc, split_rows=False)
+            om.compute_logits(torch.from_numpy(synthetic_pixels(1, 224, 1)), [enc], text_features=tf)   # warm-up (thread pool, allocator)
             t0 = time.time()
             om.compute_logits(px, [enc], text_features=tf)
             dt = time.time() - t0
         if best is None or dt < best[0]:
             best = (dt, impl)
-    return {"value": round(1.0 / best[0], 5), "unit": "images/s", "cores": cores, "kind": "port",
-            "sample": f"1 image {side}x{side} x {n_prompts} cached prompts, fp32, torch CPU ({best[1]} attention), "
-                      f"single call {best[0]:.1f} s"}
+    return {"value": round(nimg / best[0], 5), "unit": "images/s", "cores": cores, "kind": "port",
+            "sample": f"{nimg} images {side}x{side} x {n_prompts} cached prompts in one batch, fp32, torch CPU "
+                      f"({best[1]} attention), {cores} threads, {best[0]:.1f} s"}
 
 
 def main():
