@@ -45,6 +45,10 @@ hipError_t launch_flash_attn(int dtype, const void* q, const void* k, const void
 hipError_t launch_flash_attn32(int dtype, const void* q, const void* k, const void* vT, void* ctx,
                                int64_t qk_batch_stride, int B, int H, int n_valid, int n_pad, int ring, hipStream_t s);
 
+// software-pipelined 32x32x16 kernel (attention32p.hip), 16-bit operands only
+hipError_t launch_flash_attn32p(int dtype, const void* q, const void* k, const void* vT, void* ctx,
+                                int64_t qk_batch_stride, int B, int H, int n_valid, int n_pad, hipStream_t s);
+
 // MPNet self-attention for short sequences: qkv [T*L][3*H*64] (q|k|v), additive relative-position bias
 // rel_bias[H][num_buckets] via bucket table [L][L] and key-padding mask [T][L]; ctx [T*L][H*64].
 hipError_t launch_text_attn(int dtype, const void* qkv, const float* rel_bias, const int* bucket_tbl,

@@ -84,7 +84,7 @@ def _attn_ref(q, k, v):
     return torch.einsum("bhqk,bhkd->bhqd", torch.softmax(s, -1), v)
 
 
-@pytest.fixture(params=[1, 8, 2, 3], ids=["mfma16", "mfma16x8waves", "mfma32", "mfma32ring3"])
+@pytest.fixture(params=[1, 8, 2, 3, 4], ids=["mfma16", "mfma16x8waves", "mfma32", "mfma32ring3", "mfma32pipelined"])
 def attn_variant(request, lib):
     """Both flash-attention kernels (32x32x16 default, 16x16x32) must pass every attention test."""
     lib.rz_set_option(b"attn_variant", request.param)
@@ -93,7 +93,8 @@ def attn_variant(request, lib):
 
 
 @pytest.mark.parametrize("dt", ["f32", "bf16", "f16"])
-@pytest.mark.parametrize("case", [(1, 2, 257), (2, 12, 362), (1, 3, 64), (1, 1, 1), (1, 2, 1370), (1, 1, 128), (1, 2, 700)])
+@pytest.mark.parametrize("case", [(1, 2, 257), (2, 12, 362), (1, 3, 64), (1, 1, 1), (1, 2, 1370), (1, 1, 128), (1, 2, 700), (1, 1, 192),
+                                  (1, 1, 130), (1, 1, 320)])
 def test_flash_attention(lib, dt, case, attn_variant):
     """n_valid not a multiple of any tile (257, 362, 1370), single key, exact tile multiples."""
     code, tdt = DT[dt]

@@ -29,13 +29,15 @@ def timeit(fn, iters=10, warm=3):
     return a.elapsed_time(b) / iters
 
 
-def bench_attn(images, n=5330, dt=1):
+def bench_attn(images, n=5330, dt=1, zeros=False):
     npad = (n + 127) // 128 * 128
     H = 12
     tdt = {0: torch.float32, 1: torch.bfloat16, 2: torch.float16}[dt]
     q = (torch.randn(images, H, npad, 64, device="cuda") * 0.6).to(tdt)
     k = torch.randn(images, H, npad, 64, device="cuda").to(tdt)
     vt = torch.randn(images, H, 64, npad, device="cuda").to(tdt)
+    if zeros:      # DVFS probe: same instruction stream, no operand toggling
+        q.zero_(); k.zero_(); vt.zero_()
     ctx = torch.empty(images * npad, H * 64, device="cuda", dtype=tdt)
     f = lambda: lib.rz_flash_attention(dt, P(q), P(k), P(vt), P(ctx), images, H, n, npad, ST())
     assert f() == 0, lib.rz_last_error()
@@ -77,6 +79,7 @@ if __name__ == "__main__":
     ap.add_argument("--variant", type=int, default=0)
     ap.add_argument("--attn-variant", type=int, default=0)
     ap.add_argument("--gemm-debug", type=int, default=0)
+    ap.add_argument("--zeros", action="store_true")
     a = ap.parse_args()
     if a.v1:
         lib.rz_set_option(b"gemm_v1_only", 1)
@@ -87,6 +90,6 @@ if __name__ == "__main__":
     if a.variant:
         lib.rz_set_option(b"gemm_variant", a.variant)
     if a.what in ("attn", "all"):
-        bench_attn(a.images, dt=a.dtype)
+        bench_attn(a.images, dt=a.dtype, zeros=a.zeros)
     if a.what in ("gemm", "all"):
         bench_gemm(a.images, dt=a.dtype)
