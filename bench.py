@@ -100,6 +100,7 @@ def main():
                     help="similarity-map post-processing inside the step (BASELINE cfg 4): per-pixel bilinear maps or fused grounding points")
     ap.add_argument("--min-len", type=int, default=6)
     ap.add_argument("--max-len", type=int, default=10)
+    ap.add_argument("--force-dist", action="store_true", help="rehearsal: initialise the RCCL process group even with one rank")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true")
     ap.add_argument("--attn-variant", type=int, default=None, help="A/B switch (rz_set_option): 1 = 16x16x32 4 waves, 8 = 8 waves, 2/3 = 32x32x16 kernel")
@@ -116,9 +117,12 @@ def main():
             raise SystemExit("launch multi-GPU runs with torch.distributed.run (one rank per GPU)")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    if world > 1:
+    use_dist = world > 1 or args.force_dist
+    if use_dist:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group(backend="nccl", device_id=device)
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        dist.init_process_group(backend="nccl", device_id=device, rank=rank, world_size=world)
 
     from radzero_amd.modeling import RadZeroModel
     from radzero_amd.parallel import sharded_text_features
@@ -146,7 +150,8 @@ def main():
     # one-time prompt encoding: sharded over ranks + ONE all_gather (RCCL over xGMI), then cached
     torch.cuda.synchronize()
     t0 = time.time()
-    text_features = sharded_text_features(lambda e: model.forward_text_model(e)["text_features_wo_l2_norm"], enc)
+    text_features = sharded_text_features(lambda e: model.forward_text_model(e)["text_features_wo_l2_norm"], enc,
+                                          feature_dim=cfg.hidden_size)
     torch.cuda.synchronize()
     text_ms = (time.time() - t0) * 1e3
 
@@ -160,7 +165,7 @@ def main():
 
     for _ in range(args.warmup):
         step()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     if not args.no_kernel_events:
@@ -169,7 +174,7 @@ def main():
     for _ in range(args.steps):
         out = step()
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
@@ -178,7 +183,7 @@ def main():
         prof = model.profile_read()
         model.profile(False)
     tmax = torch.tensor([elapsed], dtype=torch.float64, device=device)
-    if world > 1:
+    if use_dist:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     elapsed = float(tmax.item())
     assert bool(torch.isfinite(out["logits"]).all())
@@ -221,7 +226,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(cfg, sd, S, T, ids, mask)
         print(json.dumps(res), flush=True)
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

@@ -32,7 +32,7 @@ def calculate_similarities(batches: Iterable[torch.Tensor], text_batch, model, d
     (utils.py:103-104), on rank 0 when distributed."""
     enc = text_batch["encoded_key_phrases"]
     encode = lambda e: model.forward_text_model(e)["text_features_wo_l2_norm"]
-    feats = sharded_text_features(encode, enc) if distributed else model.encode_prompts(enc)
+    feats = sharded_text_features(encode, enc, feature_dim=model.config.hidden_size) if distributed else model.encode_prompts(enc)
     out = []
     for pixel_values in batches:
         out.append(model.compute_logits(pixel_values=pixel_values.to(model.device), encoded_key_phrases=[enc],

@@ -23,9 +23,11 @@ def shard_range(n_items: int, rank: int, world: int) -> Tuple[int, int]:
 
 
 def sharded_text_features(encode_fn: Callable[[Dict[str, torch.Tensor]], torch.Tensor],
-                          encoded: Dict[str, torch.Tensor], group=None) -> torch.Tensor:
+                          encoded: Dict[str, torch.Tensor], group=None, feature_dim: int | None = None) -> torch.Tensor:
     """Encode this rank's share of the prompts with `encode_fn` ((t,L) ids/mask -> (t, D) fp32) and
-    all_gather the rest.  Every rank returns the full (T, D) table in prompt order."""
+    all_gather the rest.  Every rank returns the full (T, D) table in prompt order.
+    `feature_dim` (= hidden size) lets ranks that receive no prompt (T not a multiple of the world size) size their
+    padding without an extra collective; when omitted it is agreed on with one small all_reduce."""
     if not (dist.is_available() and dist.is_initialized()):
         return encode_fn(encoded)
     world, rank = dist.get_world_size(group), dist.get_rank(group)
@@ -33,25 +35,25 @@ def sharded_text_features(encode_fn: Callable[[Dict[str, torch.Tensor]], torch.T
     t = ids.shape[0]
     per = (t + world - 1) // world
     lo, hi = shard_range(t, rank, world)
-    if hi > lo:
-        local = encode_fn({"input_ids": ids[lo:hi], "attention_mask": mask[lo:hi]}).float()
-        d = local.shape[1]
-    else:                                   # more ranks than prompts: this rank contributes padding only
-        local, d = None, None
-    # agree on D (ranks without prompts do not know it) without an extra collective when avoidable
     dev = ids.device if ids.is_cuda else torch.device("cpu")
-    if local is None:
-        dim = torch.zeros(1, dtype=torch.int64, device=dev)
-    else:
-        dim = torch.tensor([d], dtype=torch.int64, device=dev)
-    if world > t:
-        dist.all_reduce(dim, op=dist.ReduceOp.MAX, group=group)
-    d = int(dim.item())
+    local = encode_fn({"input_ids": ids[lo:hi], "attention_mask": mask[lo:hi]}).float() if hi > lo else None
+    d = feature_dim
+    if d is None:
+        some_rank_empty = per * (world - 1) >= t          # same on every rank: the collective below is entered by all or none
+        if some_rank_empty:
+            dim = torch.tensor([0 if local is None else local.shape[1]], dtype=torch.int64, device=dev)
+            dist.all_reduce(dim, op=dist.ReduceOp.MAX, group=group)
+            d = int(dim.item())
+        else:
+            d = local.shape[1]
     buf = torch.zeros((per, d), dtype=torch.float32, device=dev)
     if local is not None:
         buf[: hi - lo] = local.to(dev)
     out = torch.empty((world * per, d), dtype=torch.float32, device=dev)
-    dist.all_gather_into_tensor(out, buf, group=group) if dev.type == "cuda" else _all_gather_cpu(out, buf, group)
+    if dev.type == "cuda":
+        dist.all_gather_into_tensor(out, buf, group=group)
+    else:
+        _all_gather_cpu(out, buf, group)
     return out[:t].contiguous()
 
 

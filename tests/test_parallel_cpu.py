@@ -39,7 +39,7 @@ def _worker(rank, world, port, n_prompts, q):
         enc = {"input_ids": ids, "attention_mask": mask}
         table = sharded_text_features(_encode, enc)
         ref = _encode(enc)
-        ok_table = torch.equal(table, ref)
+        ok_table = torch.equal(table, ref) and torch.equal(sharded_text_features(_encode, enc, feature_dim=8), ref)
         local = torch.full((2, n_prompts), float(rank)) + torch.arange(n_prompts).float() * 0.01
         allg = gather_logits(local)
         ok_gather = True
@@ -54,7 +54,7 @@ def _worker(rank, world, port, n_prompts, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,n_prompts", [(2, 14), (2, 1), (3, 14), (3, 2)])
+@pytest.mark.parametrize("world,n_prompts", [(2, 14), (2, 1), (3, 14), (3, 2), (3, 4), (4, 9)])
 def test_sharded_text_features_gloo(world, n_prompts):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
