@@ -120,6 +120,42 @@ __device__ __forceinline__ void gemm_epilogue_lds(const GemmArgs& g, const f32x4
             *reinterpret_cast<f32x4*>(wlds + outer * 256 + ((chunk ^ (outer & 15)) << 4)) = acc[i][j];
         }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                  // same wave, in-order LDS queue; keeps hipcc from reordering
+    // 16-bit row-major outputs: 8 values = ONE 16-byte store per lane, 8 rows x 128 B per wave instruction (the epilogue is
+    // store-ISSUE bound: half the store instructions of the 8-byte form)
+    if constexpr (sizeof(T) == 2 && (EPI == EPI_STORE || EPI == EPI_GELU || EPI == EPI_HEADS || EPI == EPI_VT)) {
+        const int c2 = (lane & 7) * 2;                                     // first of two 16-B fp32 chunks = 8 inner indices
+#pragma unroll 2
+        for (int it = 0; it < 8; ++it) {
+            const int outer = it * 8 + (lane >> 3);
+            f32x4 v0 = *reinterpret_cast<const f32x4*>(wlds + outer * 256 + ((c2 ^ (outer & 15)) << 4));
+            f32x4 v1 = *reinterpret_cast<const f32x4*>(wlds + outer * 256 + (((c2 + 1) ^ (outer & 15)) << 4));
+            T* o;
+            if constexpr (EPI == EPI_VT) {
+                // outer = feature n, inner = 8 consecutive tokens of one image: vT[b][head][d][tok..tok+7]
+                const int n = nw + outer, m = mw + c2 * 4;
+                const float bv = g.bias ? g.bias[n] : 0.f;
+                v0 += bv; v1 += bv;
+                const int b = m / g.rows_per_image, tok = m - b * g.rows_per_image;
+                o = reinterpret_cast<T*>(g.out) + (((int64_t)b * g.heads_total + (n >> 6)) * 64 + (n & 63)) * g.rows_per_image + tok;
+            } else {
+                const int m = mw + outer, n = nw + c2 * 4;
+                if (g.bias) { v0 += *reinterpret_cast<const f32x4*>(g.bias + n); v1 += *reinterpret_cast<const f32x4*>(g.bias + n + 4); }
+                if constexpr (EPI == EPI_GELU) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { v0[e] = gelu_for<T>(v0[e]); v1[e] = gelu_for<T>(v1[e]); }
+                }
+                if constexpr (EPI == EPI_HEADS) {
+                    const int b = m / g.rows_per_image, tok = m - b * g.rows_per_image;
+                    o = reinterpret_cast<T*>(g.out) + (((int64_t)b * g.heads_total + (n >> 6)) * g.rows_per_image + tok) * 64 + (n & 63);
+                } else {
+                    o = reinterpret_cast<T*>(g.out) + (int64_t)m * g.ldo + n;
+                }
+            }
+            *reinterpret_cast<typename Traits<T>::frag*>(o) = pack8<T>(v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        return;
+    }
     const int c = lane & 15;                                           // chunk read by this lane
 #pragma unroll 4
     for (int it = 0; it < 16; ++it) {
@@ -423,7 +459,11 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel_v3(GemmArgs g) {
     if (g.debug_flags & 4) return;      // measurement only: no epilogue
     const f32x4 (&lo)[4][4] = *reinterpret_cast<const f32x4 (*)[4][4]>(&acc[0]);
     const f32x4 (&hi)[4][4] = *reinterpret_cast<const f32x4 (*)[4][4]>(&acc[4]);
-    if (!(g.debug_flags & 8)) {         // default: direct epilogue (bit3 selects the LDS-staged one; measured equal within noise)
+    // default: LDS-staged 16-byte stores for the 16-bit row-major / per-head / transposed outputs (+9..15 % on those GEMMs),
+    // direct epilogue for GELU (VALU-bound) and the fp32 residual read-modify-write (equal within noise).
+    // debug bit3 forces the LDS-staged epilogue everywhere, bit4 the direct one everywhere.
+    constexpr bool kLdsDefault = sizeof(T) == 2 && (EPI == EPI_STORE || EPI == EPI_HEADS || EPI == EPI_VT);
+    if ((g.debug_flags & 16) || (!kLdsDefault && !(g.debug_flags & 8))) {
         gemm_epilogue<T, EPI>(g, lo, m0 + wm * 128, n0 + wn * 64, l15, lg);
         gemm_epilogue<T, EPI>(g, hi, m0 + wm * 128 + 64, n0 + wn * 64, l15, lg);
         return;
@@ -541,7 +581,11 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel_v4(GemmArgs g) {
     }
     const f32x4 (&lo)[4][4] = *reinterpret_cast<const f32x4 (*)[4][4]>(&acc[0]);
     const f32x4 (&hi)[4][4] = *reinterpret_cast<const f32x4 (*)[4][4]>(&acc[4]);
-    if (!(g.debug_flags & 8)) {         // default: direct epilogue (bit3 selects the LDS-staged one; measured equal within noise)
+    // default: LDS-staged 16-byte stores for the 16-bit row-major / per-head / transposed outputs (+9..15 % on those GEMMs),
+    // direct epilogue for GELU (VALU-bound) and the fp32 residual read-modify-write (equal within noise).
+    // debug bit3 forces the LDS-staged epilogue everywhere, bit4 the direct one everywhere.
+    constexpr bool kLdsDefault = sizeof(T) == 2 && (EPI == EPI_STORE || EPI == EPI_HEADS || EPI == EPI_VT);
+    if ((g.debug_flags & 16) || (!kLdsDefault && !(g.debug_flags & 8))) {
         gemm_epilogue<T, EPI>(g, lo, m0 + wm * 128, n0 + wn * 64, l15, lg);
         gemm_epilogue<T, EPI>(g, hi, m0 + wm * 128 + 64, n0 + wn * 64, l15, lg);
         return;

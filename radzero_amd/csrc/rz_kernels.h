@@ -27,7 +27,7 @@ struct GemmArgs {
     int rows_per_image;           // padded tokens per image (EPI_HEADS / EPI_VT / EPI_PATCH)
     int heads_total;              // heads in the destination tensor (EPI_HEADS / EPI_VT)
     int debug_flags;              // measurement only: bit0 skip MFMA/ds_read body, bit1 skip W staging, bit2 skip epilogue,
-                                  // bit3 use the LDS-staged full-line epilogue (256x256 kernels)
+                                  // bit3 force the LDS-staged full-line epilogue, bit4 force the direct epilogue (256x256 kernels)
 };
 
 hipError_t launch_gemm(int dtype, int epi, const GemmArgs& g, hipStream_t s);
