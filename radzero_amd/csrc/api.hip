@@ -24,6 +24,7 @@ int fail(int code, const std::string& msg) {
     return code;
 }
 // 0 = auto (= 1: measured fastest in bench.py, 1000 TFLOP/s); 1 = 16x16x32 kernel, 4 waves/128 q rows; 8 = same kernel, 8 waves/256 q rows;
+// 64 = 16x16x32 kernel, 4 waves x 64 q rows (4 q tiles per wave);
 // 2 = 32x32x16 kernel, 2-stage ring; 3 = 32x32x16 kernel, 3-stage ring; 4 = 32x32x16 software-pipelined (16-bit only)
 int g_vision_chunk = 0;   // images per pass of rz_vision_forward (0 = whole batch)
 int g_vision_streams = 1; // 2 = split the batch over two internal HIP streams
@@ -33,7 +34,7 @@ hipError_t flash_attn(int dt, const void* q, const void* k, const void* vt, void
                       hipStream_t s) {
     if (g_attn_variant == 4 && dt != RZ_F32) return launch_flash_attn32p(dt, q, k, vt, ctx, bs, B, H, nv, np, s);
     if (g_attn_variant == 2 || g_attn_variant == 3) return launch_flash_attn32(dt, q, k, vt, ctx, bs, B, H, nv, np, g_attn_variant, s);
-    return launch_flash_attn(dt, q, k, vt, ctx, bs, B, H, nv, np, g_attn_variant == 8 ? 8 : 4, s);
+    return launch_flash_attn(dt, q, k, vt, ctx, bs, B, H, nv, np, (g_attn_variant == 8 || g_attn_variant == 64 || g_attn_variant == 264) ? g_attn_variant : 4, s);
 }
 
 int hip_fail(hipError_t e, const char* what) {
@@ -156,7 +157,7 @@ struct ProfScope {
     hipStream_t s;
     int idx = -1;
     ProfScope(rz_model* m_, int fam, hipStream_t s_) : m(m_), s(s_) {
-        if (!m->prof) return;
+        if (!m->prof || m->ev_used >= (1u << 20)) return;      // bounded: profiling left on without reads stops recording
         if (m->ev_used == m->ev_pool.size()) {
             rz_model::Ev e;
             if (hipEventCreate(&e.a) != hipSuccess || hipEventCreate(&e.b) != hipSuccess) return;
@@ -349,6 +350,7 @@ int rz_create(const rz_config* cfg, rz_handle_t* out) {
 
 int rz_destroy(rz_handle_t m) {
     if (!m) return 0;
+    (void)hipDeviceSynchronize();        // nothing of this handle may still be in flight when its buffers go away
     for (void* p : m->allocs) (void)hipFree(p);
     for (auto& kv : m->pos_tables) kv.second.buf.release();
     DevBuf* bufs[] = {&m->h, &m->xn, &m->qk, &m->vt, &m->ctx, &m->mid, &m->vhat, &m->vws, &m->qhat,
@@ -461,6 +463,7 @@ int rz_set_position_table(rz_handle_t m, int gh, int gw, const float* pos_host) 
     for (int t = 1; t < nv; ++t)
         for (int d = 0; d < D; ++d) tbl[(size_t)t * D + d] = pos_host[(size_t)t * D + d] + m->patch_bias_host[d];
     auto& pt = m->pos_tables[{gh, gw}];
+    RZ_HIP(hipDeviceSynchronize());
     RZ_HIP(pt.buf.ensure(tbl.size() * 4, false));
     RZ_HIP(hipMemcpy(pt.buf.p, tbl.data(), tbl.size() * 4, hipMemcpyHostToDevice));
     pt.n_valid = nv;
@@ -472,6 +475,7 @@ int rz_reserve(rz_handle_t m, int max_batch, int max_tokens, int max_prompts, in
     if (!m || max_batch < 0 || max_tokens < 0 || max_prompts < 0 || max_len < 0) return fail(RZ_ERR_INVALID, "rz_reserve: bad argument");
     const size_t es = dsize(m->dt), D = m->D, F = m->F;
     const int npad = round_up(max_tokens, 128);
+    RZ_HIP(hipDeviceSynchronize());      // buffers may be re-allocated below: wait for any forward still using the old ones
     if (max_batch > 0 && max_tokens > 0) {
         const int B = std::max(max_batch, m->cap_batch), NP = std::max(npad, m->cap_npad);
         const size_t rows = (size_t)B * NP;

@@ -60,8 +60,10 @@ __device__ __forceinline__ typename Traits<T>::frag lds_frag_row(const char* til
 
 // NW = waves per workgroup (4 or 8): 8 waves share each K/V tile -> half the L2->LDS staging bytes per FLOP
 // (one CU sustains only ~50 GB/s of global_load_lds traffic, tools/mb_ldsdma.hip), at <=128 VGPRs for 2 WGs/CU.
-template <typename T, int NW>
-__global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 3) void flash_attn_kernel(const T* __restrict__ q, const T* __restrict__ k,
+// QT = 16-row query tiles per wave (2 or 4): QT = 4 halves both the K/V staging bytes and the LDS fragment reads per MFMA
+// (every K / V^T fragment feeds 4 MFMAs instead of 2) at the price of ~250 VGPRs (2 waves per SIMD).
+template <typename T, int NW, int QT>
+__global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : (QT == 4 ? 2 : 3)) void flash_attn_kernel(const T* __restrict__ q, const T* __restrict__ k,
                                                             const T* __restrict__ vT, T* __restrict__ ctx,
                                                             int64_t qk_batch_stride, int B, int H, int n_valid, int n_pad) {
     typedef typename Traits<T>::frag frag_t;
@@ -75,7 +77,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 3) void flash_attn_kernel(co
     const int l15 = lane & 15, lg = lane >> 4;
 
     // XCD-aware mapping: all query blocks of one (image, head) pair run on one XCD (its K/V stay in that L2)
-    constexpr int QROWS = 32 * NW;
+    constexpr int QROWS = 16 * QT * NW;
     const int nq = n_pad / QROWS;
     const int pairs = B * H;
     const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
@@ -91,10 +93,10 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 3) void flash_attn_kernel(co
     const int64_t v_ld = (int64_t)n_pad * ES;
 
     // Q fragments: qf[qt][ks] = Q[row q0 + qt*16 + l15][d = ks*32 + lg*8 .. +7]
-    const int q0 = qb * QROWS + wave * 32;
-    frag_t qf[2][2];
+    const int q0 = qb * QROWS + wave * (16 * QT);
+    frag_t qf[QT][2];
 #pragma unroll
-    for (int qt = 0; qt < 2; ++qt)
+    for (int qt = 0; qt < QT; ++qt)
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks)
             qf[qt][ks] = *reinterpret_cast<const frag_t*>(qbase + (int64_t)(q0 + qt * 16 + l15) * 64 + ks * 32 + lg * 8);
@@ -138,9 +140,9 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 3) void flash_attn_kernel(co
         }
     };
 
-    f32x4 oacc[2][4];
+    f32x4 oacc[QT][4];
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
+    for (int a = 0; a < QT; ++a)
 #pragma unroll
         for (int c = 0; c < 4; ++c) oacc[a][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
     // Scores arrive in log2 units (log2(e)/sqrt(dh) is folded into the packed q weights), so the softmax is
@@ -148,8 +150,9 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 3) void flash_attn_kernel(co
     // accumulators are INITIALISED to -mrow, so the MFMA chain leaves s - mrow and the common path is
     // max -> exp2 -> sum with no subtraction and no rescale of O (re-centre only when a row's max grew by more
     // than 2^FA_DEFER since the last re-centring; wave-uniform branch).
-    float mrow[2] = {0.f, 0.f};
-    float lrow[2] = {0.f, 0.f};               // lane-partial running sum
+    float mrow[QT], lrow[QT];                 // reference point; lane-partial running sum
+#pragma unroll
+    for (int a = 0; a < QT; ++a) { mrow[a] = 0.f; lrow[a] = 0.f; }
 
     // one KV tile.  FIRST: tile 0 (establishes the reference point).  MASK: ragged last tile (keys >= n_valid dead).
     auto tile = [&](int t, auto first_c, auto mask_c) {
@@ -158,9 +161,9 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 3) void flash_attn_kernel(co
         const char* sk = lds + buf * TILE;
         const char* sv = lds + (2 + buf) * TILE;
         // ---- S' = K Q^T - mrow ----
-        f32x4 sacc[2][4];
+        f32x4 sacc[QT][4];
 #pragma unroll
-        for (int a = 0; a < 2; ++a) {
+        for (int a = 0; a < QT; ++a) {
             const float c0 = FIRST ? 0.f : -mrow[a];
 #pragma unroll
             for (int c = 0; c < 4; ++c) sacc[a][c] = (f32x4){c0, c0, c0, c0};
@@ -194,8 +197,8 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 3) void flash_attn_kernel(co
         for (int ks = 0; ks < 2; ++ks) {
 #pragma unroll
             for (int kt = 0; kt < 4; ++kt) {
-                sacc[0][kt] = mma(kf[ks][kt], qf[0][ks], sacc[0][kt]);
-                sacc[1][kt] = mma(kf[ks][kt], qf[1][ks], sacc[1][kt]);
+#pragma unroll
+                for (int a = 0; a < QT; ++a) sacc[a][kt] = mma(kf[ks][kt], qf[a][ks], sacc[a][kt]);
             }
         }
         // V^T fragments of the first 32-key step: requested now, consumed after the softmax
@@ -210,13 +213,16 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 3) void flash_attn_kernel(co
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const bool dead = key0 + 32 * (kt >> 1) + 8 * lg + 4 * (kt & 1) + r >= n_valid;
-                    if (dead) { sacc[0][kt][r] = -INFINITY; sacc[1][kt][r] = -INFINITY; }
+                    if (dead) {
+#pragma unroll
+                        for (int a = 0; a < QT; ++a) sacc[a][kt][r] = -INFINITY;
+                    }
                 }
         }
         // ---- row maxima of S' (per query = per lane column, + 2 shuffles across the 4 key sub-blocks) ----
-        float mx[2];
+        float mx[QT];
 #pragma unroll
-        for (int qt = 0; qt < 2; ++qt) {
+        for (int qt = 0; qt < QT; ++qt) {
             // plain fmaxf chains: hipcc fuses them into v_max3_f32 (this file is built with -fno-honor-nans, so no
             // canonicalising v_max per MFMA output).  NOT inline asm: an asm VALU op reading an MFMA result gets
             // none of the MFMA->VALU wait states the compiler inserts for its own instructions.
@@ -234,15 +240,15 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 3) void flash_attn_kernel(co
         // ---- re-centre ----
         if constexpr (FIRST) {
 #pragma unroll
-            for (int qt = 0; qt < 2; ++qt) {
+            for (int qt = 0; qt < QT; ++qt) {
                 mrow[qt] = mx[qt];      // tile 0 always holds >= 1 live key: finite
 #pragma unroll
                 for (int kt = 0; kt < 4; ++kt) sacc[qt][kt] -= mx[qt];
             }
-        } else if (__builtin_expect(__any(fmaxf(mx[0], mx[1]) > FA_DEFER), 0)) {
+        } else if (__builtin_expect(__any((QT == 4 ? fmaxf(fmaxf(mx[0], mx[1]), fmaxf(mx[QT - 2], mx[QT - 1])) : fmaxf(mx[0], mx[1])) > FA_DEFER), 0)) {
             asm volatile("" ::: "memory");   // keeps hipcc from if-converting the rare path into the hot one
 #pragma unroll
-            for (int qt = 0; qt < 2; ++qt) {
+            for (int qt = 0; qt < QT; ++qt) {
                 const float delta = fmaxf(mx[qt], 0.f);
                 const float alpha = __builtin_amdgcn_exp2f(-delta);
                 mrow[qt] += delta;
@@ -255,9 +261,9 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 3) void flash_attn_kernel(co
             asm volatile("" ::: "memory");
         }
         // ---- P = 2^S', row sums, pack P^T fragments ----
-        frag_t pf[2][2];
+        frag_t pf[QT][2];
 #pragma unroll
-        for (int qt = 0; qt < 2; ++qt) {
+        for (int qt = 0; qt < QT; ++qt) {
             float pv[4][4];
             float psum = 0.f;
 #pragma unroll
@@ -280,13 +286,13 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 3) void flash_attn_kernel(co
         asm volatile("" ::: "memory");
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) {
-            oacc[0][dt] = mma(vf0[dt], pf[0][0], oacc[0][dt]);
-            oacc[1][dt] = mma(vf0[dt], pf[1][0], oacc[1][dt]);
+#pragma unroll
+            for (int a = 0; a < QT; ++a) oacc[a][dt] = mma(vf0[dt], pf[a][0], oacc[a][dt]);
         }
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) {
-            oacc[0][dt] = mma(vf1[dt], pf[0][1], oacc[0][dt]);
-            oacc[1][dt] = mma(vf1[dt], pf[1][1], oacc[1][dt]);
+#pragma unroll
+            for (int a = 0; a < QT; ++a) oacc[a][dt] = mma(vf1[dt], pf[a][1], oacc[a][dt]);
         }
     };
     using TrueT = std::integral_constant<bool, true>;
@@ -312,7 +318,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 3) void flash_attn_kernel(co
 
     // ---- epilogue: O = O^T / l, ctx[(b*n_pad + q)][h*64 + d] ----
 #pragma unroll
-    for (int qt = 0; qt < 2; ++qt) {
+    for (int qt = 0; qt < QT; ++qt) {
         float l = lrow[qt];
         l += __shfl_xor(l, 16, 64);
         l += __shfl_xor(l, 32, 64);
@@ -330,16 +336,19 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 3) void flash_attn_kernel(co
 hipError_t launch_flash_attn(int dtype, const void* q, const void* k, const void* vT, void* ctx,
                              int64_t qk_batch_stride, int B, int H, int n_valid, int n_pad, int waves, hipStream_t s) {
     if (n_pad % FA_QROWS || n_valid <= 0 || n_valid > n_pad || B <= 0 || H <= 0) return hipErrorInvalidValue;
-    if (waves == 8 && (n_pad % 256 || dtype == DT_F32)) waves = 4;      // 8-wave variant: 256-row q blocks, 16-bit operands
-    const int nq = n_pad / (32 * waves);
+    int qt = 2;
+    if (waves == 64) { waves = 4; qt = 4; }                              // "64": 4 waves x 64 query rows
+    if (waves == 264) { waves = 2; qt = 4; }                             // "264": 2 waves x 64 query rows (128-row q blocks)
+    if ((waves == 8 || qt == 4) && ((n_pad % 256 && waves != 2) || dtype == DT_F32)) { waves = 4; qt = 2; }   // 16-bit operands only
+    const int nq = n_pad / (16 * qt * waves);
     const int pairs = B * H;
     dim3 grid(((pairs + 7) / 8) * 8 * nq), block(64 * waves);
-#define RZ_FA(TT, NWV) hipLaunchKernelGGL((flash_attn_kernel<TT, NWV>), grid, block, 0, s, (const TT*)q, (const TT*)k, \
-                                          (const TT*)vT, (TT*)ctx, qk_batch_stride, B, H, n_valid, n_pad)
+#define RZ_FA(TT, NWV, QTV) hipLaunchKernelGGL((flash_attn_kernel<TT, NWV, QTV>), grid, block, 0, s, (const TT*)q, (const TT*)k, \
+                                               (const TT*)vT, (TT*)ctx, qk_batch_stride, B, H, n_valid, n_pad)
     switch (dtype) {
-        case DT_F32: RZ_FA(float, 4); break;
-        case DT_BF16: if (waves == 8) RZ_FA(bf16_t, 8); else RZ_FA(bf16_t, 4); break;
-        case DT_F16: if (waves == 8) RZ_FA(f16_t, 8); else RZ_FA(f16_t, 4); break;
+        case DT_F32: RZ_FA(float, 4, 2); break;
+        case DT_BF16: if (waves == 8) RZ_FA(bf16_t, 8, 2); else if (waves == 2) RZ_FA(bf16_t, 2, 4); else if (qt == 4) RZ_FA(bf16_t, 4, 4); else RZ_FA(bf16_t, 4, 2); break;
+        case DT_F16: if (waves == 8) RZ_FA(f16_t, 8, 2); else if (waves == 2) RZ_FA(f16_t, 2, 4); else if (qt == 4) RZ_FA(f16_t, 4, 4); else RZ_FA(f16_t, 4, 2); break;
         default: return hipErrorInvalidValue;
     }
 #undef RZ_FA
