@@ -641,7 +641,7 @@ int rz_text_forward(rz_handle_t m, const int64_t* ids, const int64_t* mask, int 
         if ((rc = gemm(m, EPI_STORE, m->txn.p, D, l.wqkv.p, D, Mp, 3 * D, D, (const float*)l.bqkv.p, m->tqkv.p, 3 * D, nullptr, nullptr, 0, Mp, 0, s))) return rc;
         {
             ProfScope ps(m, RZ_PROF_ATTN, s);
-            RZ_HIP(launch_text_attn(m->dt, m->tqkv.p, rel_bias, nullptr, mask, m->tctx.p, T, L, H, 0, s));
+            RZ_HIP(launch_text_attn(m->dt, m->tqkv.p, rel_bias, mask, m->tctx.p, T, L, H, s));
         }
         if ((rc = gemm(m, EPI_RESID_ADD, m->tctx.p, D, l.wo.p, D, Mp, D, D, (const float*)l.bo.p, tsum, D, nullptr, th, D, Mp, 0, s))) return rc;
         {

@@ -399,9 +399,8 @@ __global__ void text_attn_kernel(const T* __restrict__ qkv, const float* __restr
     for (int d = 0; d < 64; ++d) op[d] = from_f32<T>(o[d] * inv);
 }
 
-hipError_t launch_text_attn(int dtype, const void* qkv, const float* rel_bias, const int* /*bucket_tbl*/,
-                            const int64_t* attn_mask, void* ctx, int T, int L, int H, int /*num_buckets*/,
-                            hipStream_t s) {
+hipError_t launch_text_attn(int dtype, const void* qkv, const float* rel_bias, const int64_t* attn_mask, void* ctx, int T, int L,
+                            int H, hipStream_t s) {
     if (T <= 0 || L <= 0) return hipErrorInvalidValue;
     dim3 block(64), grid((L + 63) / 64, H, T);
     switch (dtype) {

@@ -49,11 +49,10 @@ hipError_t launch_flash_attn32(int dtype, const void* q, const void* k, const vo
 hipError_t launch_flash_attn32p(int dtype, const void* q, const void* k, const void* vT, void* ctx,
                                 int64_t qk_batch_stride, int B, int H, int n_valid, int n_pad, hipStream_t s);
 
-// MPNet self-attention for short sequences: qkv [T*L][3*H*64] (q|k|v), additive relative-position bias
-// rel_bias[H][num_buckets] via bucket table [L][L] and key-padding mask [T][L]; ctx [T*L][H*64].
-hipError_t launch_text_attn(int dtype, const void* qkv, const float* rel_bias, const int* bucket_tbl,
-                            const int64_t* attn_mask, void* ctx, int T, int L, int H, int num_buckets,
-                            hipStream_t s);
+// MPNet self-attention for short sequences: qkv [T*L][3*H*64] (q|k|v), additive relative-position bias expanded by the
+// host to rel_bias[H][L][L], key-padding mask [T][L]; ctx [T*L][H*64].
+hipError_t launch_text_attn(int dtype, const void* qkv, const float* rel_bias, const int64_t* attn_mask, void* ctx, int T, int L,
+                            int H, hipStream_t s);
 
 // LayerNorm over rows of 768: fp32 in; writes T-typed normalized copy (out_t, may be null) and/or
 // fp32 (out_f32, may alias in).
