@@ -109,11 +109,20 @@ int rz_vlcabs(rz_handle_t h, const float* text_features_dev, int n_prompts, int 
 int rz_upsample_maps(rz_handle_t h, const float* maps_dev, int64_t map_stride, int n_maps, int grid, int out_h, int out_w,
                      int apply_sigmoid, float* out_dev, void* stream);
 
+/* AspectRatioBlipImageProcessor branch of the same helper (segmentation_utils.py:41-60): keep_aspect_ratio != 0 upsamples to the
+ * padded square max(H, W) and returns the crop [pad_top : pad_top + H, pad_left : pad_left + W] (never materialising the square). */
+int rz_upsample_maps_ex(rz_handle_t h, const float* maps_dev, int64_t map_stride, int n_maps, int grid, int out_h, int out_w,
+                        int apply_sigmoid, int keep_aspect_ratio, float* out_dev, void* stream);
+
 /* ---- get_grounding_point, BlipImageProcessor branch (inference/grounding_utils.py:166-261): flat argmax of the
  *      bilinear-upsampled map -> (x, y), fused (the n_maps x H x W map is never written: 4.3 GB at BASELINE cfg 4) ----
  * xy_out_dev: int32 (n_maps, 2) = (x_index, y_index); keys_ws_dev: scratch of n_maps x 8 bytes. */
 int rz_grounding_points(rz_handle_t h, const float* maps_dev, int64_t map_stride, int n_maps, int grid, int out_h, int out_w,
                         int32_t* xy_out_dev, void* keys_ws_dev, void* stream);
+
+/* same with the AspectRatioBlipImageProcessor branch (grounding_utils.py:172-190) when keep_aspect_ratio != 0 */
+int rz_grounding_points_ex(rz_handle_t h, const float* maps_dev, int64_t map_stride, int n_maps, int grid, int out_h, int out_w,
+                           int keep_aspect_ratio, int32_t* xy_out_dev, void* keys_ws_dev, void* stream);
 
 /* ---- InferDataset collate_fn + Blip image processor (inference/dataset.py:31-51; processing.py:31-49, :90-91) on the device:
  *      cv2.normalize(NORM_MINMAX) to 8 bit (optional) -> grey->RGB -> Pillow bicubic resize of the uint8 image (same 22-bit

@@ -89,6 +89,8 @@ SYMBOLS = {
     "rz_vlcabs": (_I, [_P, _P, _I, _I, _P, _P, _P, _P]),
     "rz_upsample_maps": (_I, [_P, _P, _L, _I, _I, _I, _I, _I, _P, _P]),
     "rz_grounding_points": (_I, [_P, _P, _L, _I, _I, _I, _I, _P, _P, _P]),
+    "rz_grounding_points_ex": (_I, [_P, _P, _L, _I, _I, _I, _I, _I, _P, _P, _P]),
+    "rz_upsample_maps_ex": (_I, [_P, _P, _L, _I, _I, _I, _I, _I, _I, _P, _P]),
     "rz_preprocess_image": (_I, [_P, _I, _I, _I, _I, _I, _P, _P, _I, _P, _P, _I, _P, _P, _F, _I, _P, _P, _P]),
     "rz_gemm": (_I, [_I, _I, _P, _P, _P, _P, _I, _I, _I, _P]),
     "rz_gemm_ex": (_I, [_I, _I, _P, _L, _P, _L, _P, _P, _L, _P, _P, _L, _I, _I, _I, _I, _I, _P]),

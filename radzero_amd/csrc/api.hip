@@ -681,25 +681,35 @@ int rz_vlcabs(rz_handle_t m, const float* text_features, int T, int B, float* sc
 
 int rz_upsample_maps(rz_handle_t m, const float* maps, int64_t map_stride, int n_maps, int grid, int out_h, int out_w,
                      int apply_sigmoid, float* out, void* stream) {
+    return rz_upsample_maps_ex(m, maps, map_stride, n_maps, grid, out_h, out_w, apply_sigmoid, 0, out, stream);
+}
+
+int rz_upsample_maps_ex(rz_handle_t m, const float* maps, int64_t map_stride, int n_maps, int grid, int out_h, int out_w,
+                        int apply_sigmoid, int keep_aspect_ratio, float* out, void* stream) {
     if (!maps || !out || n_maps <= 0 || grid <= 0 || out_h <= 0 || out_w <= 0 || map_stride < (int64_t)grid * grid)
         return fail(RZ_ERR_INVALID, "rz_upsample_maps: bad argument");
     hipStream_t s = (hipStream_t)stream;
     if (m) {
         ProfScope ps(m, RZ_PROF_VLCABS, s);
-        RZ_HIP(launch_upsample_bilinear(maps, map_stride, out, nullptr, n_maps, grid, out_h, out_w, apply_sigmoid, s));
+        RZ_HIP(launch_upsample_bilinear(maps, map_stride, out, nullptr, n_maps, grid, out_h, out_w, apply_sigmoid, keep_aspect_ratio, s));
     } else {
-        RZ_HIP(launch_upsample_bilinear(maps, map_stride, out, nullptr, n_maps, grid, out_h, out_w, apply_sigmoid, s));
+        RZ_HIP(launch_upsample_bilinear(maps, map_stride, out, nullptr, n_maps, grid, out_h, out_w, apply_sigmoid, keep_aspect_ratio, s));
     }
     return 0;
 }
 
 int rz_grounding_points(rz_handle_t m, const float* maps, int64_t map_stride, int n_maps, int grid, int out_h, int out_w,
                         int32_t* xy_out, void* keys_ws, void* stream) {
+    return rz_grounding_points_ex(m, maps, map_stride, n_maps, grid, out_h, out_w, 0, xy_out, keys_ws, stream);
+}
+
+int rz_grounding_points_ex(rz_handle_t m, const float* maps, int64_t map_stride, int n_maps, int grid, int out_h, int out_w,
+                           int keep_aspect_ratio, int32_t* xy_out, void* keys_ws, void* stream) {
     if (!maps || !xy_out || !keys_ws || n_maps <= 0 || grid <= 0 || out_h <= 0 || out_w <= 0 || map_stride < (int64_t)grid * grid)
         return fail(RZ_ERR_INVALID, "rz_grounding_points: bad argument");
     hipStream_t s = (hipStream_t)stream;
     (void)m;
-    RZ_HIP(launch_grounding_points(maps, map_stride, (unsigned long long*)keys_ws, xy_out, n_maps, grid, out_h, out_w, s));
+    RZ_HIP(launch_grounding_points(maps, map_stride, (unsigned long long*)keys_ws, xy_out, n_maps, grid, out_h, out_w, keep_aspect_ratio, s));
     return 0;
 }
 

@@ -86,11 +86,11 @@ hipError_t launch_vlcabs(const float* tokens, const float* ln_gamma, const float
 // bilinear upsample (align_corners=False) of patch-grid maps [M][g][g] -> [M][H][W], optional sigmoid;
 // optional per-map argmax (flat index of first max) -> argmax_out[M].
 hipError_t launch_upsample_bilinear(const float* maps, int64_t map_stride, float* out, int64_t* argmax_out, int M, int g,
-                                    int Hout, int Wout, int apply_sigmoid, hipStream_t s);
+                                    int Hout, int Wout, int apply_sigmoid, int keep_aspect, hipStream_t s);
 
 // argmax (x, y) of the bilinear-upsampled map, without materialising it; keys_ws: M x u64 scratch
 hipError_t launch_grounding_points(const float* maps, int64_t map_stride, unsigned long long* keys_ws, int* xy_out, int M, int g,
-                                   int Hout, int Wout, hipStream_t s);
+                                   int Hout, int Wout, int keep_aspect, hipStream_t s);
 
 // device-side image preprocessing (preprocess.hip): raw image [H][W][C] (src_dtype 0 u8 / 1 u16 / 2 f32) -> fp32 [3][S][S].
 // bounds_*/kk_*: Pillow resampling tables (device, int32): bounds [out][2] = (first, count), kk [out][ksize] 22-bit fixed point.

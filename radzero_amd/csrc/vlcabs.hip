@@ -205,13 +205,14 @@ hipError_t launch_vlcabs(const float* tokens, const float* ln_gamma, const float
 // n_maps*H*W*4 bytes (4.29 GB at BASELINE cfg 4).
 __global__ __launch_bounds__(256) void upsample_bilinear_kernel(const float* __restrict__ maps, int64_t map_stride,
                                                                 float* __restrict__ out, int g, int Hout, int Wout,
-                                                                float sy, float sx, int apply_sigmoid) {
+                                                                float sy, float sx, int apply_sigmoid, int off_y, int off_x) {
+    // (off_y, off_x): crop origin inside the virtual square map of the aspect-ratio branch (0 for the plain branch)
     const int m = blockIdx.z;
     const int y = blockIdx.y;
     const int x4 = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
     if (x4 >= Wout) return;
     const float* src = maps + (int64_t)m * map_stride;
-    float fy = sy * (y + 0.5f) - 0.5f; fy = fy < 0.f ? 0.f : fy;
+    float fy = sy * (y + off_y + 0.5f) - 0.5f; fy = fy < 0.f ? 0.f : fy;
     const int y0 = (int)fy;
     const int y1 = y0 + (y0 < g - 1 ? 1 : 0);
     const float ly = fy - y0, hy = 1.f - ly;
@@ -221,7 +222,7 @@ __global__ __launch_bounds__(256) void upsample_bilinear_kernel(const float* __r
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int x = x4 + i;
-        float fx = sx * (x + 0.5f) - 0.5f; fx = fx < 0.f ? 0.f : fx;
+        float fx = sx * (x + off_x + 0.5f) - 0.5f; fx = fx < 0.f ? 0.f : fx;
         int x0 = (int)fx;
         x0 = x0 > g - 1 ? g - 1 : x0;                         // only reachable for x >= Wout (masked below)
         const int x1 = x0 + (x0 < g - 1 ? 1 : 0);
@@ -252,7 +253,7 @@ __device__ __forceinline__ unsigned long long pack_key(float v, unsigned idx) {
 
 __global__ __launch_bounds__(256) void grounding_argmax_kernel(const float* __restrict__ maps, int64_t map_stride,
                                                                unsigned long long* __restrict__ keys, int g, int Hout, int Wout,
-                                                               float sy, float sx) {
+                                                               float sy, float sx, int off_y, int off_x) {
     __shared__ unsigned long long red[4];
     const int m = blockIdx.y;
     const float* src = maps + (int64_t)m * map_stride;
@@ -260,9 +261,10 @@ __global__ __launch_bounds__(256) void grounding_argmax_kernel(const float* __re
     unsigned long long best = 0ull;
     for (unsigned idx = blockIdx.x * 256u + threadIdx.x; idx < total; idx += gridDim.x * 256u) {
         const int y = idx / Wout, x = idx - y * Wout;
-        float fy = sy * (y + 0.5f) - 0.5f; fy = fy < 0.f ? 0.f : fy;
-        float fx = sx * (x + 0.5f) - 0.5f; fx = fx < 0.f ? 0.f : fx;
-        const int y0 = (int)fy, x0 = (int)fx;
+        float fy = sy * (y + off_y + 0.5f) - 0.5f; fy = fy < 0.f ? 0.f : fy;
+        float fx = sx * (x + off_x + 0.5f) - 0.5f; fx = fx < 0.f ? 0.f : fx;
+        int y0 = (int)fy, x0 = (int)fx;
+        y0 = y0 > g - 1 ? g - 1 : y0; x0 = x0 > g - 1 ? g - 1 : x0;
         const int y1 = y0 + (y0 < g - 1 ? 1 : 0), x1 = x0 + (x0 < g - 1 ? 1 : 0);
         const float ly = fy - y0, lx = fx - x0;
         const float hy = 1.f - ly, hx = 1.f - lx;
@@ -293,25 +295,33 @@ __global__ void grounding_decode_kernel(const unsigned long long* __restrict__ k
 }
 
 hipError_t launch_grounding_points(const float* maps, int64_t map_stride, unsigned long long* keys_ws, int* xy_out, int M, int g,
-                                   int Hout, int Wout, hipStream_t s) {
+                                   int Hout, int Wout, int keep_aspect, hipStream_t s) {
     if (M <= 0 || g <= 0 || Hout <= 0 || Wout <= 0 || (int64_t)Hout * Wout > 0x7FFFFFFFll) return hipErrorInvalidValue;
     hipError_t e = hipMemsetAsync(keys_ws, 0, (size_t)M * sizeof(unsigned long long), s);
     if (e != hipSuccess) return e;
-    const float sy = (float)g / (float)Hout, sx = (float)g / (float)Wout;
+    // keep_aspect: the map is upsampled to the padded square max(H, W) and the original area cropped out
+    // (AspectRatioBlipImageProcessor branch, grounding_utils.py:172-190 / segmentation_utils.py:41-60)
+    const int P = Hout > Wout ? Hout : Wout;
+    const float sy = keep_aspect ? (float)g / (float)P : (float)g / (float)Hout;
+    const float sx = keep_aspect ? (float)g / (float)P : (float)g / (float)Wout;
+    const int off_y = keep_aspect ? (P - Hout) / 2 : 0, off_x = keep_aspect ? (P - Wout) / 2 : 0;
     const int64_t total = (int64_t)Hout * Wout;
     int nblk = (int)((total + 256 * 16 - 1) / (256 * 16));
     nblk = nblk < 1 ? 1 : (nblk > 256 ? 256 : nblk);
-    hipLaunchKernelGGL(grounding_argmax_kernel, dim3(nblk, M), dim3(256), 0, s, maps, map_stride, keys_ws, g, Hout, Wout, sy, sx);
+    hipLaunchKernelGGL(grounding_argmax_kernel, dim3(nblk, M), dim3(256), 0, s, maps, map_stride, keys_ws, g, Hout, Wout, sy, sx, off_y, off_x);
     hipLaunchKernelGGL(grounding_decode_kernel, dim3((M + 255) / 256), dim3(256), 0, s, keys_ws, xy_out, M, Wout);
     return hipGetLastError();
 }
 
 hipError_t launch_upsample_bilinear(const float* maps, int64_t map_stride, float* out, int64_t* argmax_out, int M, int g,
-                                    int Hout, int Wout, int apply_sigmoid, hipStream_t s) {
+                                    int Hout, int Wout, int apply_sigmoid, int keep_aspect, hipStream_t s) {
     if (M <= 0 || g <= 0 || Hout <= 0 || Wout <= 0 || argmax_out != nullptr) return hipErrorInvalidValue;
-    const float sy = (float)g / (float)Hout, sx = (float)g / (float)Wout;
+    const int P = Hout > Wout ? Hout : Wout;
+    const float sy = keep_aspect ? (float)g / (float)P : (float)g / (float)Hout;
+    const float sx = keep_aspect ? (float)g / (float)P : (float)g / (float)Wout;
+    const int off_y = keep_aspect ? (P - Hout) / 2 : 0, off_x = keep_aspect ? (P - Wout) / 2 : 0;
     hipLaunchKernelGGL(upsample_bilinear_kernel, dim3((Wout + 1023) / 1024, Hout, M), dim3(256), 0, s, maps, map_stride, out, g,
-                       Hout, Wout, sy, sx, apply_sigmoid);
+                       Hout, Wout, sy, sx, apply_sigmoid, off_y, off_x);
     return hipGetLastError();
 }
 

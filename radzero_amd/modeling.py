@@ -306,8 +306,10 @@ class RadZeroModel:
 
     # ---- similarity-map post-processing (segmentation_utils.py:62-70, attention_map_base.py:57) ---
     @torch.no_grad()
-    def upsample_similarity(self, similarity_scores: torch.Tensor, size, sigmoid: bool = False) -> torch.Tensor:
-        """(..., g*g) patch-grid scores -> (..., H, W) bilinear (align_corners=False) [+ sigmoid]."""
+    def upsample_similarity(self, similarity_scores: torch.Tensor, size, sigmoid: bool = False,
+                            keep_aspect_ratio: bool = False) -> torch.Tensor:
+        """(..., g*g) patch-grid scores -> (..., H, W) bilinear (align_corners=False) [+ sigmoid].
+        keep_aspect_ratio: the AspectRatioBlipImageProcessor branch (upsample to the padded square, crop the image area)."""
         hh, ww = int(size[0]), int(size[1])
         g = int(round(math.sqrt(similarity_scores.shape[-1])))
         if g * g != similarity_scores.shape[-1]:
@@ -321,12 +323,12 @@ class RadZeroModel:
             flat, stride = s.contiguous(), g * g
         out = torch.empty((n_maps, hh, ww), dtype=torch.float32, device=self._device)
         with torch.cuda.device(self._device):
-            _lib.check(self._lib.rz_upsample_maps(self._h, _ptr(flat), stride, n_maps, g, hh, ww, int(sigmoid), _ptr(out),
-                                                  self._stream()), "rz_upsample_maps")
+            _lib.check(self._lib.rz_upsample_maps_ex(self._h, _ptr(flat), stride, n_maps, g, hh, ww, int(sigmoid),
+                                                     int(keep_aspect_ratio), _ptr(out), self._stream()), "rz_upsample_maps")
         return out.reshape(*lead, hh, ww)
 
     @torch.no_grad()
-    def grounding_points(self, similarity_scores: torch.Tensor, size) -> torch.Tensor:
+    def grounding_points(self, similarity_scores: torch.Tensor, size, keep_aspect_ratio: bool = False) -> torch.Tensor:
         """get_grounding_point (grounding_utils.py:166-261) for every map: (..., g*g) -> (..., 2) int32 (x, y) of the
         first maximum of the bilinear-upsampled map; the (H, W) map itself is never materialised."""
         hh, ww = int(size[0]), int(size[1])
@@ -343,8 +345,8 @@ class RadZeroModel:
         xy = torch.empty((n_maps, 2), dtype=torch.int32, device=self._device)
         ws = torch.empty((n_maps,), dtype=torch.int64, device=self._device)
         with torch.cuda.device(self._device):
-            _lib.check(self._lib.rz_grounding_points(self._h, _ptr(flat), stride, n_maps, g, hh, ww, _ptr(xy), _ptr(ws),
-                                                     self._stream()), "rz_grounding_points")
+            _lib.check(self._lib.rz_grounding_points_ex(self._h, _ptr(flat), stride, n_maps, g, hh, ww, int(keep_aspect_ratio),
+                                                        _ptr(xy), _ptr(ws), self._stream()), "rz_grounding_points")
         return xy.reshape(*lead, 2)
 
     # ---- measurement -----------------------------------------------------------------------------
