@@ -1,8 +1,9 @@
-// radzero_hip — flash attention, 32x32x16-MFMA formulation (default vision attention kernel), gfx950.
+// radzero_hip — flash attention, 32x32x16-MFMA formulation (attn_variant 2 / 3; the default is attention.hip's
+// 16x16x32 kernel, which measures the same within noise in bench.py), gfx950.
 //
 // Same math and data layout as attention.hip's flash_attn_kernel (softmax_2(Q K^T) V over per-head tensors,
-// TF:dinov2/modeling_dinov2.py:153-178), re-tiled because that kernel is VALU-ISSUE bound (rocprofv3 PMC,
-// profiles/r01/pmc_attn_v2.txt: VALU busy 63 % vs MFMA busy 43 % of SIMD cycles):
+// TF:dinov2/modeling_dinov2.py:153-178), re-tiled to cut vector-ALU issue pressure (rocprofv3 PMC,
+// profiles/r01/pmc_attn_and_gemm_v3.txt: VALU busy 63 % vs MFMA busy 43 % of SIMD cycles in the 16x16x32 kernel):
 //   * v_mfma_f32_32x32x16 does twice the FLOPs per issued instruction of 16x16x32 (each MFMA holds the SIMD's
 //     vector issue port for 8 cycles either way);
 //   * one query per lane (q = lane&31): one set of row statistics instead of two, one cross-lane exchange;
