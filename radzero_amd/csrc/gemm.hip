@@ -700,7 +700,9 @@ static hipError_t launch_gemm_t(int epi, const GemmArgs& g, hipStream_t s) {
     const bool ok4 = ok3 && sizeof(T) == 2 && (g.K % 32 == 0);
     const bool ok5 = ok2 && sizeof(T) == 2 && (g.K % 32 == 0);
     int variant = g_variant;
-    if (variant == 0) variant = ok3 ? 3 : 1;     // measured on MI355X (tools/kbench.py): v3 0.825 ms, v1/v2 0.975 ms per layer of 8 images
+    // measured on MI355X (tools/kbench.py): v3 0.825 ms, v1/v2 0.975 ms per layer of 8 images; with fewer than ~200 big tiles
+    // (single-image calls) the 128x128 kernel fills the 256 CUs better
+    if (variant == 0) variant = (ok3 && (int64_t)(g.M / BM2) * (g.N / BN3) >= 200) ? 3 : 1;
     if (variant == 5 && !ok5) variant = ok3 ? 3 : 1;
     if (variant == 4 && !ok4) variant = ok3 ? 3 : 1;
     if (variant == 3 && !ok3) variant = 1;

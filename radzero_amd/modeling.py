@@ -349,6 +349,36 @@ class RadZeroModel:
                                                         _ptr(xy), _ptr(ws), self._stream()), "rz_grounding_points")
         return xy.reshape(*lead, 2)
 
+    # ---- hipGraph replay for latency-bound (single / small image) calls --------------------------
+    def make_graphed(self, pixel_shape, encoded_key_phrases, maps: str = "none"):
+        """Capture compute_logits for a fixed pixel shape + prompt set into a HIP graph (≈140 kernel launches per call
+        collapse into one replay).  Returns `run(pixel_values) -> outputs`; the returned tensors are the graph's static
+        buffers and are overwritten by the next `run`."""
+        enc = {k: v.to(self._device) for k, v in encoded_key_phrases[0].items()}
+        feats = self.encode_prompts(enc)
+        static_px = torch.zeros(tuple(pixel_shape), dtype=torch.float32, device=self._device)
+        with torch.cuda.device(self._device):
+            side = torch.cuda.Stream(device=self._device)
+            side.wait_stream(torch.cuda.current_stream(self._device))
+            with torch.cuda.stream(side):                       # warm-up off the capture path: workspaces, tables
+                for _ in range(2):
+                    self.compute_logits(static_px, [enc], text_features=feats)
+            torch.cuda.current_stream(self._device).wait_stream(side)
+            torch.cuda.synchronize(self._device)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                out = self.compute_logits(static_px, [enc], text_features=feats)
+                if maps == "points":
+                    out["grounding_points"] = self.grounding_points(out["similarity_scores"], pixel_shape[-2:])
+
+        def run(pixel_values: torch.Tensor):
+            static_px.copy_(pixel_values.to(device=self._device, dtype=torch.float32), non_blocking=True)
+            graph.replay()
+            return out
+
+        run.graph = graph
+        return run
+
     # ---- measurement -----------------------------------------------------------------------------
     def profile(self, enable: bool):
         _lib.check(self._lib.rz_profile_enable(self._h, int(enable)), "rz_profile_enable")
