@@ -151,8 +151,9 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : (QT == 4 ? 2 : 3)) void flas
     // max -> exp2 -> sum with no subtraction and no rescale of O (re-centre only when a row's max grew by more
     // than 2^FA_DEFER since the last re-centring; wave-uniform branch).
     float mrow[QT], lrow[QT];                 // reference point; lane-partial running sum
+    f32x4 cinit[QT];                          // {-m,-m,-m,-m}: C operand of the first score MFMA of every tile (no per-tile v_mov)
 #pragma unroll
-    for (int a = 0; a < QT; ++a) { mrow[a] = 0.f; lrow[a] = 0.f; }
+    for (int a = 0; a < QT; ++a) { mrow[a] = 0.f; lrow[a] = 0.f; cinit[a] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
 
     // one KV tile.  FIRST: tile 0 (establishes the reference point).  MASK: ragged last tile (keys >= n_valid dead).
     auto tile = [&](int t, auto first_c, auto mask_c) {
@@ -162,12 +163,6 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : (QT == 4 ? 2 : 3)) void flas
         const char* sv = lds + (2 + buf) * TILE;
         // ---- S' = K Q^T - mrow ----
         f32x4 sacc[QT][4];
-#pragma unroll
-        for (int a = 0; a < QT; ++a) {
-            const float c0 = FIRST ? 0.f : -mrow[a];
-#pragma unroll
-            for (int c = 0; c < 4; ++c) sacc[a][c] = (f32x4){c0, c0, c0, c0};
-        }
         auto load_k = [&](int ks, int kt) -> frag_t {
             const int krb = (32 * (kt >> 1) + 4 * (kt & 1)) * 128;   // immediate
             if constexpr (ES == 4) {
@@ -194,12 +189,14 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : (QT == 4 ? 2 : 3)) void flas
 #pragma unroll
             for (int kt = 0; kt < 4; ++kt) kf[ks][kt] = load_k(ks, kt);
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
+        for (int kt = 0; kt < 4; ++kt) {
 #pragma unroll
-            for (int kt = 0; kt < 4; ++kt) {
+            for (int a = 0; a < QT; ++a) sacc[a][kt] = mma(kf[0][kt], qf[a][0], cinit[a]);     // = K Q^T - m (cinit is 0 on tile 0)
+        }
 #pragma unroll
-                for (int a = 0; a < QT; ++a) sacc[a][kt] = mma(kf[ks][kt], qf[a][ks], sacc[a][kt]);
-            }
+        for (int kt = 0; kt < 4; ++kt) {
+#pragma unroll
+            for (int a = 0; a < QT; ++a) sacc[a][kt] = mma(kf[1][kt], qf[a][1], sacc[a][kt]);
         }
         // V^T fragments of the first 32-key step: requested now, consumed after the softmax
         frag_t vf0[4];
@@ -242,6 +239,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : (QT == 4 ? 2 : 3)) void flas
 #pragma unroll
             for (int qt = 0; qt < QT; ++qt) {
                 mrow[qt] = mx[qt];      // tile 0 always holds >= 1 live key: finite
+                cinit[qt] = (f32x4){-mx[qt], -mx[qt], -mx[qt], -mx[qt]};
 #pragma unroll
                 for (int kt = 0; kt < 4; ++kt) sacc[qt][kt] -= mx[qt];
             }
@@ -252,6 +250,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : (QT == 4 ? 2 : 3)) void flas
                 const float delta = fmaxf(mx[qt], 0.f);
                 const float alpha = __builtin_amdgcn_exp2f(-delta);
                 mrow[qt] += delta;
+                cinit[qt] -= delta;
                 lrow[qt] *= alpha;
 #pragma unroll
                 for (int kt = 0; kt < 4; ++kt) sacc[qt][kt] -= delta;
