@@ -25,6 +25,9 @@ namespace rz {
 
 constexpr int FA_QROWS = 128;   // query rows per 4-wave workgroup (the 8-wave variant covers 256)
 constexpr int FA_KEYS = 64;     // keys per KV tile
+#ifndef RZ_FA_WAVES
+#define RZ_FA_WAVES 3
+#endif
 constexpr float FA_DEFER = 8.0f;  // a row is re-centred only when its max grew by more than 2^8 (P <= 256: safe in fp32/bf16/f16)
 
 template <typename T> struct FaCfg {
@@ -63,7 +66,7 @@ __device__ __forceinline__ typename Traits<T>::frag lds_frag_row(const char* til
 // QT = 16-row query tiles per wave (2 or 4): QT = 4 halves both the K/V staging bytes and the LDS fragment reads per MFMA
 // (every K / V^T fragment feeds 4 MFMAs instead of 2) at the price of ~250 VGPRs (2 waves per SIMD).
 template <typename T, int NW, int QT>
-__global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : (QT == 4 ? 2 : 3)) void flash_attn_kernel(const T* __restrict__ q, const T* __restrict__ k,
+__global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : (QT == 4 ? 2 : RZ_FA_WAVES)) void flash_attn_kernel(const T* __restrict__ q, const T* __restrict__ k,
                                                             const T* __restrict__ vT, T* __restrict__ ctx,
                                                             int64_t qk_batch_stride, int B, int H, int n_valid, int n_pad) {
     typedef typename Traits<T>::frag frag_t;
