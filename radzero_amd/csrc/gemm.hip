@@ -11,194 +11,10 @@
 // 128 bytes per step (64 x 16-bit or 32 x f32), two LDS stages filled by global_load_lds_dwordx4 with
 // the panel XOR swizzle of rz_common.h.  M must be a multiple of 128 (callers pad rows per image),
 // N a multiple of 128, K*sizeof(T) a multiple of 128.
-#include "rz_common.h"
-#include "rz_kernels.h"
+#include "gemm_common.h"
 
 namespace rz {
 
-constexpr int BM = 128, BN = 128;
-constexpr int PANEL_BYTES = 128 * 128;  // one operand tile in LDS (128 rows x 128 B)
-
-// Tile rasterisation.  Each XCD (private 4 MB L2) runs a contiguous range of logical tile ids (xcd_remap);
-// within that range ids walk GROUP_M m-tiles, then step to the next n-tile, so the ~32-64 tiles in flight
-// on an XCD form a compact (GROUP_M x 8) block that shares its A and W panels through L2 instead of
-// re-fetching them from the Infinity Cache / HBM (128x128 tiles alone are L2-bandwidth bound otherwise).
-template <int GROUP_M>
-__device__ __forceinline__ void tile_coords(int id, int tiles_m, int tiles_n, int& tm, int& tn) {
-    const int per_group = GROUP_M * tiles_n;
-    const int grp = id / per_group;
-    const int first_m = grp * GROUP_M;
-    const int gsz = min(tiles_m - first_m, GROUP_M);
-    const int r = id - grp * per_group;
-    tm = first_m + r % gsz;
-    tn = r / gsz;
-}
-
-// Fused epilogue for one wave's 64x64 accumulator block (4x4 MFMA tiles); (mw, nw) = block origin.
-template <typename T, int EPI>
-__device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, const f32x4 (&acc)[4][4], int mw, int nw, int l15, int lg) {
-    constexpr bool SWAP = (EPI != EPI_VT);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const f32x4 a = acc[i][j];
-            if constexpr (SWAP) {
-                const int m = mw + i * 16 + l15;
-                const int n = nw + j * 16 + 4 * lg;     // 4 consecutive columns n..n+3
-                f32x4 v = a;
-                if (g.bias) {
-                    const f32x4 b = *reinterpret_cast<const f32x4*>(g.bias + n);
-                    v += b;
-                }
-                if constexpr (EPI == EPI_STORE) {
-                    T* o = reinterpret_cast<T*>(g.out) + (int64_t)m * g.ldo + n;
-                    *reinterpret_cast<typename Traits<T>::vec4*>(o) = pack4<T>(v[0], v[1], v[2], v[3]);
-                } else if constexpr (EPI == EPI_GELU) {
-                    T* o = reinterpret_cast<T*>(g.out) + (int64_t)m * g.ldo + n;
-                    *reinterpret_cast<typename Traits<T>::vec4*>(o) =
-                        pack4<T>(gelu_for<T>(v[0]), gelu_for<T>(v[1]), gelu_for<T>(v[2]), gelu_for<T>(v[3]));
-                } else if constexpr (EPI == EPI_HEADS) {
-                    // out[b][head][tok][64], head = n/64 over `heads_total` heads (q heads then k heads)
-                    const int b = m / g.rows_per_image, tok = m - b * g.rows_per_image;
-                    T* o = reinterpret_cast<T*>(g.out) +
-                           (((int64_t)b * g.heads_total + (n >> 6)) * g.rows_per_image + tok) * 64 + (n & 63);
-                    *reinterpret_cast<typename Traits<T>::vec4*>(o) = pack4<T>(v[0], v[1], v[2], v[3]);
-                } else if constexpr (EPI == EPI_RESID_SCALE) {
-                    // h[m][n] += lambda[n] * (acc + bias[n])   (fp32 residual stream, in place)
-                    const f32x4 s = *reinterpret_cast<const f32x4*>(g.scale + n);
-                    float* r = g.resid + (int64_t)m * g.ldr + n;
-                    f32x4 h = *reinterpret_cast<f32x4*>(r);
-                    h += s * v;
-                    *reinterpret_cast<f32x4*>(r) = h;
-                } else if constexpr (EPI == EPI_RESID_ADD) {
-                    // out_f32[m][n] = acc + bias[n] + resid[m][n]   (post-LN blocks: LN applied by the next kernel)
-                    const f32x4 h = *reinterpret_cast<const f32x4*>(g.resid + (int64_t)m * g.ldr + n);
-                    *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(g.out) + (int64_t)m * g.ldo + n) = v + h;
-                } else if constexpr (EPI == EPI_PATCH) {
-                    // h[m][n] = acc + posb[tok][n]; posb = pos-embed + (cls | conv bias), zero on pad rows
-                    const int b = m / g.rows_per_image, tok = m - b * g.rows_per_image;
-                    const f32x4 p = *reinterpret_cast<const f32x4*>(g.scale + (int64_t)tok * g.N + n);
-                    *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(g.out) + (int64_t)m * g.ldo + n) = v + p;
-                } else if constexpr (EPI == EPI_STORE_F32) {
-                    *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(g.out) + (int64_t)m * g.ldo + n) = v;
-                }
-            } else {
-                // EPI_VT: lane owns column n, rows m..m+3 (4 consecutive tokens of one image)
-                const int m = mw + i * 16 + 4 * lg;
-                const int n = nw + j * 16 + l15;
-                const float bv = g.bias ? g.bias[n] : 0.f;
-                const int b = m / g.rows_per_image, tok = m - b * g.rows_per_image;
-                // vT[b][head][d][tok]
-                T* o = reinterpret_cast<T*>(g.out) +
-                       (((int64_t)b * g.heads_total + (n >> 6)) * 64 + (n & 63)) * g.rows_per_image + tok;
-                *reinterpret_cast<typename Traits<T>::vec4*>(o) = pack4<T>(a[0] + bv, a[1] + bv, a[2] + bv, a[3] + bv);
-            }
-        }
-    }
-}
-
-// ---------------------------------------------------------------------------------------------------
-// LDS-staged epilogue (256x256 kernels).  Measured with the debug flags of tools/kbench.py: the direct epilogue above
-// (8/16-byte pieces, 32-64 B per row per instruction) costs 31 % of a K=768 GEMM and nothing overlaps it (one
-// workgroup per CU).  Here each wave drops a 64x64 fp32 block of accumulators into its private 16 KB LDS region
-// (XOR-swizzled 16-B chunks), reads it back row-major and touches global memory in full lines:
-// 4 rows x 256 B (fp32 read-modify-write) or 4 rows x 128 B (16-bit stores) per wave instruction.
-// `outer`/`inner`: SWAP epilogues outer = m, inner = n; EPI_VT outer = n, inner = m (so V^T rows are written whole).
-// ---------------------------------------------------------------------------------------------------
-template <typename T, int EPI>
-__device__ __forceinline__ void gemm_epilogue_lds(const GemmArgs& g, const f32x4 (&acc)[4][4], char* wlds, int mw, int nw, int lane) {
-    constexpr bool SWAP = (EPI != EPI_VT);
-    const int l15 = lane & 15, lg = lane >> 4;
-    // write: lane holds, for tile (i, j), 4 consecutive inner indices of one outer index
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int outer = (SWAP ? i : j) * 16 + l15;
-            const int chunk = (SWAP ? j : i) * 4 + lg;                 // 16-B chunk index along inner (0..15)
-            *reinterpret_cast<f32x4*>(wlds + outer * 256 + ((chunk ^ (outer & 15)) << 4)) = acc[i][j];
-        }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                  // same wave, in-order LDS queue; keeps hipcc from reordering
-    // 16-bit row-major outputs: 8 values = ONE 16-byte store per lane, 8 rows x 128 B per wave instruction (the epilogue is
-    // store-ISSUE bound: half the store instructions of the 8-byte form)
-    if constexpr (sizeof(T) == 2 && (EPI == EPI_STORE || EPI == EPI_GELU || EPI == EPI_HEADS || EPI == EPI_VT)) {
-        const int c2 = (lane & 7) * 2;                                     // first of two 16-B fp32 chunks = 8 inner indices
-#pragma unroll 2
-        for (int it = 0; it < 8; ++it) {
-            const int outer = it * 8 + (lane >> 3);
-            f32x4 v0 = *reinterpret_cast<const f32x4*>(wlds + outer * 256 + ((c2 ^ (outer & 15)) << 4));
-            f32x4 v1 = *reinterpret_cast<const f32x4*>(wlds + outer * 256 + (((c2 + 1) ^ (outer & 15)) << 4));
-            T* o;
-            if constexpr (EPI == EPI_VT) {
-                // outer = feature n, inner = 8 consecutive tokens of one image: vT[b][head][d][tok..tok+7]
-                const int n = nw + outer, m = mw + c2 * 4;
-                const float bv = g.bias ? g.bias[n] : 0.f;
-                v0 += bv; v1 += bv;
-                const int b = m / g.rows_per_image, tok = m - b * g.rows_per_image;
-                o = reinterpret_cast<T*>(g.out) + (((int64_t)b * g.heads_total + (n >> 6)) * 64 + (n & 63)) * g.rows_per_image + tok;
-            } else {
-                const int m = mw + outer, n = nw + c2 * 4;
-                if (g.bias) { v0 += *reinterpret_cast<const f32x4*>(g.bias + n); v1 += *reinterpret_cast<const f32x4*>(g.bias + n + 4); }
-                if constexpr (EPI == EPI_GELU) {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) { v0[e] = gelu_for<T>(v0[e]); v1[e] = gelu_for<T>(v1[e]); }
-                }
-                if constexpr (EPI == EPI_HEADS) {
-                    const int b = m / g.rows_per_image, tok = m - b * g.rows_per_image;
-                    o = reinterpret_cast<T*>(g.out) + (((int64_t)b * g.heads_total + (n >> 6)) * g.rows_per_image + tok) * 64 + (n & 63);
-                } else {
-                    o = reinterpret_cast<T*>(g.out) + (int64_t)m * g.ldo + n;
-                }
-            }
-            *reinterpret_cast<typename Traits<T>::frag*>(o) = pack8<T>(v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]);
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        return;
-    }
-    const int c = lane & 15;                                           // chunk read by this lane
-#pragma unroll 4
-    for (int it = 0; it < 16; ++it) {
-        const int outer = it * 4 + (lane >> 4);
-        f32x4 v = *reinterpret_cast<const f32x4*>(wlds + outer * 256 + ((c ^ (outer & 15)) << 4));
-        const int inner = c * 4;
-        const int m = mw + (SWAP ? outer : inner);
-        const int n = nw + (SWAP ? inner : outer);
-        if constexpr (SWAP) {
-            if (g.bias) v += *reinterpret_cast<const f32x4*>(g.bias + n);
-            if constexpr (EPI == EPI_STORE) {
-                *reinterpret_cast<typename Traits<T>::vec4*>(reinterpret_cast<T*>(g.out) + (int64_t)m * g.ldo + n) = pack4<T>(v[0], v[1], v[2], v[3]);
-            } else if constexpr (EPI == EPI_GELU) {
-                *reinterpret_cast<typename Traits<T>::vec4*>(reinterpret_cast<T*>(g.out) + (int64_t)m * g.ldo + n) =
-                    pack4<T>(gelu_for<T>(v[0]), gelu_for<T>(v[1]), gelu_for<T>(v[2]), gelu_for<T>(v[3]));
-            } else if constexpr (EPI == EPI_HEADS) {
-                const int b = m / g.rows_per_image, tok = m - b * g.rows_per_image;
-                T* o = reinterpret_cast<T*>(g.out) + (((int64_t)b * g.heads_total + (n >> 6)) * g.rows_per_image + tok) * 64 + (n & 63);
-                *reinterpret_cast<typename Traits<T>::vec4*>(o) = pack4<T>(v[0], v[1], v[2], v[3]);
-            } else if constexpr (EPI == EPI_RESID_SCALE) {
-                const f32x4 sc = *reinterpret_cast<const f32x4*>(g.scale + n);
-                float* r = g.resid + (int64_t)m * g.ldr + n;
-                *reinterpret_cast<f32x4*>(r) = *reinterpret_cast<const f32x4*>(r) + sc * v;
-            } else if constexpr (EPI == EPI_RESID_ADD) {
-                const f32x4 h = *reinterpret_cast<const f32x4*>(g.resid + (int64_t)m * g.ldr + n);
-                *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(g.out) + (int64_t)m * g.ldo + n) = v + h;
-            } else if constexpr (EPI == EPI_PATCH) {
-                const int b = m / g.rows_per_image, tok = m - b * g.rows_per_image;
-                const f32x4 p = *reinterpret_cast<const f32x4*>(g.scale + (int64_t)tok * g.N + n);
-                *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(g.out) + (int64_t)m * g.ldo + n) = v + p;
-            } else if constexpr (EPI == EPI_STORE_F32) {
-                *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(g.out) + (int64_t)m * g.ldo + n) = v;
-            }
-        } else {
-            // EPI_VT: one feature n, tokens m..m+3 of one image: vT[b][head][d][tok]
-            const float bv = g.bias ? g.bias[n] : 0.f;
-            const int b = m / g.rows_per_image, tok = m - b * g.rows_per_image;
-            T* o = reinterpret_cast<T*>(g.out) + (((int64_t)b * g.heads_total + (n >> 6)) * 64 + (n & 63)) * g.rows_per_image + tok;
-            *reinterpret_cast<typename Traits<T>::vec4*>(o) = pack4<T>(v[0] + bv, v[1] + bv, v[2] + bv, v[3] + bv);
-        }
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-}
 
 template <typename T, int EPI>
 __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs g) {
@@ -702,7 +518,15 @@ static hipError_t launch_gemm_t(int epi, const GemmArgs& g, hipStream_t s) {
     int variant = g_variant;
     // measured on MI355X (tools/kbench.py): v3 0.825 ms, v1/v2 0.975 ms per layer of 8 images; with fewer than ~200 big tiles
     // (single-image calls) the 128x128 kernel fills the 256 CUs better
-    if (variant == 0) variant = (ok3 && (int64_t)(g.M / BM2) * (g.N / BN3) >= 200) ? 3 : 1;
+    // v7 (gemm7.hip, 16-bit only): 0.755 ms per layer, main loop 1.40 us per K tile against 1.68 for v3 (tools/kslope.py)
+    if (variant == 0) {
+        const bool big = ok3 && (int64_t)(g.M / BM2) * (g.N / BN3) >= 200;
+        variant = !big ? 1 : gemm_v7_ok(Traits<T>::kDType, g) ? 7 : 3;
+    }
+    if (variant == 7 || variant == 9) {
+        if (gemm_v7_ok(Traits<T>::kDType, g)) return launch_gemm_v7(variant, Traits<T>::kDType, epi, g, s);
+        variant = ok3 ? 3 : 1;
+    }
     if (variant == 5 && !ok5) variant = ok3 ? 3 : 1;
     if (variant == 4 && !ok4) variant = ok3 ? 3 : 1;
     if (variant == 3 && !ok3) variant = 1;

@@ -1,0 +1,277 @@
+// radzero_hip — deep-pipelined 256x256x64 GEMM for 16-bit operands ("v7"); same fused epilogues and call sites as
+// gemm.hip (C[M,N] = A[M,K] W[N,K]^T, both operands K-contiguous).
+//
+// EIGHT waves (2x4, 128x64 each, two per SIMD) run as two groups (wr = 0 / 1) staggered by one barrier, four phases per
+// K tile.  A phase is
+//     LOAD part : ds_read the fragments of one 64x32 accumulator quadrant, issue 2 LDS-DMA pieces (one staging unit)
+//     barrier
+//     MFMA part : 16 MFMAs (quadrant x K=64); s_waitcnt vmcnt(6)
+//     barrier
+// and because group 1 runs one barrier behind group 0, the MFMA part of one wave on a SIMD always coincides with the
+// LOAD part of the other: the matrix pipe is fed by one wave while the other pays ds_read latency and DMA issue.
+// The DMA queue is never drained: three staging units (48 KB per CU) stay in flight across every barrier, and each unit
+// has at least 3.5 phases (~2000 cycles) to land — in-kernel stamps (MODE 2, tools/kstamp.py) showed the earlier
+// one-unit-deep version of this loop waiting ~40 % of its time for operands from beyond L2.
+//
+// LDS: two 64 KB K-tile buffers, each an A panel and a W panel of 256 rows x 128 B (swizzle of rz_common.h).
+// Staging units of K tile T (16 KB = 16 pieces of 8 rows, 2 per wave) and the phase that issues them:
+//     U0(T) = A rows 0-63 of each 128-row half     issued in phase 2 of tile T-2   first read in phase 0 of tile T
+//     U1(T) = W rows with (row & 32) == 0          issued in phase 3 of tile T-2   first read in phase 0
+//     U2(T) = W rows with (row & 32) != 0          issued in phase 0 of tile T-1   first read in phase 1
+//     U3(T) = A rows 64-127 of each half           issued in phase 1 of tile T-1   first read in phase 2
+// (tile T-2 lives in the same buffer as T: U0/U1 refill rows of the CURRENT buffer that were read in its phase 0.)
+// A half wr is staged and read by group wr only.
+// Ordering (phases numbered globally, q = 4T + u; group 1 is one barrier interval late):
+//   RAW  a unit issued in LOAD(p) is first read in LOAD(p+5) or later.  Every wave's vmcnt(6) at the end of MFMA(p+3)
+//        leaves only the three younger units in flight, i.e. retires its pieces of that unit; group 1 executes that wait
+//        in interval 2p+8 and a barrier follows, group 0 reads in interval 2p+10, group 1 in 2p+11.
+//   WAR  a unit overwrites rows whose last ds_read was issued at least two phases (four barriers) earlier by either
+//        group, and every ds_read is retired (lgkmcnt) before the MFMAs of its own phase.
+#include "gemm_common.h"
+
+namespace rz {
+
+constexpr int V7_BM = 256, V7_BN = 256;
+constexpr int V7_STAGE = (V7_BM + V7_BN) * 128;     // 64 KB: A panel (256 rows x 128 B) then W panel
+
+template <typename T, bool SWAP>
+__device__ __forceinline__ void v7_mma(f32x4& c, const typename Traits<T>::frag& a, const typename Traits<T>::frag& b) {
+    if constexpr (SWAP) c = mma(b, a, c); else c = mma(a, b, c);
+}
+
+__device__ __forceinline__ void v7_glds(const char* src, char* lds_dst) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                     (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 0);
+}
+
+#define RZ_STAMP(idx)                                                                                   \
+    if constexpr (MODE == 2) {                                                                          \
+        __builtin_amdgcn_sched_barrier(0);                                                              \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st[idx]) :: "memory");               \
+        __builtin_amdgcn_sched_barrier(0);                                                              \
+    }
+
+template <int N> __device__ __forceinline__ void v7_wait_vm() {
+    if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else if constexpr (N == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+}
+
+// One K tile.  S1: tile T+1 exists (issue its U2, U3 into `nxt`), S2: tile T+2 exists (issue its U0, U1 into `cur`).
+// a1/w1 (a2/w2): this wave's per-lane source pointers at the K offset of tile T+1 (T+2).
+template <typename T, bool SWAP, bool S1, bool S2, int MODE>
+__device__ __forceinline__ void v7_tile(f32x4 (&acc)[2][4][4], char* cur, char* nxt, unsigned a_rd, unsigned b_rd,
+                                        const char* const (&a1)[2], const char* const (&w1)[2], const char* const (&a2)[2],
+                                        const char* const (&w2)[2], int64_t a_sub, int64_t w_sub, unsigned a_dst, unsigned w_dst,
+                                        unsigned long long (&st)[24]) {
+    typedef typename Traits<T>::frag frag_t;
+    frag_t fa[2][4], fb0[2][2], fb1[2][2];          // [k-half][fragment]
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        // ---- LOAD part
+        RZ_STAMP(u * 6 + 0)
+        if (u == 0 || u == 2) {
+            const unsigned o = a_rd + (u == 2 ? 64 * 128 : 0);
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) fa[ks][i] = *reinterpret_cast<const frag_t*>(cur + ((o ^ (ks * 64)) + i * 2048));
+        }
+        if (u == 0) {
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) fb0[ks][j] = *reinterpret_cast<const frag_t*>(cur + ((b_rd ^ (ks * 64)) + j * 2048));
+        }
+        if (u == 1) {
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) fb1[ks][j] = *reinterpret_cast<const frag_t*>(cur + (((b_rd + 32 * 128) ^ (ks * 64)) + j * 2048));
+        }
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            if (u == 0 && S1) v7_glds(w1[e] + w_sub, nxt + w_dst + 32 * 128 + e * 1024);     // U2(T+1)
+            if (u == 1 && S1) v7_glds(a1[e] + a_sub, nxt + a_dst + 64 * 128 + e * 1024);     // U3(T+1)
+            if (u == 2 && S2) v7_glds(a2[e], cur + a_dst + e * 1024);                        // U0(T+2)
+            if (u == 3 && S2) v7_glds(w2[e], cur + w_dst + e * 1024);                        // U1(T+2)
+        }
+        RZ_STAMP(u * 6 + 1)
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        RZ_STAMP(u * 6 + 2)
+        // ---- MFMA part: quadrant (mi, ni) = (0,0) (0,1) (1,1) (1,0)
+        const int mi = u >> 1, ni = (u == 1 || u == 2) ? 1 : 0;
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    v7_mma<T, SWAP>(acc[mi][i][ni * 2 + j], fa[ks][i], ni ? fb1[ks][j] : fb0[ks][j]);
+        __builtin_amdgcn_s_setprio(0);
+        RZ_STAMP(u * 6 + 3)
+        // everything issued three or more phases ago must have landed: count the units issued in phases q-2, q-1, q
+        constexpr int kYoung[4] = {(S1 ? 3 : 0), (S1 ? 3 : 0), (S1 ? 2 : 0) + (S2 ? 1 : 0), (S1 ? 1 : 0) + (S2 ? 2 : 0)};
+        if (u == 0) v7_wait_vm<2 * kYoung[0]>();
+        if (u == 1) v7_wait_vm<2 * kYoung[1]>();
+        if (u == 2) v7_wait_vm<2 * kYoung[2]>();
+        if (u == 3) v7_wait_vm<2 * kYoung[3]>();
+        RZ_STAMP(u * 6 + 4)
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        RZ_STAMP(u * 6 + 5)
+    }
+}
+
+template <typename T, int EPI, int MODE>
+__global__ __launch_bounds__(512, 2) void gemm_kernel_v7(GemmArgs g) {
+    static_assert(sizeof(T) == 2, "v7 is for 16-bit operands");
+    __shared__ __attribute__((aligned(1024))) char lds[2 * V7_STAGE];
+    constexpr bool SWAP = (EPI != EPI_VT);
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 2, wc = wave & 3;
+    const int l15 = lane & 15, lg = lane >> 4;
+
+    const int tiles_n = g.N / V7_BN, tiles_m = g.M / V7_BM;
+    const int bid = xcd_remap(blockIdx.x, tiles_m * tiles_n);
+    int tm, tn;
+    tile_coords<4>(bid, tiles_m, tiles_n, tm, tn);
+    const int m0 = tm * V7_BM, n0 = tn * V7_BN;
+    const int64_t lda_b = g.lda * 2, ldw_b = g.ldw * 2;
+    const int nk = g.K / 64;
+
+    // this wave's two DMA pieces (e = 0, 1) of each unit: 8 panel rows each
+    //   A units: rows wr*128 + sub*64 + ((wave&3)*2 + e)*8      W units: rows (wave>>1)*64 + sub*32 + ((wave&1)*2 + e)*8
+    // lane l lands on row +(l>>3), chunk l&7, and fetches chunk (l&7) ^ swz_std(row) = (l&7) ^ ((4e + (l>>4)) & 7)
+    const int a_row = wr * 128 + (wave & 3) * 16, w_row = (wave >> 1) * 64 + (wave & 1) * 16;
+    const char* a_src[2];
+    const char* w_src[2];
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+        const int64_t sw = (((lane & 7) ^ ((4 * e + (lane >> 4)) & 7)) << 4);
+        a_src[e] = reinterpret_cast<const char*>(g.A) + ((int64_t)m0 + a_row + e * 8 + (lane >> 3)) * lda_b + sw;
+        w_src[e] = reinterpret_cast<const char*>(g.W) + ((int64_t)n0 + w_row + e * 8 + (lane >> 3)) * ldw_b + sw;
+    }
+    const int64_t a_sub = 64 * lda_b, w_sub = 32 * ldw_b;
+    const unsigned a_dst = (unsigned)(a_row * 128), w_dst = (unsigned)(V7_BM * 128 + w_row * 128);
+    const unsigned frd = (unsigned)(l15 * 128 + ((lg ^ ((l15 >> 1) & 7)) << 4));
+    const unsigned a_rd = (unsigned)(wr * 128 * 128) + frd;
+    const unsigned b_rd = (unsigned)(V7_BM * 128 + wc * 64 * 128) + frd;
+
+    f32x4 acc[2][4][4];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[a][i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    // prologue: K tile 0 complete in buffer 0; U0, U1 of tile 1 on their way into buffer 1 (nk >= 2)
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+        v7_glds(a_src[e], lds + a_dst + e * 1024);
+        v7_glds(w_src[e], lds + w_dst + e * 1024);
+        v7_glds(w_src[e] + w_sub, lds + w_dst + 32 * 128 + e * 1024);
+        v7_glds(a_src[e] + a_sub, lds + a_dst + 64 * 128 + e * 1024);
+    }
+#pragma unroll
+    for (int e = 0; e < 2; ++e) v7_glds(a_src[e] + 128, lds + V7_STAGE + a_dst + e * 1024);
+#pragma unroll
+    for (int e = 0; e < 2; ++e) v7_glds(w_src[e] + 128, lds + V7_STAGE + w_dst + e * 1024);
+    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (wr == 1) __builtin_amdgcn_s_barrier();          // group 1 runs one barrier behind group 0
+
+    unsigned long long st[24];
+    unsigned long long clk0 = 0, rt0 = 0;
+    if constexpr (MODE == 2) {
+#pragma unroll
+        for (int i = 0; i < 24; ++i) st[i] = 0;
+        clk0 = __builtin_amdgcn_s_memtime(); rt0 = __builtin_amdgcn_s_memrealtime();
+    }
+    int kt = 0;
+    for (; kt + 2 < nk; ++kt) {
+        char* cur = lds + (kt & 1) * V7_STAGE;
+        char* nxt = lds + ((kt + 1) & 1) * V7_STAGE;
+        const int64_t k1 = (int64_t)(kt + 1) * 128, k2 = k1 + 128;
+        const char* a1[2] = {a_src[0] + k1, a_src[1] + k1};
+        const char* w1[2] = {w_src[0] + k1, w_src[1] + k1};
+        const char* a2[2] = {a_src[0] + k2, a_src[1] + k2};
+        const char* w2[2] = {w_src[0] + k2, w_src[1] + k2};
+        v7_tile<T, SWAP, true, true, MODE>(acc, cur, nxt, a_rd, b_rd, a1, w1, a2, w2, a_sub, w_sub, a_dst, w_dst, st);
+    }
+    if constexpr (MODE == 2) {          // diagnostic build: stamps of the last steady-state K tile of workgroup 0 -> g.resid (u64[8][24] + 2)
+        if (bid == 0 && lane == 0 && g.resid) {
+#pragma unroll
+            for (int i = 0; i < 24; ++i) reinterpret_cast<unsigned long long*>(g.resid)[wave * 24 + i] = st[i];
+            if (wave == 0) {            // the steady-state loop of this workgroup: shader cycles and 100 MHz real-time ticks
+                reinterpret_cast<unsigned long long*>(g.resid)[192] = __builtin_amdgcn_s_memtime() - clk0;
+                reinterpret_cast<unsigned long long*>(g.resid)[193] = __builtin_amdgcn_s_memrealtime() - rt0;
+            }
+        }
+    }
+    {
+        char* cur = lds + (kt & 1) * V7_STAGE;
+        char* nxt = lds + ((kt + 1) & 1) * V7_STAGE;
+        const int64_t k1 = (int64_t)(kt + 1) * 128;
+        const char* a1[2] = {a_src[0] + k1, a_src[1] + k1};
+        const char* w1[2] = {w_src[0] + k1, w_src[1] + k1};
+        unsigned long long st2[24];
+        v7_tile<T, SWAP, true, false, MODE == 2 ? 0 : MODE>(acc, cur, nxt, a_rd, b_rd, a1, w1, a1, w1, a_sub, w_sub, a_dst, w_dst, st2);
+        v7_tile<T, SWAP, false, false, MODE == 2 ? 0 : MODE>(acc, nxt, cur, a_rd, b_rd, a1, w1, a1, w1, a_sub, w_sub, a_dst, w_dst, st2);
+    }
+    if (wr == 0) __builtin_amdgcn_s_barrier();
+    if (g.debug_flags & 4) return;      // measurement only: no epilogue
+
+    const int mw = m0 + wr * 128, nw = n0 + wc * 64;
+    constexpr bool kLdsDefault = (EPI == EPI_STORE || EPI == EPI_HEADS || EPI == EPI_VT);
+    if ((g.debug_flags & 16) || (!kLdsDefault && !(g.debug_flags & 8))) {
+        gemm_epilogue<T, EPI>(g, acc[0], mw, nw, l15, lg);
+        gemm_epilogue<T, EPI>(g, acc[1], mw + 64, nw, l15, lg);
+        return;
+    }
+    __syncthreads();                    // every wave is past its last operand read: LDS is free
+    char* wlds = lds + wave * (64 * 256);
+    gemm_epilogue_lds<T, EPI>(g, acc[0], wlds, mw, nw, lane);
+    gemm_epilogue_lds<T, EPI>(g, acc[1], wlds, mw + 64, nw, lane);
+}
+
+template <typename T>
+static hipError_t launch_v7_t(int variant, int epi, const GemmArgs& g, hipStream_t s) {
+    dim3 grid((g.M / V7_BM) * (g.N / V7_BN)), block(512);
+#define RZ_CASE7(E) case E: if (variant == 9) { if constexpr (E == EPI_STORE) hipLaunchKernelGGL((gemm_kernel_v7<T, E, 2>), grid, block, 0, s, g); } \
+                         else hipLaunchKernelGGL((gemm_kernel_v7<T, E, 0>), grid, block, 0, s, g); break;
+    switch (epi) {
+        RZ_CASE7(EPI_STORE)
+        RZ_CASE7(EPI_GELU)
+        RZ_CASE7(EPI_HEADS)
+        RZ_CASE7(EPI_VT)
+        RZ_CASE7(EPI_RESID_SCALE)
+        RZ_CASE7(EPI_RESID_ADD)
+        RZ_CASE7(EPI_PATCH)
+        RZ_CASE7(EPI_STORE_F32)
+        default: return hipErrorInvalidValue;
+    }
+#undef RZ_CASE7
+    return hipGetLastError();
+}
+
+// shape contract (checked by the dispatcher in gemm.hip): M % 256 == 0, N % 256 == 0, K % 64 == 0, K >= 128, 16-bit dtype
+bool gemm_v7_ok(int dtype, const GemmArgs& g) {
+    return dtype != DT_F32 && g.M % V7_BM == 0 && g.N % V7_BN == 0 && g.K % 64 == 0 && g.K >= 128;
+}
+
+// variant 7 = production kernel, 9 = the same loop with s_memtime stamps (EPI_STORE only, tools/kstamp.py)
+hipError_t launch_gemm_v7(int variant, int dtype, int epi, const GemmArgs& g, hipStream_t s) {
+    if (!gemm_v7_ok(dtype, g)) return hipErrorInvalidValue;
+    return dtype == DT_BF16 ? launch_v7_t<bf16_t>(variant, epi, g, s) : launch_v7_t<f16_t>(variant, epi, g, s);
+}
+
+}  // namespace rz

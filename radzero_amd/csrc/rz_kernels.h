@@ -33,7 +33,9 @@ struct GemmArgs {
 hipError_t launch_gemm(int dtype, int epi, const GemmArgs& g, hipStream_t s);
 void gemm_force_v1(bool on);   // A/B switch: use only the 128x128 two-stage kernel
 void gemm_set_debug_flags(int f);
-void gemm_set_variant(int v);  // 0 auto, 1 = 128x128x2stage, 2 = 256x128x3stage, 3 = 256x256x2stage
+void gemm_set_variant(int v);  // 0 auto, 1 = 128x128x2stage, 2 = 256x128x3stage, 3 = 256x256x2stage, 7 = 256x256 staggered 8-phase (gemm7.hip), 9 = 7 + in-kernel stamps
+bool gemm_v7_ok(int dtype, const GemmArgs& g);
+hipError_t launch_gemm_v7(int variant, int dtype, int epi, const GemmArgs& g, hipStream_t s);
 
 // Flash attention over per-head tensors: q,k [B][H][Npad][64], vT [B][H][64][Npad] -> ctx [B*Npad][H*64].
 // Scores are NOT rescaled inside (1/sqrt(dh) is folded into the packed q weights).

@@ -157,7 +157,7 @@ def test_upsample(lib, g, size):
     assert (out_s.cpu() - torch.sigmoid(ref)).abs().max().item() <= 1e-5
 
 
-@pytest.mark.parametrize("variant", [1, 2, 3, 4, 5])
+@pytest.mark.parametrize("variant", [1, 2, 3, 4, 5, 7])
 @pytest.mark.parametrize("dt", ["f32", "bf16", "f16"])
 def test_gemm_variants_agree(lib, variant, dt):
     """All tile variants (128x128x2-stage, 256x128x3-stage counted-vmcnt, 256x256) against the fp32 reference,
@@ -183,3 +183,36 @@ def test_gemm_variants_agree(lib, variant, dt):
     tol = {"f32": 1e-4, "bf16": 2.5e-2, "f16": 3e-3}[dt]
     assert (out.float() - torch.nn.functional.gelu(ref)).abs().max().item() <= tol
     assert (resid - (resid0 + scale * ref)).abs().max().item() <= 2e-4 * math.sqrt(K / 64)
+
+
+@pytest.mark.parametrize("variant", [7])
+@pytest.mark.parametrize("K", [128, 192, 256, 768, 3072])
+@pytest.mark.parametrize("dt", ["bf16", "f16"])
+def test_gemm_pipelined_variants_bitwise(lib, variant, K, dt):
+    """The deep-pipelined 256x256 kernels (gemm7.hip: counted vmcnt, raw barriers, staggered wave groups) accumulate
+    every output element over K in the same order with the same MFMA as the 256x256 two-stage kernel, so the results
+    must be IDENTICAL bit for bit: any LDS-DMA race (a fragment read before its piece landed, a stage overwritten
+    before it was read) shows up as a difference.  K = 128 / 192 exercise the tail-only and one-iteration loops;
+    several tiles per CU queue behind each other at M = 4096."""
+    code, tdt = DT[dt]
+    M, N = 4096, 768
+    g = torch.Generator(device="cpu").manual_seed(K + variant)
+    a = (torch.randn(M, K, generator=g) * 0.7).to(tdt).cuda()
+    w = (torch.randn(N, K, generator=g) / math.sqrt(K)).to(tdt).cuda()
+    bias = torch.randn(N, generator=g).cuda()
+    outs = {}
+    for v in (3, variant):
+        check(lib, lib.rz_set_option(b"gemm_variant", v))
+        try:
+            res = []
+            for epi in (0, 1, 2, 3, 7):             # store, GELU, per-head q|k, transposed v, fp32 store
+                out = torch.zeros(M, N, dtype=torch.float32 if epi == 7 else tdt, device="cuda")
+                for _ in range(3):                  # back-to-back launches: tiles of consecutive kernels overlap on the chip
+                    check(lib, lib.rz_gemm_ex(code, epi, P(a), K, P(w), K, P(bias), P(out), N, None, None, 0, 256, N // 64, M, N, K, stream()))
+                res.append(out)
+            torch.cuda.synchronize()
+            outs[v] = res
+        finally:
+            lib.rz_set_option(b"gemm_variant", 0)
+    for r3, rv in zip(outs[3], outs[variant]):
+        assert torch.equal(r3, rv)

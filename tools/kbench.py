@@ -70,6 +70,35 @@ def bench_gemm(images, n=5330, dt=1):
     print(f"gemm per-layer total {tot:.3f} ms for {images} images")
 
 
+def bench_library(images, n=5330, dt=1):
+    """Calibration only (never on the product path): the vendor libraries at the same shapes -- hipBLASLt through
+    F.linear (bias fused, no other epilogue) and torch SDPA (its flash backend) on the padded token count."""
+    import torch.nn.functional as F
+    npad = (n + 127) // 128 * 128
+    M = images * npad
+    tdt = {0: torch.float32, 1: torch.bfloat16, 2: torch.float16}[dt]
+    for name, N, K in [("qk", 1536, 768), ("v/out", 768, 768), ("fc1", 3072, 768), ("fc2", 768, 3072)]:
+        a = torch.randn(M, K, device="cuda").to(tdt)
+        w = (torch.randn(N, K, device="cuda") / math.sqrt(K)).to(tdt)
+        bias = torch.randn(N, device="cuda").to(tdt)
+        ms = timeit(lambda: F.linear(a, w, bias))
+        ms0 = timeit(lambda: F.linear(a, w))
+        print(f"hipblaslt {name:6s} M={M} N={N} K={K}: +bias {ms:.3f} ms {2.0 * M * N * K / ms / 1e9:.1f} TFLOP/s | "
+              f"no bias {ms0:.3f} ms {2.0 * M * N * K / ms0 / 1e9:.1f} TFLOP/s")
+    q = (torch.randn(images, 12, n, 64, device="cuda") * 0.6).to(tdt)
+    k = torch.randn(images, 12, n, 64, device="cuda").to(tdt)
+    v = torch.randn(images, 12, n, 64, device="cuda").to(tdt)
+    fl = images * 4.0 * n * n * 768
+    for backend in ("FLASH_ATTENTION", "EFFICIENT_ATTENTION"):
+        try:
+            from torch.nn.attention import SDPBackend, sdpa_kernel
+            with sdpa_kernel(getattr(SDPBackend, backend)):
+                ms = timeit(lambda: F.scaled_dot_product_attention(q, k, v))
+            print(f"torch sdpa {backend} images={images} n={n}: {ms:.3f} ms  {fl / ms / 1e9:.1f} TFLOP/s")
+        except Exception as e:  # backend not built into this wheel
+            print(f"torch sdpa {backend}: unavailable ({type(e).__name__}: {str(e)[:120]})")
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("what", nargs="?", default="all")
@@ -93,3 +122,5 @@ if __name__ == "__main__":
         bench_attn(a.images, dt=a.dtype, zeros=a.zeros)
     if a.what in ("gemm", "all"):
         bench_gemm(a.images, dt=a.dtype)
+    if a.what == "library":
+        bench_library(a.images, dt=a.dtype)
