@@ -105,6 +105,7 @@ def main():
     ap.add_argument("--no-kernel-events", action="store_true")
     ap.add_argument("--attn-variant", type=int, default=None, help="A/B switch (rz_set_option): 1 = 16x16x32 4 waves, 8 = 8 waves, 2/3 = 32x32x16 kernel")
     ap.add_argument("--vision-chunk", type=int, default=None, help="images per internal pass of the vision encoder (0 = whole batch)")
+    ap.add_argument("--mlp-chunk", type=int, default=None, help="images per fc1->fc2 pass (-1 = auto, 0 = whole batch)")
     ap.add_argument("--vision-streams", type=int, default=None, help="2 = split the batch over two internal HIP streams")
     ap.add_argument("--gemm-variant", type=int, default=None, help="A/B switch: 0 auto, 1..4 force a GEMM tile variant")
     args = ap.parse_args()
@@ -132,6 +133,8 @@ def main():
         _lib.check(_lib.load().rz_set_option(b"attn_variant", args.attn_variant), "rz_set_option")
     if args.vision_chunk is not None:
         _lib.check(_lib.load().rz_set_option(b"vision_chunk", args.vision_chunk), "rz_set_option")
+    if args.mlp_chunk is not None:
+        _lib.check(_lib.load().rz_set_option(b"mlp_chunk", args.mlp_chunk), "rz_set_option")
     if args.vision_streams is not None:
         _lib.check(_lib.load().rz_set_option(b"vision_streams", args.vision_streams), "rz_set_option")
     if args.gemm_variant is not None:

@@ -9,7 +9,7 @@ P = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None
 ST = lambda: ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 variant = int(sys.argv[1]) if len(sys.argv) > 1 else 7
 N = int(sys.argv[2]) if len(sys.argv) > 2 else 3072
-M = 43008
+M = int(os.environ.get('KSLOPE_M', 43008))
 tiles = (M // 256) * (N // 256)
 rounds = tiles / 256.0
 
