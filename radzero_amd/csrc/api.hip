@@ -28,7 +28,7 @@ int fail(int code, const std::string& msg) {
 // 2 = 32x32x16 kernel, 2-stage ring; 3 = 32x32x16 kernel, 3-stage ring; 4 = 32x32x16 software-pipelined (16-bit only)
 int g_vision_chunk = 0;   // images per pass of rz_vision_forward (0 = whole batch)
 int g_vision_streams = 1; // 2 = split the batch over two internal HIP streams
-int g_mlp_chunk = -1;     // images per fc1->fc2 pass (-1 = auto, 0 = whole batch): see run_chunk in rz_vision_forward
+int g_mlp_chunk = 0;      // images per fc1->fc2 pass (0 = whole batch = default, -1 = auto ~126 MiB of hidden rows): run_chunk in rz_vision_forward
 int g_attn_variant = 0;
 
 hipError_t flash_attn(int dt, const void* q, const void* k, const void* vt, void* ctx, int64_t bs, int B, int H, int nv, int np,
@@ -577,8 +577,9 @@ int rz_vision_forward(rz_handle_t m, const float* px, int B, int C, int Himg, in
             }
             // MLP in row chunks that all reuse the FIRST rows of `mid`: the GELU'd hidden activations of a few images
             // (4 x 5376 x 3072 bf16 = 126 MiB) stay in the 256 MB Infinity Cache between fc1's stores and fc2's loads and
-            // the same lines are overwritten by the next chunk, instead of 1 GB per layer going out to HBM and back
-            // (tools/kmlp.py: 2.05 -> 1.83 ms per layer of 32 images).
+            // the same lines are overwritten by the next chunk, instead of 1 GB per layer going out to HBM and back.
+            // Measured: tools/kmlp.py 2.05 -> 1.83 ms per layer of 32 images in isolation, but no gain inside the model
+            // (372-374 vs 375-376 images/s), so the default is one pass over the whole chunk (option "mlp_chunk").
             for (int i0 = 0; i0 < Bc; i0 += mlp_images) {
                 const int Mi = std::min(mlp_images, Bc - i0) * np;
                 const size_t r0 = (size_t)i0 * np;

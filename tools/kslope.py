@@ -35,6 +35,8 @@ for flags in (0, 4):
         a = torch.randn(M, K, device="cuda").bfloat16()
         w = (torch.randn(N, K, device="cuda") / math.sqrt(K)).bfloat16()
         bias = torch.randn(N, device="cuda")
+        if os.environ.get("KSLOPE_ZEROS"):      # DVFS probe: same instruction stream, no operand toggling
+            a.zero_(); w.zero_()
         out = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
         f = lambda: lib.rz_gemm_ex(1, 0, P(a), K, P(w), K, P(bias), P(out), N, None, None, 0, M, N // 64, M, N, K, ST())
         assert f() == 0, lib.rz_last_error()
