@@ -190,4 +190,70 @@ __device__ __forceinline__ void gemm_epilogue_lds(const GemmArgs& g, const f32x4
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Whole-tile 16-bit epilogue for the 8-wave 256x256 kernels (wave (wr, wc) owns rows wr*128.., columns wc*64..; acc[a]
+// = its 64x64 block a).  Every lane converts its accumulators (bias, GELU) to T and drops them as 8-byte pieces into ONE
+// 256-row x 512-byte image of the output tile in LDS (the operand buffers are free by then): 128 KB of LDS writes +
+// 128 KB of reads instead of the 4 x 128 KB of the per-wave fp32 staging above, and the global stores become
+// 2 rows x 512 contiguous bytes per wave instruction instead of 8 rows x 128.  Image row r holds output row m0+r
+// (EPI_VT: output FEATURE n0+r, tokens along the row); 16-byte chunk c of row r sits at chunk position c ^ (r & 15), so the
+// 16 rows x 4 pieces of a write instruction spread over all banks and a row is read back as 512 contiguous bytes.
+// ---------------------------------------------------------------------------------------------------
+template <typename T, int EPI>
+__device__ __forceinline__ void gemm_epilogue_tile16(const GemmArgs& g, const f32x4 (&acc)[2][4][4], char* lds, int m0, int n0,
+                                                     int wr, int wc, int lane, int tid) {
+    static_assert(sizeof(T) == 2 && (EPI == EPI_STORE || EPI == EPI_GELU || EPI == EPI_HEADS || EPI == EPI_VT), "16-bit row-major outputs only");
+    constexpr bool SWAP = (EPI != EPI_VT);
+    typedef typename Traits<T>::vec4 vec4_t;
+    const int l15 = lane & 15, lg = lane >> 4;
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            f32x4 b4 = (f32x4){0.f, 0.f, 0.f, 0.f};
+            float bv = 0.f;
+            if constexpr (SWAP) { if (g.bias) b4 = *reinterpret_cast<const f32x4*>(g.bias + n0 + wc * 64 + j * 16 + 4 * lg); }
+            else { if (g.bias) bv = g.bias[n0 + wc * 64 + j * 16 + l15]; }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                f32x4 v = acc[a][i][j];
+                int row, c16;
+                if constexpr (SWAP) {
+                    v += b4;
+                    row = wr * 128 + a * 64 + i * 16 + l15;                 // output row
+                    c16 = wc * 8 + j * 2 + (lg >> 1);                       // 8 columns per 16-byte chunk
+                } else {
+                    v += bv;
+                    row = wc * 64 + j * 16 + l15;                           // output feature
+                    c16 = wr * 16 + a * 8 + i * 2 + (lg >> 1);              // 8 tokens per chunk
+                }
+                if constexpr (EPI == EPI_GELU) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = gelu_for<T>(v[e]);
+                }
+                *reinterpret_cast<vec4_t*>(lds + row * 512 + ((c16 ^ (row & 15)) << 4) + (lg & 1) * 8) = pack4<T>(v[0], v[1], v[2], v[3]);
+            }
+        }
+    __syncthreads();
+#pragma unroll 4
+    for (int it = 0; it < 16; ++it) {
+        const int q = it * 512 + tid;
+        const int row = q >> 5, c16 = q & 31;
+        const typename Traits<T>::frag v = *reinterpret_cast<const typename Traits<T>::frag*>(lds + row * 512 + ((c16 ^ (row & 15)) << 4));
+        T* o;
+        if constexpr (EPI == EPI_VT) {
+            const int n = n0 + row, m = m0 + c16 * 8;
+            const int b = m / g.rows_per_image, tok = m - b * g.rows_per_image;
+            o = reinterpret_cast<T*>(g.out) + (((int64_t)b * g.heads_total + (n >> 6)) * 64 + (n & 63)) * g.rows_per_image + tok;
+        } else if constexpr (EPI == EPI_HEADS) {
+            const int m = m0 + row, n = n0 + c16 * 8;
+            const int b = m / g.rows_per_image, tok = m - b * g.rows_per_image;
+            o = reinterpret_cast<T*>(g.out) + (((int64_t)b * g.heads_total + (n >> 6)) * g.rows_per_image + tok) * 64 + (n & 63);
+        } else {
+            o = reinterpret_cast<T*>(g.out) + (int64_t)(m0 + row) * g.ldo + n0 + c16 * 8;
+        }
+        *reinterpret_cast<typename Traits<T>::frag*>(o) = v;
+    }
+}
+
 }  // namespace rz

@@ -151,19 +151,20 @@ __device__ __forceinline__ float wave_max(float v) {
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 
 // exact-erf GELU with erf from Abramowitz-Stegun 7.1.26 (|erf error| <= 1.5e-7, i.e. below bf16/f16 output rounding
-// by 4 orders of magnitude): 1 rcp + 1 exp2 + 9 FMA-class ops instead of libm's branchy erff.
+// by 4 orders of magnitude): 1 rcp + 1 exp2 + 12 FMA-class ops instead of libm's branchy erff.
 //   erf(z) = 1 - (a1 t + ... + a5 t^5) e^{-z^2},  t = 1/(1 + p z),  z = |x|/sqrt(2)
 __device__ __forceinline__ float gelu_erf_fast(float x) {
-    const float z = fabsf(x) * 0.70710678118654752440f;
-    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
-    float poly = fmaf(t, 1.061405429f, -1.453152027f);
-    poly = fmaf(poly, t, 1.421413741f);
-    poly = fmaf(poly, t, -0.284496736f);
-    poly = fmaf(poly, t, 0.254829592f);
+    // gelu(x) = max(x, 0) - |x| * Q(|x|),  Q(a) = (1 - erf(a / sqrt 2)) / 2 = (a1 t + ... + a5 t^5) / 2 * e^{-a^2/2}
+    // (coefficients pre-halved; |x| is a free source modifier; the max/sub pair replaces a compare + select + subtract)
+    const float ax = fabsf(x);
+    const float t = __builtin_amdgcn_rcpf(fmaf(ax, 0.3275911f * 0.70710678118654752440f, 1.0f));
+    float poly = fmaf(t, 0.5f * 1.061405429f, 0.5f * -1.453152027f);
+    poly = fmaf(poly, t, 0.5f * 1.421413741f);
+    poly = fmaf(poly, t, 0.5f * -0.284496736f);
+    poly = fmaf(poly, t, 0.5f * 0.254829592f);
     poly *= t;
-    const float pe = poly * __builtin_amdgcn_exp2f(x * x * -0.72134752044448170368f);   // e^{-x^2/2}
-    const float r = 0.5f * x * pe;          // = 0.5 x (1 - erf(z))
-    return x > 0.f ? x - r : r;
+    const float e = __builtin_amdgcn_exp2f(x * x * -0.72134752044448170368f);   // e^{-x^2/2}
+    return fmaxf(x, 0.f) - ax * (poly * e);
 }
 template <typename T> __device__ __forceinline__ float gelu_for(float x) {
     if constexpr (sizeof(T) == 4) return gelu_erf(x);      // fp32 parity mode: libm erff

@@ -28,7 +28,7 @@ def timeit(fn, iters=20, warm=5):
 
 
 lib.rz_set_option(b"gemm_variant", variant)
-for flags in (0, 4):
+for flags in [int(x) for x in os.environ.get('KSLOPE_FLAGS', '0,4').split(',')]:
     lib.rz_set_option(b"gemm_debug_flags", flags)
     res = []
     for K in (256, 768, 1536, 3072):
