@@ -33,7 +33,7 @@ struct GemmArgs {
 hipError_t launch_gemm(int dtype, int epi, const GemmArgs& g, hipStream_t s);
 void gemm_force_v1(bool on);   // A/B switch: use only the 128x128 two-stage kernel
 void gemm_set_debug_flags(int f);
-void gemm_set_variant(int v);  // 0 auto, 1 = 128x128x2stage, 2 = 256x128x3stage, 3 = 256x256x2stage, 7 = 256x256 staggered 8-phase (gemm7.hip), 9 = 7 + in-kernel stamps
+void gemm_set_variant(int v);  // 0 auto, 1 = 128x128 two-stage, 3 = 256x256 two-stage, 7 = 256x256 staggered 8-phase (gemm7.hip), 9 = 7 + in-kernel stamps
 bool gemm_v7_ok(int dtype, const GemmArgs& g);
 hipError_t launch_gemm_v7(int variant, int dtype, int epi, const GemmArgs& g, hipStream_t s);
 
@@ -46,10 +46,6 @@ hipError_t launch_flash_attn(int dtype, const void* q, const void* k, const void
 // Same contract, 32x32x16-MFMA formulation (attention32.hip) — the default; launch_flash_attn is kept for A/B.
 hipError_t launch_flash_attn32(int dtype, const void* q, const void* k, const void* vT, void* ctx,
                                int64_t qk_batch_stride, int B, int H, int n_valid, int n_pad, int ring, hipStream_t s);
-
-// software-pipelined 32x32x16 kernel (attention32p.hip), 16-bit operands only
-hipError_t launch_flash_attn32p(int dtype, const void* q, const void* k, const void* vT, void* ctx,
-                                int64_t qk_batch_stride, int B, int H, int n_valid, int n_pad, hipStream_t s);
 
 // MPNet self-attention for short sequences: qkv [T*L][3*H*64] (q|k|v), additive relative-position bias expanded by the
 // host to rel_bias[H][L][L], key-padding mask [T][L]; ctx [T*L][H*64].

@@ -84,7 +84,7 @@ def _attn_ref(q, k, v):
     return torch.einsum("bhqk,bhkd->bhqd", torch.softmax(s, -1), v)
 
 
-@pytest.fixture(params=[1, 8, 64, 264, 2, 3, 4], ids=["mfma16", "mfma16x8waves", "mfma16x64rows", "mfma16x2wavesx64rows", "mfma32", "mfma32ring3", "mfma32pipelined"])
+@pytest.fixture(params=[1, 8, 64, 264, 2, 3], ids=["mfma16", "mfma16x8waves", "mfma16x64rows", "mfma16x2wavesx64rows", "mfma32", "mfma32ring3"])
 def attn_variant(request, lib):
     """Both flash-attention kernels (32x32x16 default, 16x16x32) must pass every attention test."""
     lib.rz_set_option(b"attn_variant", request.param)
@@ -157,13 +157,13 @@ def test_upsample(lib, g, size):
     assert (out_s.cpu() - torch.sigmoid(ref)).abs().max().item() <= 1e-5
 
 
-@pytest.mark.parametrize("variant", [1, 2, 3, 4, 5, 7])
+@pytest.mark.parametrize("variant", [1, 3, 7])
 @pytest.mark.parametrize("dt", ["f32", "bf16", "f16"])
 def test_gemm_variants_agree(lib, variant, dt):
-    """All tile variants (128x128x2-stage, 256x128x3-stage counted-vmcnt, 256x256) against the fp32 reference,
+    """All tile variants (128x128 two-stage, 256x256 two-stage, 256x256 staggered 8-phase) against the fp32 reference,
     on a shape every variant accepts, with each epilogue family that matters (store / GELU / residual+LayerScale)."""
     code, tdt = DT[dt]
-    M, N, K = 1024, 768, 3072 if variant == 2 else 768
+    M, N, K = 1024, 768, 768
     g = torch.Generator(device="cpu").manual_seed(variant)
     a = (torch.randn(M, K, generator=g) * 0.7).to(tdt).cuda()
     w = (torch.randn(N, K, generator=g) / math.sqrt(K)).to(tdt).cuda()
