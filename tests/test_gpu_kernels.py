@@ -216,3 +216,27 @@ def test_gemm_pipelined_variants_bitwise(lib, variant, K, dt):
             lib.rz_set_option(b"gemm_variant", 0)
     for r3, rv in zip(outs[3], outs[variant]):
         assert torch.equal(r3, rv)
+
+
+@pytest.mark.parametrize("shape", [(43008, 3072, 768), (43008, 768, 3072), (21504, 1536, 768)])
+def test_gemm_staggered_race_screen_full_size(lib, shape):
+    """Race screen of the staggered kernel at the bench shapes (8 rounds of tiles per CU, operands streaming from
+    beyond L2, back-to-back launches): ten runs must all be bit-identical to the two-stage kernel's result."""
+    M, N, K = shape
+    g = torch.Generator(device="cpu").manual_seed(N + K)
+    a = (torch.randn(M, K, generator=g) * 0.7).bfloat16().cuda()
+    w = (torch.randn(N, K, generator=g) / math.sqrt(K)).bfloat16().cuda()
+    bias = torch.randn(N, generator=g).cuda()
+    ref = torch.empty(M, N, dtype=torch.bfloat16, device="cuda")
+    check(lib, lib.rz_set_option(b"gemm_variant", 3))
+    try:
+        check(lib, lib.rz_gemm_ex(1, 0, P(a), K, P(w), K, P(bias), P(ref), N, None, None, 0, M, N // 64, M, N, K, stream()))
+        check(lib, lib.rz_set_option(b"gemm_variant", 7))
+        outs = [torch.zeros_like(ref) for _ in range(10)]
+        for o in outs:
+            check(lib, lib.rz_gemm_ex(1, 0, P(a), K, P(w), K, P(bias), P(o), N, None, None, 0, M, N // 64, M, N, K, stream()))
+        torch.cuda.synchronize()
+    finally:
+        lib.rz_set_option(b"gemm_variant", 0)
+    for o in outs:
+        assert torch.equal(o, ref)
