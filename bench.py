@@ -103,7 +103,7 @@ def main():
     ap.add_argument("--force-dist", action="store_true", help="rehearsal: initialise the RCCL process group even with one rank")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true")
-    ap.add_argument("--attn-variant", type=int, default=None, help="A/B switch (rz_set_option): 1 = 16x16x32 4 waves, 8 = 8 waves, 2/3 = 32x32x16 kernel")
+    ap.add_argument("--attn-variant", type=int, default=None, help="A/B switch (rz_set_option): 1 = default 16x16x32 4 waves, 16 = same with VALU row sums, 8 = 8 waves, 64/264 = 64 query rows per wave, 2/3 = 32x32x16 kernel")
     ap.add_argument("--vision-chunk", type=int, default=None, help="images per internal pass of the vision encoder (0 = whole batch)")
     ap.add_argument("--mlp-chunk", type=int, default=None, help="images per fc1->fc2 pass (-1 = auto, 0 = whole batch)")
     ap.add_argument("--vision-streams", type=int, default=None, help="2 = split the batch over two internal HIP streams")

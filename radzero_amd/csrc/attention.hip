@@ -65,7 +65,11 @@ __device__ __forceinline__ typename Traits<T>::frag lds_frag_row(const char* til
 // (one CU sustains only ~50 GB/s of global_load_lds traffic, tools/mb_ldsdma.hip), at <=128 VGPRs for 2 WGs/CU.
 // QT = 16-row query tiles per wave (2 or 4): QT = 4 halves both the K/V staging bytes and the LDS fragment reads per MFMA
 // (every K / V^T fragment feeds 4 MFMAs instead of 2) at the price of ~250 VGPRs (2 waves per SIMD).
-template <typename T, int NW, int QT>
+// LS = row sums on the matrix pipe: l^T += 1 P^T with an all-ones A fragment (two more MFMAs per 16-row query tile and KV
+// tile, every lane then holds l of its own query in all four registers) instead of 32 v_add_f32 per wave and tile — the
+// kernel is bound by VALU / MFMA ISSUE slots (VALU active 67 %, MFMA busy 45 %, issue-stalled 45 % of wave cycles,
+// profiles/r01/mfma_utilisation_pmc.json), and the matrix pipe has room.  l then sums the T-rounded P that also feeds PV.
+template <typename T, int NW, int QT, bool LS = false>
 __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : (QT == 4 ? 2 : RZ_FA_WAVES)) void flash_attn_kernel(const T* __restrict__ q, const T* __restrict__ k,
                                                             const T* __restrict__ vT, T* __restrict__ ctx,
                                                             int64_t qk_batch_stride, int B, int H, int n_valid, int n_pad) {
@@ -76,7 +80,8 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : (QT == 4 ? 2 : RZ_FA_WAVES))
     constexpr int ES = (int)sizeof(T);
     __shared__ __attribute__((aligned(1024))) char lds[4 * TILE];   // K0 K1 V0 V1
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // provably uniform: LDS-DMA bases go to M0 by SALU only
     const int l15 = lane & 15, lg = lane >> 4;
 
     // XCD-aware mapping: all query blocks of one (image, head) pair run on one XCD (its K/V stay in that L2)
@@ -155,8 +160,10 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : (QT == 4 ? 2 : RZ_FA_WAVES))
     // than 2^FA_DEFER since the last re-centring; wave-uniform branch).
     float mrow[QT], lrow[QT];                 // reference point; lane-partial running sum
     f32x4 cinit[QT];                          // {-m,-m,-m,-m}: C operand of the first score MFMA of every tile (no per-tile v_mov)
+    f32x4 lacc[QT];                           // LS: running row sums, accumulated by the matrix pipe
+    const frag_t ones = pack8<T>(1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f);
 #pragma unroll
-    for (int a = 0; a < QT; ++a) { mrow[a] = 0.f; lrow[a] = 0.f; cinit[a] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+    for (int a = 0; a < QT; ++a) { mrow[a] = 0.f; lrow[a] = 0.f; cinit[a] = (f32x4){0.f, 0.f, 0.f, 0.f}; lacc[a] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
 
     // one KV tile.  FIRST: tile 0 (establishes the reference point).  MASK: ragged last tile (keys >= n_valid dead).
     auto tile = [&](int t, auto first_c, auto mask_c) {
@@ -219,7 +226,10 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : (QT == 4 ? 2 : RZ_FA_WAVES))
                     }
                 }
         }
-        // ---- row maxima of S' (per query = per lane column, + 2 shuffles across the 4 key sub-blocks) ----
+        // ---- maxima of S': per LANE (one query, 16 of its 64 keys); the other three lanes of the query are only
+        // consulted when a re-centring actually happens — "any lane above the threshold" decides the same thing as
+        // "any row above the threshold", so the hot path carries no cross-lane step (the ds_bpermute pairs and their
+        // lgkmcnt(0) waits used to sit between the score MFMAs and the exponentials of every tile).
         float mx[QT];
 #pragma unroll
         for (int qt = 0; qt < QT; ++qt) {
@@ -233,14 +243,17 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : (QT == 4 ? 2 : RZ_FA_WAVES))
             m0 = fmaxf(fmaxf(m0, sacc[qt][2][1]), sacc[qt][2][2]);
             m0 = fmaxf(fmaxf(m0, sacc[qt][2][3]), sacc[qt][3][0]);
             m0 = fmaxf(fmaxf(m0, sacc[qt][3][1]), sacc[qt][3][2]);
-            m0 = fmaxf(m0, sacc[qt][3][3]);
-            m0 = fmaxf(m0, __shfl_xor(m0, 16, 64));
-            mx[qt] = fmaxf(m0, __shfl_xor(m0, 32, 64));
+            mx[qt] = fmaxf(m0, sacc[qt][3][3]);
         }
+        auto row_max = [&](float m0) {
+            m0 = fmaxf(m0, __shfl_xor(m0, 16, 64));
+            return fmaxf(m0, __shfl_xor(m0, 32, 64));
+        };
         // ---- re-centre ----
         if constexpr (FIRST) {
 #pragma unroll
             for (int qt = 0; qt < QT; ++qt) {
+                mx[qt] = row_max(mx[qt]);
                 mrow[qt] = mx[qt];      // tile 0 always holds >= 1 live key: finite
                 cinit[qt] = (f32x4){-mx[qt], -mx[qt], -mx[qt], -mx[qt]};
 #pragma unroll
@@ -250,11 +263,11 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : (QT == 4 ? 2 : RZ_FA_WAVES))
             asm volatile("" ::: "memory");   // keeps hipcc from if-converting the rare path into the hot one
 #pragma unroll
             for (int qt = 0; qt < QT; ++qt) {
-                const float delta = fmaxf(mx[qt], 0.f);
+                const float delta = fmaxf(row_max(mx[qt]), 0.f);
                 const float alpha = __builtin_amdgcn_exp2f(-delta);
                 mrow[qt] += delta;
                 cinit[qt] -= delta;
-                lrow[qt] *= alpha;
+                if constexpr (LS) lacc[qt] *= alpha; else lrow[qt] *= alpha;
 #pragma unroll
                 for (int kt = 0; kt < 4; ++kt) sacc[qt][kt] -= delta;
 #pragma unroll
@@ -273,9 +286,9 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : (QT == 4 ? 2 : RZ_FA_WAVES))
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     pv[kt][r] = __builtin_amdgcn_exp2f(sacc[qt][kt][r]);
-                    psum += pv[kt][r];
+                    if constexpr (!LS) psum += pv[kt][r];
                 }
-            lrow[qt] += psum;
+            if constexpr (!LS) lrow[qt] += psum;
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk)
                 pf[qt][kk] = pack8<T>(pv[2 * kk][0], pv[2 * kk][1], pv[2 * kk][2], pv[2 * kk][3],
@@ -295,6 +308,12 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : (QT == 4 ? 2 : RZ_FA_WAVES))
         for (int dt = 0; dt < 4; ++dt) {
 #pragma unroll
             for (int a = 0; a < QT; ++a) oacc[a][dt] = mma(vf1[dt], pf[a][1], oacc[a][dt]);
+        }
+        if constexpr (LS) {
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                for (int a = 0; a < QT; ++a) lacc[a] = mma(ones, pf[a][kk], lacc[a]);
         }
     };
     using TrueT = std::integral_constant<bool, true>;
@@ -321,9 +340,14 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : (QT == 4 ? 2 : RZ_FA_WAVES))
     // ---- epilogue: O = O^T / l, ctx[(b*n_pad + q)][h*64 + d] ----
 #pragma unroll
     for (int qt = 0; qt < QT; ++qt) {
-        float l = lrow[qt];
-        l += __shfl_xor(l, 16, 64);
-        l += __shfl_xor(l, 32, 64);
+        float l;
+        if constexpr (LS) {
+            l = lacc[qt][0];            // every row of the ones-tile is the same sum: no cross-lane step
+        } else {
+            l = lrow[qt];
+            l += __shfl_xor(l, 16, 64);
+            l += __shfl_xor(l, 32, 64);
+        }
         const float inv = 1.0f / l;
         const int qrow = q0 + qt * 16 + l15;
         T* o = ctx + ((int64_t)b * n_pad + qrow) * (H * 64) + h * 64 + lg * 4;
@@ -339,7 +363,11 @@ hipError_t launch_flash_attn(int dtype, const void* q, const void* k, const void
                              int64_t qk_batch_stride, int B, int H, int n_valid, int n_pad, int waves, hipStream_t s) {
     if (n_pad % FA_QROWS || n_valid <= 0 || n_valid > n_pad || B <= 0 || H <= 0) return hipErrorInvalidValue;
     int qt = 2;
-    if (waves == 64) { waves = 4; qt = 4; }                              // "64": 4 waves x 64 query rows
+    // default shape (4 waves x 32 query rows): row sums on the matrix pipe; "16" = same shape with VALU row sums (A/B)
+    const bool ls = (waves == 4 || waves == 416);
+    if (waves == 416 || waves == 16) waves = 4;
+    const bool ls4 = (waves == 464);                                     // "464": 4 waves x 64 query rows, row sums on the matrix pipe
+    if (waves == 64 || waves == 464) { waves = 4; qt = 4; }              // "64": 4 waves x 64 query rows
     if (waves == 264) { waves = 2; qt = 4; }                             // "264": 2 waves x 64 query rows (128-row q blocks)
     if ((waves == 8 || qt == 4) && ((n_pad % 256 && waves != 2) || dtype == DT_F32)) { waves = 4; qt = 2; }   // 16-bit operands only
     const int nq = n_pad / (16 * qt * waves);
@@ -347,13 +375,16 @@ hipError_t launch_flash_attn(int dtype, const void* q, const void* k, const void
     dim3 grid(((pairs + 7) / 8) * 8 * nq), block(64 * waves);
 #define RZ_FA(TT, NWV, QTV) hipLaunchKernelGGL((flash_attn_kernel<TT, NWV, QTV>), grid, block, 0, s, (const TT*)q, (const TT*)k, \
                                                (const TT*)vT, (TT*)ctx, qk_batch_stride, B, H, n_valid, n_pad)
+#define RZ_FA_LS(TT) hipLaunchKernelGGL((flash_attn_kernel<TT, 4, 2, true>), grid, block, 0, s, (const TT*)q, (const TT*)k, \
+                                        (const TT*)vT, (TT*)ctx, qk_batch_stride, B, H, n_valid, n_pad)
     switch (dtype) {
-        case DT_F32: RZ_FA(float, 4, 2); break;
-        case DT_BF16: if (waves == 8) RZ_FA(bf16_t, 8, 2); else if (waves == 2) RZ_FA(bf16_t, 2, 4); else if (qt == 4) RZ_FA(bf16_t, 4, 4); else RZ_FA(bf16_t, 4, 2); break;
-        case DT_F16: if (waves == 8) RZ_FA(f16_t, 8, 2); else if (waves == 2) RZ_FA(f16_t, 2, 4); else if (qt == 4) RZ_FA(f16_t, 4, 4); else RZ_FA(f16_t, 4, 2); break;
+        case DT_F32: if (ls) RZ_FA_LS(float); else RZ_FA(float, 4, 2); break;
+        case DT_BF16: if (ls) RZ_FA_LS(bf16_t); else if (ls4 && qt == 4) hipLaunchKernelGGL((flash_attn_kernel<bf16_t, 4, 4, true>), grid, block, 0, s, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)vT, (bf16_t*)ctx, qk_batch_stride, B, H, n_valid, n_pad); else if (waves == 8) RZ_FA(bf16_t, 8, 2); else if (waves == 2) RZ_FA(bf16_t, 2, 4); else if (qt == 4) RZ_FA(bf16_t, 4, 4); else RZ_FA(bf16_t, 4, 2); break;
+        case DT_F16: if (ls) RZ_FA_LS(f16_t); else if (waves == 8) RZ_FA(f16_t, 8, 2); else if (waves == 2) RZ_FA(f16_t, 2, 4); else if (qt == 4) RZ_FA(f16_t, 4, 4); else RZ_FA(f16_t, 4, 2); break;
         default: return hipErrorInvalidValue;
     }
 #undef RZ_FA
+#undef RZ_FA_LS
     return hipGetLastError();
 }
 
