@@ -218,10 +218,11 @@ def test_gemm_pipelined_variants_bitwise(lib, variant, K, dt):
         assert torch.equal(r3, rv)
 
 
-@pytest.mark.parametrize("shape", [(43008, 3072, 768), (43008, 768, 3072), (21504, 1536, 768)])
+@pytest.mark.parametrize("shape", [(43008, 3072, 768), (43008, 768, 3072), (21504, 1536, 768), (37632, 768, 768), (17664, 768, 768)])
 def test_gemm_staggered_race_screen_full_size(lib, shape):
     """Race screen of the staggered kernel at the bench shapes (8 rounds of tiles per CU, operands streaming from
-    beyond L2, back-to-back launches): ten runs must all be bit-identical to the two-stage kernel's result."""
+    beyond L2, back-to-back launches): ten runs must all be bit-identical to the two-stage kernel's result.
+    The last two shapes have 147 / 69 row tiles: not a multiple of the rasterisation group (4) nor of the 8 XCDs."""
     M, N, K = shape
     g = torch.Generator(device="cpu").manual_seed(N + K)
     a = (torch.randn(M, K, generator=g) * 0.7).bfloat16().cuda()
