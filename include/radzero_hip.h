@@ -153,7 +153,16 @@ int rz_layernorm(int dtype, const float* in_dev, const float* gamma_dev, const f
 int rz_flash_attention(int dtype, const void* q_dev, const void* k_dev, const void* v_t_dev, void* ctx_dev, int batch,
                        int heads, int n_valid, int n_pad, void* stream);
 
-/* process-wide tuning / A-B switches (measurement only): "gemm_v1_only" = 1 forces the 128x128 two-stage GEMM */
+/* process-wide tuning / A-B switches (measurement only; defaults are the measured-fastest choices, 0 restores them):
+ *   "gemm_variant"     0 auto | 1 128x128 two-stage | 3 256x256 two-stage | 7 256x256 staggered 8-phase (16-bit, gemm7.hip)
+ *                      | 9 = 7 with in-kernel s_memtime stamps (EPI_STORE only; stamps land in the `resid_dev` buffer)
+ *   "gemm_v1_only"     1 = same as gemm_variant 1
+ *   "gemm_debug_flags" bit 2 skip the epilogue, bit 3 per-wave fp32 LDS epilogue, bit 4 direct epilogue, bit 6 skip the K loop
+ *   "attn_variant"     0/1 default (16x16x32 MFMA, 4 waves x 32 query rows, row sums on the matrix pipe) | 16 same with VALU
+ *                      row sums | 8 eight waves | 64 / 264 / 464 64 query rows per wave | 2 / 3 32x32x16 MFMA kernel
+ *   "vision_chunk"     images per internal pass of rz_vision_forward (0 = whole batch)
+ *   "vision_streams"   2 = two halves of the batch on two internal streams
+ *   "mlp_chunk"        images per fc1->fc2 pass (0 = whole batch, -1 = ~126 MiB of hidden activations) */
 int rz_set_option(const char* name, int value);
 
 /* ---- measurement: HIP-event timing of kernel families on the launch stream ---- */
