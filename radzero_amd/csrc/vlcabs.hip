@@ -18,64 +18,86 @@ constexpr int VC_ROWS = 64;     // token rows per workgroup in the scores kernel
 constexpr int VC_CHUNK = 128;   // token rows per softmax chunk
 constexpr int VC_TG = 16;       // prompts per workgroup in the partial kernel
 
-// ---- scores: one wave per token row ----
+// ---- scores ----
+// A workgroup handles VC_ROWS token rows in sub-blocks of 16.  Per sub-block: each wave normalises four rows in registers
+// (shared LayerNorm, then L2), writes vhat to global memory and to an LDS tile [16][768] (row stride 772 floats);
+// then S[16 tokens][16 prompts] tiles are computed on the matrix pipe with the exact-fp32 MFMA (v_mfma_f32_16x16x4_f32):
+// A = vhat rows from LDS, B = qhat rows straight from global/L2 (T x 768 fp32, cached), one 16-byte read of each per
+// 16-wide K block feeding four MFMAs.  The former version reduced every (token, prompt) dot product with a 6-step
+// cross-lane sum of its own: 0.50 ms at T=14 and 1.7 ms at T=64 against 0.2 ms of HBM time for tokens + vhat.
+constexpr int VC_LDS_STRIDE = 772;      // floats; 772 mod 64 = 4 spreads the 16 rows of an A-fragment read over the banks
+
 __global__ __launch_bounds__(256) void vlcabs_scores_kernel(const float* __restrict__ tokens, const float* __restrict__ gamma,
                                                             const float* __restrict__ beta, float eps,
                                                             const float* __restrict__ qhat, float inv_tau,
                                                             float* __restrict__ vhat, float* __restrict__ scores, int T,
                                                             int n_valid, int n_pad) {
-    extern __shared__ float sc[];   // [T][VC_ROWS]
+    __shared__ __attribute__((aligned(16))) float vs[16 * VC_LDS_STRIDE];
     constexpr int D = 768;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int l15 = lane & 15, lg = lane >> 4;
     const int b = blockIdx.y, row0 = blockIdx.x * VC_ROWS;
-    for (int rr = 0; rr < VC_ROWS / 4; ++rr) {
-        const int rl = wave * (VC_ROWS / 4) + rr;
-        const int64_t row = (int64_t)b * n_pad + row0 + rl;
-        f32x4 v[3];
+    const int ttiles = (T + 15) / 16;
+    for (int sub = 0; sub < VC_ROWS / 16; ++sub) {
+        const int tok0 = row0 + sub * 16;
+#pragma unroll 1
+        for (int rr = 0; rr < 4; ++rr) {
+            const int rl = wave * 4 + rr;
+            const int64_t row = (int64_t)b * n_pad + tok0 + rl;
+            f32x4 v[3];
 #pragma unroll
-        for (int i = 0; i < 3; ++i) v[i] = *reinterpret_cast<const f32x4*>(tokens + row * D + (lane + 64 * i) * 4);
-        // shared LayerNorm (eps 1e-5), two-pass
-        float s = 0.f;
+            for (int i = 0; i < 3; ++i) v[i] = *reinterpret_cast<const f32x4*>(tokens + row * D + (lane + 64 * i) * 4);
+            // shared LayerNorm (eps 1e-5), two-pass
+            float s = 0.f;
 #pragma unroll
-        for (int i = 0; i < 3; ++i) s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
-        const float mu = wave_sum(s) * (1.0f / D);
-        float q = 0.f;
-#pragma unroll
-        for (int i = 0; i < 3; ++i) {
-            v[i] -= mu;
-            q += (v[i][0] * v[i][0] + v[i][1] * v[i][1]) + (v[i][2] * v[i][2] + v[i][3] * v[i][3]);
-        }
-        const float rstd = rsqrtf(wave_sum(q) * (1.0f / D) + eps);
-        float n2 = 0.f;
-#pragma unroll
-        for (int i = 0; i < 3; ++i) {
-            const f32x4 g = *reinterpret_cast<const f32x4*>(gamma + (lane + 64 * i) * 4);
-            const f32x4 be = *reinterpret_cast<const f32x4*>(beta + (lane + 64 * i) * 4);
-            v[i] = v[i] * rstd * g + be;
-            n2 += (v[i][0] * v[i][0] + v[i][1] * v[i][1]) + (v[i][2] * v[i][2] + v[i][3] * v[i][3]);
-        }
-        const float inv = 1.0f / fmaxf(sqrtf(wave_sum(n2)), 1e-12f);
-#pragma unroll
-        for (int i = 0; i < 3; ++i) {
-            v[i] *= inv;
-            *reinterpret_cast<f32x4*>(vhat + row * D + (lane + 64 * i) * 4) = v[i];
-        }
-        for (int t = 0; t < T; ++t) {
-            float d = 0.f;
+            for (int i = 0; i < 3; ++i) s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
+            const float mu = wave_sum(s) * (1.0f / D);
+            float q = 0.f;
 #pragma unroll
             for (int i = 0; i < 3; ++i) {
-                const f32x4 qv = *reinterpret_cast<const f32x4*>(qhat + (int64_t)t * D + (lane + 64 * i) * 4);
-                d += (qv[0] * v[i][0] + qv[1] * v[i][1]) + (qv[2] * v[i][2] + qv[3] * v[i][3]);
+                v[i] -= mu;
+                q += (v[i][0] * v[i][0] + v[i][1] * v[i][1]) + (v[i][2] * v[i][2] + v[i][3] * v[i][3]);
             }
-            d = wave_sum(d);
-            if (lane == 0) sc[t * VC_ROWS + rl] = d * inv_tau;
+            const float rstd = rsqrtf(wave_sum(q) * (1.0f / D) + eps);
+            float n2 = 0.f;
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                const f32x4 g = *reinterpret_cast<const f32x4*>(gamma + (lane + 64 * i) * 4);
+                const f32x4 be = *reinterpret_cast<const f32x4*>(beta + (lane + 64 * i) * 4);
+                v[i] = v[i] * rstd * g + be;
+                n2 += (v[i][0] * v[i][0] + v[i][1] * v[i][1]) + (v[i][2] * v[i][2] + v[i][3] * v[i][3]);
+            }
+            const float inv = 1.0f / fmaxf(sqrtf(wave_sum(n2)), 1e-12f);
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                v[i] *= inv;
+                *reinterpret_cast<f32x4*>(vhat + row * D + (lane + 64 * i) * 4) = v[i];
+                *reinterpret_cast<f32x4*>(vs + rl * VC_LDS_STRIDE + (lane + 64 * i) * 4) = v[i];
+            }
         }
-    }
-    __syncthreads();
-    for (int idx = threadIdx.x; idx < T * VC_ROWS; idx += 256) {
-        const int t = idx / VC_ROWS, r = idx % VC_ROWS;
-        const int tok = row0 + r;
-        if (tok < n_valid) scores[((int64_t)b * T + t) * n_valid + tok] = sc[idx];
+        __syncthreads();
+        // S tile: D[token 4*lg + r][prompt l15]; K is walked in blocks of 16 (lane (., lg) supplies k = 16*kb + 4*lg + u
+        // for the u-th of four MFMAs: a permuted but consistent K order for both operands)
+        for (int tt = wave; tt < ttiles; tt += 4) {
+            const int t = tt * 16 + l15;
+            const float* qrow = qhat + (int64_t)(t < T ? t : T - 1) * D + 4 * lg;
+            const float* arow = vs + l15 * VC_LDS_STRIDE + 4 * lg;
+            f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+            for (int kb = 0; kb < D / 16; ++kb) {
+                const f32x4 av = *reinterpret_cast<const f32x4*>(arow + kb * 16);
+                const f32x4 bv = *reinterpret_cast<const f32x4*>(qrow + kb * 16);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u], bv[u], acc, 0, 0, 0);
+            }
+            if (t < T) {
+                float* o = scores + ((int64_t)b * T + t) * n_valid + tok0 + 4 * lg;
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (tok0 + 4 * lg + r < n_valid) o[r] = acc[r] * inv_tau;
+            }
+        }
+        __syncthreads();
     }
 }
 
@@ -188,9 +210,7 @@ hipError_t launch_vlcabs(const float* tokens, const float* ln_gamma, const float
                          const float* qhat, float tau, float* vhat, float* ws, float* scores, float* t2i_logits,
                          float* logits, int B, int T, int n_valid, int n_pad, int D, hipStream_t s) {
     if (D != 768 || B <= 0 || T <= 0 || n_pad % VC_CHUNK || n_valid > n_pad) return hipErrorInvalidValue;
-    const size_t shm = (size_t)T * VC_ROWS * sizeof(float);
-    if (shm > 120 * 1024) return hipErrorInvalidValue;   // T <= 480 per call
-    hipLaunchKernelGGL(vlcabs_scores_kernel, dim3(n_pad / VC_ROWS, B), dim3(256), shm, s, tokens, ln_gamma, ln_beta, ln_eps,
+    hipLaunchKernelGGL(vlcabs_scores_kernel, dim3(n_pad / VC_ROWS, B), dim3(256), 0, s, tokens, ln_gamma, ln_beta, ln_eps,
                        qhat, 1.0f / tau, vhat, scores, T, n_valid, n_pad);
     const int nchunks = n_pad / VC_CHUNK;
     hipLaunchKernelGGL(vlcabs_partial_kernel, dim3(nchunks, B, (T + VC_TG - 1) / VC_TG), dim3(256), 0, s, vhat, scores, ws, T,
@@ -203,41 +223,56 @@ hipError_t launch_vlcabs(const float* tokens, const float* ln_gamma, const float
 // One thread produces 4 consecutive pixels of a row (16-byte store); the two source rows of an output row are the
 // same for the whole row, so their addresses/weights are computed once per thread.  HBM-write bound:
 // n_maps*H*W*4 bytes (4.29 GB at BASELINE cfg 4).
+constexpr int UP_ROWS = 8;      // output rows per thread: the four x interpolation set-ups are amortised over them
 __global__ __launch_bounds__(256) void upsample_bilinear_kernel(const float* __restrict__ maps, int64_t map_stride,
                                                                 float* __restrict__ out, int g, int Hout, int Wout,
                                                                 float sy, float sx, int apply_sigmoid, int off_y, int off_x) {
     // (off_y, off_x): crop origin inside the virtual square map of the aspect-ratio branch (0 for the plain branch)
     const int m = blockIdx.z;
-    const int y = blockIdx.y;
+    const int ybase = blockIdx.y * UP_ROWS;
     const int x4 = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
     if (x4 >= Wout) return;
     const float* src = maps + (int64_t)m * map_stride;
-    float fy = sy * (y + off_y + 0.5f) - 0.5f; fy = fy < 0.f ? 0.f : fy;
-    const int y0 = (int)fy;
-    const int y1 = y0 + (y0 < g - 1 ? 1 : 0);
-    const float ly = fy - y0, hy = 1.f - ly;
-    const float* r0 = src + y0 * g;
-    const float* r1 = src + y1 * g;
-    float v[4];
+    int x0[4], x1[4];
+    float lx[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int x = x4 + i;
         float fx = sx * (x + off_x + 0.5f) - 0.5f; fx = fx < 0.f ? 0.f : fx;
-        int x0 = (int)fx;
-        x0 = x0 > g - 1 ? g - 1 : x0;                         // only reachable for x >= Wout (masked below)
-        const int x1 = x0 + (x0 < g - 1 ? 1 : 0);
-        const float lx = fx - x0, hx = 1.f - lx;
-        float t = hy * (hx * r0[x0] + lx * r0[x1]) + ly * (hx * r1[x0] + lx * r1[x1]);
-        if (apply_sigmoid) t = 1.0f / (1.0f + expf(-t));
-        v[i] = t;
+        int xa = (int)fx;
+        xa = xa > g - 1 ? g - 1 : xa;                         // only reachable for x >= Wout (masked below)
+        x0[i] = xa;
+        x1[i] = xa + (xa < g - 1 ? 1 : 0);
+        lx[i] = fx - xa;
     }
-    float* o = out + ((int64_t)m * Hout + y) * Wout + x4;
-    if (x4 + 3 < Wout && ((((int64_t)m * Hout + y) * Wout + x4) & 3) == 0) {
-        *reinterpret_cast<f32x4*>(o) = (f32x4){v[0], v[1], v[2], v[3]};
-    } else {
+    const bool full = x4 + 3 < Wout;
+#pragma unroll 2
+    for (int r = 0; r < UP_ROWS; ++r) {
+        const int y = ybase + r;
+        if (y >= Hout) break;
+        float fy = sy * (y + off_y + 0.5f) - 0.5f; fy = fy < 0.f ? 0.f : fy;
+        const int y0 = (int)fy;
+        const int y1 = y0 + (y0 < g - 1 ? 1 : 0);
+        const float ly = fy - y0, hy = 1.f - ly;
+        const float* r0 = src + y0 * g;
+        const float* r1 = src + y1 * g;
+        float v[4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
-            if (x4 + i < Wout) o[i] = v[i];
+        for (int i = 0; i < 4; ++i) {
+            const float hx = 1.f - lx[i];
+            float t = hy * (hx * r0[x0[i]] + lx[i] * r0[x1[i]]) + ly * (hx * r1[x0[i]] + lx[i] * r1[x1[i]]);
+            if (apply_sigmoid) t = 1.0f / (1.0f + expf(-t));
+            v[i] = t;
+        }
+        const int64_t base = ((int64_t)m * Hout + y) * Wout + x4;
+        float* o = out + base;
+        if (full && (base & 3) == 0) {
+            *reinterpret_cast<f32x4*>(o) = (f32x4){v[0], v[1], v[2], v[3]};
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                if (x4 + i < Wout) o[i] = v[i];
+        }
     }
 }
 
@@ -320,7 +355,7 @@ hipError_t launch_upsample_bilinear(const float* maps, int64_t map_stride, float
     const float sy = keep_aspect ? (float)g / (float)P : (float)g / (float)Hout;
     const float sx = keep_aspect ? (float)g / (float)P : (float)g / (float)Wout;
     const int off_y = keep_aspect ? (P - Hout) / 2 : 0, off_x = keep_aspect ? (P - Wout) / 2 : 0;
-    hipLaunchKernelGGL(upsample_bilinear_kernel, dim3((Wout + 1023) / 1024, Hout, M), dim3(256), 0, s, maps, map_stride, out, g,
+    hipLaunchKernelGGL(upsample_bilinear_kernel, dim3((Wout + 1023) / 1024, (Hout + UP_ROWS - 1) / UP_ROWS, M), dim3(256), 0, s, maps, map_stride, out, g,
                        Hout, Wout, sy, sx, apply_sigmoid, off_y, off_x);
     return hipGetLastError();
 }
