@@ -150,21 +150,25 @@ __device__ __forceinline__ float wave_max(float v) {
 
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 
-// exact-erf GELU with erf from Abramowitz-Stegun 7.1.26 (|erf error| <= 1.5e-7, i.e. below bf16/f16 output rounding
-// by 4 orders of magnitude): 1 rcp + 1 exp2 + 12 FMA-class ops instead of libm's branchy erff.
-//   erf(z) = 1 - (a1 t + ... + a5 t^5) e^{-z^2},  t = 1/(1 + p z),  z = |x|/sqrt(2)
+// GELU for the 16-bit modes, transcendental-free:  gelu(x) = max(x, 0) - a Q(a),  a = min(|x|, 4.5),
+// Q(a) = (1 - erf(a / sqrt 2)) / 2 replaced by its degree-9 Chebyshev fit on [0, 4.5] evaluated by Horner in
+// u = 2a/4.5 - 1 (well conditioned in fp32).  |error| <= 2.3e-5 absolute, <= 3.2e-5 relative near 0 (simulated in fp32
+// over [-12, 12] against scipy's erf) — 40x below one f16 ulp at 1 and 350x below one bf16 ulp — at 9 VALU
+// issue slots per element instead of 14 for the rcp + exp2 form of Abramowitz-Stegun 7.1.26 (the fc1 epilogue is
+// VALU-bound: 65536 elements per 256x256 tile).  fp32 mode uses libm erff (gelu_erf above).
 __device__ __forceinline__ float gelu_erf_fast(float x) {
-    // gelu(x) = max(x, 0) - |x| * Q(|x|),  Q(a) = (1 - erf(a / sqrt 2)) / 2 = (a1 t + ... + a5 t^5) / 2 * e^{-a^2/2}
-    // (coefficients pre-halved; |x| is a free source modifier; the max/sub pair replaces a compare + select + subtract)
-    const float ax = fabsf(x);
-    const float t = __builtin_amdgcn_rcpf(fmaf(ax, 0.3275911f * 0.70710678118654752440f, 1.0f));
-    float poly = fmaf(t, 0.5f * 1.061405429f, 0.5f * -1.453152027f);
-    poly = fmaf(poly, t, 0.5f * 1.421413741f);
-    poly = fmaf(poly, t, 0.5f * -0.284496736f);
-    poly = fmaf(poly, t, 0.5f * 0.254829592f);
-    poly *= t;
-    const float e = __builtin_amdgcn_exp2f(x * x * -0.72134752044448170368f);   // e^{-x^2/2}
-    return fmaxf(x, 0.f) - ax * (poly * e);
+    const float a = fminf(fabsf(x), 4.5f);
+    const float u = fmaf(a, 2.0f / 4.5f, -1.0f);
+    float p = fmaf(u, -1.913512412e-02f, 2.984178795e-02f);
+    p = fmaf(p, u, 4.896834610e-02f);
+    p = fmaf(p, u, -1.296090571e-01f);
+    p = fmaf(p, u, 3.827712359e-02f);
+    p = fmaf(p, u, 1.566413223e-01f);
+    p = fmaf(p, u, -2.468006774e-01f);
+    p = fmaf(p, u, 1.809132537e-01f);
+    p = fmaf(p, u, -7.131592906e-02f);
+    p = fmaf(p, u, 1.222076767e-02f);
+    return fmaxf(x, 0.f) - a * p;
 }
 template <typename T> __device__ __forceinline__ float gelu_for(float x) {
     if constexpr (sizeof(T) == 4) return gelu_erf(x);      // fp32 parity mode: libm erff
