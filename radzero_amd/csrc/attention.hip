@@ -11,7 +11,9 @@
 //                   MFMA row i of 16-key tile kt is key 32(kt>>1) + 8(i>>2) + 4(kt&1) + (i&3), so lane
 //                   (q = lane&15, g = lane>>4), which receives rows 4g..4g+3 of every tile, owns the 8 CONTIGUOUS
 //                   keys 32kk + 8g .. +7 of each 32-key step kk (tiles 2kk and 2kk+1).
-//   softmax       : row statistics are per lane (+2 shuffles across g); no LDS round trip.
+//   softmax       : per-lane max guard and exponentials only; no cross-lane step and no LDS round trip in the hot path
+//                   (the cross-lane row maximum is needed only inside the rare re-centring branch).
+//   l^T += 1 P^T  : row sums accumulate on the matrix pipe (all-ones A fragment; template flag LS, default).
 //   O^T += V^T P^T: A = V^T fragment (row = d, 8 contiguous keys 32kk + 8g..+7: one ds_read_b128),
 //                   B = P^T packed in registers straight from the S^T accumulators (no transpose, no LDS);
 //                   V^T rows are key-contiguous because the QKV GEMM epilogue wrote V transposed ([B][H][64][Npad]).
