@@ -211,7 +211,10 @@ static hipError_t launch_gemm_t(int epi, const GemmArgs& g, hipStream_t s) {
     // than ~200 big tiles (single-image calls) the 128x128 kernel fills the 256 CUs better.
     // v7 (gemm7.hip, 16-bit only): K loop 1.40 us per 256x256x64 step against 1.68 for v3 (tools/kslope.py)
     if (variant == 0) {
-        const bool big = ok3 && (int64_t)(g.M / BM2) * (g.N / BN3) >= 200;
+        // big tiles pay off once their rounds over the 256 CUs are >= 55 % full (measured, bench.py --batch 1..7:
+        // 126 tiles -> 128x128 kernel 6 % faster; 189 tiles -> 256x256 kernel 7 % faster; 315 tiles -> 1 % faster)
+        const int64_t t256 = (int64_t)(g.M / BM2) * (g.N / BN3);
+        const bool big = ok3 && t256 >= 128 && (double)t256 / (double)(((t256 + 255) / 256) * 256) >= 0.55;
         variant = !big ? 1 : gemm_v7_ok(Traits<T>::kDType, g) ? 7 : 3;
     }
     if (variant == 7 || variant == 9) {
