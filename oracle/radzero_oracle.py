@@ -205,13 +205,28 @@ def vlcabs(text_features, vision_tokens, ln_w, ln_b, ln_eps, temperature):
     return logits_bt.t().contiguous(), scores                  # losses.py:233 (.T)
 
 
-def interpolate_similarity_scores(similarity_scores, origin_size):
-    """exp/cxr_pt/inference/segmentation_utils.py:36-70, BlipImageProcessor branch (:62-70):
-    (g*g,) -> view (1,1,g,g) -> bilinear, align_corners=False -> (1, H, W)."""
+def interpolate_similarity_scores(similarity_scores, origin_size, keep_aspect_ratio=False):
+    """exp/cxr_pt/inference/segmentation_utils.py:36-70: (g*g,) -> view (1,1,g,g) -> bilinear, align_corners=False
+    -> (1, H, W).  keep_aspect_ratio=False: BlipImageProcessor branch (:62-70).  True: AspectRatioBlipImageProcessor
+    branch (:41-60) — upsample to the padded square max(H, W), crop [pad_top:pad_top+H, pad_left:pad_left+W].
+    Pinned by tests/golden/post_maps.npz (outputs of the reference's own function)."""
     h, w = origin_size
     g = int(similarity_scores.shape[-1] ** 0.5)
     s = similarity_scores.reshape(1, 1, g, g)
-    return F.interpolate(s, size=(h, w), mode="bilinear", align_corners=False).squeeze(1)
+    if not keep_aspect_ratio:
+        return F.interpolate(s, size=(h, w), mode="bilinear", align_corners=False).squeeze(1)
+    p = max(h, w)
+    sq = F.interpolate(s, size=(p, p), mode="bilinear", align_corners=False)
+    left, top = (p - w) // 2, (p - h) // 2
+    return sq[:, :, top:top + h, left:left + w].contiguous().squeeze(1)
+
+
+def get_grounding_point(similarity_score, image_size, keep_aspect_ratio=False):
+    """exp/cxr_pt/inference/grounding_utils.py:166-261: upsample as above, first flat maximum, unravel -> (x, y)."""
+    h, w = image_size
+    m = interpolate_similarity_scores(similarity_score, image_size, keep_aspect_ratio).reshape(-1)
+    idx = int(torch.argmax(m))                   # torch.max(dim=0) on the flat map returns the first maximum
+    return idx % w, idx // w
 
 
 # --------------------------------------------------------------------------------------------

@@ -32,33 +32,62 @@ def _needs_rebuild() -> bool:
 
 
 def build(force: bool = False, verbose: bool = False) -> str:
-    """hipcc --offload-arch=gfx950 every source, link in-tree (the .so travels with the repo snapshot)."""
+    """hipcc --offload-arch=gfx950 every source, link in-tree (the .so travels with the repo snapshot).
+
+    Safe under `torch.distributed.run` (every rank imports this module at the same time): the whole build runs under an
+    exclusive `flock` on radzero_amd/build/.lock, objects and the library are written to per-process temporary names and
+    moved into place with `os.replace`, and whoever gets the lock second finds an up-to-date library and does nothing.
+    A reader therefore never maps a half-written file."""
     if not force and not _needs_rebuild():
         return LIB_PATH
     if not os.path.exists(HIPCC):
         raise RuntimeError(f"hipcc not found at {HIPCC}; cannot build libradzero_hip.so")
+    import fcntl
     obj_dir = os.path.join(PKG_DIR, "build")
     os.makedirs(obj_dir, exist_ok=True)
+    with open(os.path.join(obj_dir, ".lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            if not force and not _needs_rebuild():       # another process built it while this one waited
+                return LIB_PATH
+            return _build_locked(obj_dir, verbose, force)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
+
+
+def _build_locked(obj_dir: str, verbose: bool, force: bool = False) -> str:
     flags = [f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "-Werror=uninitialized",
              "-Werror=return-type"]
+    tag = f".{os.getpid()}.tmp"
 
     def cc(src):
         obj = os.path.join(obj_dir, src.replace(".hip", ".o"))
-        cmd = [HIPCC, *flags, *EXTRA_FLAGS.get(src, []), "-c", os.path.join(CSRC, src), "-o", obj]
+        if not force and os.path.exists(obj) and os.path.getmtime(obj) > _src_mtime(src):
+            return obj                                   # unchanged translation unit: keep its object
+        cmd = [HIPCC, *flags, *EXTRA_FLAGS.get(src, []), "-c", os.path.join(CSRC, src), "-o", obj + tag]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"hipcc failed for {src}:\n{r.stderr}")
         if r.stderr and (verbose or "-Wuninitialized" in r.stderr or "-Wreturn-type" in r.stderr or "-Wsometimes-uninitialized" in r.stderr):
             print(r.stderr, file=sys.stderr)         # these warnings have been real bugs: never hide them
+        os.replace(obj + tag, obj)
         return obj
 
     with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 1)) as ex:
         objs = list(ex.map(cc, SOURCES))
-    r = subprocess.run([HIPCC, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", LIB_PATH, *objs],
+    r = subprocess.run([HIPCC, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", LIB_PATH + tag, *objs],
                        capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError(f"link failed:\n{r.stderr}")
+    os.replace(LIB_PATH + tag, LIB_PATH)
     return LIB_PATH
+
+
+def _src_mtime(src: str) -> float:
+    """Newest mtime of a translation unit and every header it may include."""
+    deps = [os.path.join(CSRC, src)] + [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
+    deps.append(os.path.join(PKG_DIR, "..", "include", "radzero_hip.h"))
+    return max(os.path.getmtime(d) for d in deps if os.path.exists(d))
 
 
 class RzConfig(ctypes.Structure):

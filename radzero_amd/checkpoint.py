@@ -78,9 +78,43 @@ def save_checkpoint(state_dict, path: str) -> str:
     return f
 
 
-def config_from_hf(path_or_dict) -> RadZeroConfig:
-    """RadZeroConfig from a CxrAlignConfig config.json (nested vision_config / text_config /
-    align_transformer_config / loss kwargs); absent fields keep the released defaults."""
+def _shape_facts(state_dict) -> dict:
+    """Hyper-parameters that a CxrAlignModel checkpoint only carries as tensor shapes / key counts.  The reference's
+    config.json (`CxrAlignConfig.save_pretrained`, configuration.py:107-129 — fixture tests/golden/hf_layout/config.json)
+    stores the text side as `pretrained_name_or_path` only: vocabulary, depth, widths of the MPNet encoder are whatever
+    `AutoModel.from_pretrained(name)` built (text_encoders.py:13-14), i.e. visible in the state dict and nowhere else."""
+    facts = {}
+    if not state_dict:
+        return facts
+    def depth(prefix):
+        idx = {int(k[len(prefix):].split(".", 1)[0]) for k in state_dict if k.startswith(prefix)}
+        return (max(idx) + 1) if idx else 0
+    shape = lambda k: tuple(np.shape(state_dict[k])) if k in state_dict else None
+    facts["vit_layers"] = depth("vision_model.encoder.layer.")
+    facts["align_layers"] = depth("align_transformer.transformer_layers.layer.")
+    facts["text_layers"] = depth("text_model.encoder.layer.")
+    we = shape("text_model.embeddings.word_embeddings.weight")
+    pe = shape("text_model.embeddings.position_embeddings.weight")
+    rb = shape("text_model.encoder.relative_attention_bias.weight")
+    inter = shape("text_model.encoder.layer.0.intermediate.dense.weight")
+    vpos = shape("vision_model.embeddings.position_embeddings")
+    pw = shape("vision_model.embeddings.patch_embeddings.projection.weight")
+    if we: facts["vocab_size"], facts["hidden_size"] = we
+    if pe: facts["max_position_embeddings"] = pe[0]
+    if rb: facts["relative_attention_num_buckets"], facts["num_attention_heads"] = rb
+    if inter: facts["text_intermediate_size"] = inter[0]
+    if pw: facts["num_channels"], facts["patch_size"] = pw[1], pw[2]
+    if vpos and pw:
+        facts["pretrain_image_size"] = int(round((vpos[-2] - 1) ** 0.5)) * pw[2]
+    return facts
+
+
+def config_from_hf(path_or_dict, state_dict=None) -> RadZeroConfig:
+    """RadZeroConfig from a CxrAlignConfig config.json (vision_config / text_config / align_transformer_config and the
+    loss kwargs, which `PretrainedConfig` writes at the top level — a "kwargs" nesting is accepted too) plus, when
+    `state_dict` is given, the shapes of the checkpoint itself (see _shape_facts; they win where both speak, because the
+    weights are what will be multiplied).  Absent fields keep the released defaults — in particular MPNet's
+    layer_norm_eps, which lives in neither place (it is the hub config of all-mpnet-base-v2)."""
     d = path_or_dict
     if isinstance(d, str):
         p = os.path.join(d, "config.json") if os.path.isdir(d) else d
@@ -88,9 +122,10 @@ def config_from_hf(path_or_dict) -> RadZeroConfig:
     v = d.get("vision_config", {}) or {}
     t = d.get("text_config", {}) or {}
     a = d.get("align_transformer_config", {}) or {}
-    loss = ((d.get("kwargs", d).get("loss", {}) or {}).get("RadZeroLoss", {}) or {})
+    extra = d.get("kwargs") if isinstance(d.get("kwargs"), dict) else d
+    loss = ((extra.get("loss", {}) or {}).get("RadZeroLoss", {}) or {})
     base = RadZeroConfig()
-    cfg = RadZeroConfig(
+    fields = dict(
         hidden_size=v.get("hidden_size", base.hidden_size),
         num_attention_heads=v.get("num_attention_heads", base.num_attention_heads),
         mlp_ratio=v.get("mlp_ratio", base.mlp_ratio),
@@ -109,8 +144,12 @@ def config_from_hf(path_or_dict) -> RadZeroConfig:
         loss_temperature=loss.get("loss_temperature", base.loss_temperature),
         sim_op=loss.get("sim_op", base.sim_op),
     )
+    fields.update(_shape_facts(state_dict))
+    cfg = RadZeroConfig(**fields)
     if a.get("use_layer_norm"):
         raise NotImplementedError("align_transformer_config.use_layer_norm=True is not part of the released model")
-    if (d.get("kwargs", d).get("compute_logits_type", "radzero")) != "radzero":
+    if t.get("use_text_projection"):
+        raise NotImplementedError("text_config.use_text_projection=True is not part of the released model")
+    if (extra.get("compute_logits_type") or "radzero") != "radzero":
         raise NotImplementedError("only compute_logits_type == 'radzero' is implemented")
     return cfg

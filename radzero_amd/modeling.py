@@ -85,6 +85,7 @@ class RadZeroModel:
         self._grids = set()
         self._rel_bias_cache: Dict[int, torch.Tensor] = {}
         self._text_cache: Dict[bytes, torch.Tensor] = {}
+        self._text_ident_cache: Dict[tuple, tuple] = {}
         self.text_cache_enabled = True
         self._reserved = (0, 0, 0, 0)
         self.training = False
@@ -129,10 +130,11 @@ class RadZeroModel:
         analogue (README.md:77-82) for a LOCAL checkpoint directory / file (there is no network here)."""
         from .checkpoint import config_from_hf, load_checkpoint
         import os
+        sd = load_checkpoint(path)
         if config is None:
             has_cfg = os.path.isdir(path) and os.path.exists(os.path.join(path, "config.json"))
-            config = config_from_hf(path) if has_cfg else RadZeroConfig()
-        return cls.from_state_dict(load_checkpoint(path), config, torch_dtype=torch_dtype, device=device)
+            config = config_from_hf(path if has_cfg else {}, state_dict=sd)
+        return cls.from_state_dict(sd, config, torch_dtype=torch_dtype, device=device)
 
     def load_state_dict(self, state_dict, strict: bool = True):
         """Accepts the reference checkpoint's names (numpy arrays or torch tensors, any float dtype)."""
@@ -154,6 +156,7 @@ class RadZeroModel:
         self._grids.clear()
         self._rel_bias_cache.clear()
         self._text_cache.clear()
+        self._text_ident_cache.clear()
         return self
 
     # ---- nn.Module-like surface used by the reference's callers -------------------------------
@@ -263,18 +266,33 @@ class RadZeroModel:
 
     def encode_prompts(self, encoded) -> torch.Tensor:
         """text_features_wo_l2_norm for a prompt set, cached: the reference re-encodes every prompt for every
-        image batch (modeling.py:290-307); the embeddings do not depend on the images."""
+        image batch (modeling.py:290-307); the embeddings do not depend on the images.
+
+        Two levels.  (1) identity: (data_ptr, shape, dtype, device, _version) of the id / mask tensors — no device
+        work, no host sync; this is what every reference caller hits, because they tokenise once and pass the same
+        tensors for every image batch (inference/utils.py:92-100, grounding_utils.py:50-62).  The entry keeps the two
+        tensors alive, so their storage cannot be recycled under the key, and an in-place write bumps `_version`.
+        (2) content: the token bytes, for callers that re-tokenise per call (one D2H copy of a few hundred bytes)."""
         ids = encoded["input_ids"]
         mask = encoded["attention_mask"]
-        key = None
-        if self.text_cache_enabled:
-            key = ids.detach().cpu().numpy().tobytes() + b"|" + mask.detach().cpu().numpy().tobytes() + str(tuple(ids.shape)).encode()
-            hit = self._text_cache.get(key)
+        if not self.text_cache_enabled:
+            return self.forward_text_model({"input_ids": ids, "attention_mask": mask})["text_features_wo_l2_norm"]
+        ident = None
+        if torch.is_tensor(ids) and torch.is_tensor(mask):
+            ident = (ids.data_ptr(), mask.data_ptr(), tuple(ids.shape), tuple(mask.shape), ids.dtype, mask.dtype,
+                     str(ids.device), ids._version, mask._version)
+            hit = self._text_ident_cache.get(ident)
             if hit is not None:
-                return hit
-        feat = self.forward_text_model({"input_ids": ids, "attention_mask": mask})["text_features_wo_l2_norm"]
-        if key is not None:
+                return hit[2]
+        key = ids.detach().cpu().numpy().tobytes() + b"|" + mask.detach().cpu().numpy().tobytes() + str(tuple(ids.shape)).encode()
+        feat = self._text_cache.get(key)
+        if feat is None:
+            feat = self.forward_text_model({"input_ids": ids, "attention_mask": mask})["text_features_wo_l2_norm"]
             self._text_cache[key] = feat
+        if ident is not None:
+            if len(self._text_ident_cache) >= 64:                   # bounded: drop the oldest identity entry
+                self._text_ident_cache.pop(next(iter(self._text_ident_cache)))
+            self._text_ident_cache[ident] = (ids, mask, feat)
         return feat
 
     # ---- CxrAlignModel.compute_logits, compute_logits_type == "radzero" (modeling.py:278-328) ---

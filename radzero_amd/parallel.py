@@ -64,10 +64,31 @@ def _all_gather_cpu(out, buf, group):
 
 
 def gather_logits(local_logits: torch.Tensor, group=None, dst: int = 0):
-    """Optional result gather of the (B_local, T) logits to rank `dst` (similarity maps stay sharded)."""
+    """Optional result gather of the (B_local, T) logits to rank `dst` (similarity maps stay sharded).  Ranks may hold
+    different numbers of rows (uneven image shards, ranks with none): row counts are exchanged first, rows are padded
+    to the largest shard for the gather and trimmed again on `dst`.  Returns the rank-ordered concatenation on `dst`,
+    None elsewhere."""
     if not (dist.is_available() and dist.is_initialized()):
         return local_logits
-    world = dist.get_world_size(group)
-    parts = [torch.empty_like(local_logits) for _ in range(world)] if dist.get_rank(group) == dst else None
-    dist.gather(local_logits, parts, dst=dst, group=group)
+    parts = gather_row_shards(local_logits, group=group, dst=dst)
     return torch.cat(parts, dim=0) if parts is not None else None
+
+
+def gather_row_shards(local: torch.Tensor, group=None, dst: int = 0):
+    """List of every rank's (rows_r, T) tensor on rank `dst` (None elsewhere); rows_r may differ per rank and be 0."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return [local]
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    dev = local.device
+    n = torch.tensor([local.shape[0]], dtype=torch.int64, device=dev)
+    counts = [torch.zeros_like(n) for _ in range(world)]
+    dist.all_gather(counts, n, group=group)
+    counts = [int(c.item()) for c in counts]
+    nmax = max(counts)
+    if nmax == 0:
+        return [local[:0] for _ in range(world)] if rank == dst else None
+    padded = torch.zeros((nmax,) + tuple(local.shape[1:]), dtype=local.dtype, device=dev)
+    padded[: local.shape[0]] = local
+    parts = [torch.empty_like(padded) for _ in range(world)] if rank == dst else None
+    dist.gather(padded, parts, dst=dst, group=group)
+    return [p[:c] for p, c in zip(parts, counts)] if parts is not None else None

@@ -148,6 +148,30 @@ def make_state_dict(cfg: RadZeroConfig | None = None, seed: int = 20260103,
     return out
 
 
+def add_outlier_channels(sd, cfg: RadZeroConfig | None = None, seed: int = 77, n_channels: int = 4,
+                         ln_gain: float = 0.08, fc2_gain: float = 400.0):
+    """Copy of `sd` with "massive activation" channels, the feature of trained DINOv2 checkpoints the benign generator
+    above lacks: `n_channels` fixed hidden channels get their fc2 output rows (+ bias) multiplied by `fc2_gain` in every
+    Dinov2 block, so the fp32 residual stream carries a few values two orders of magnitude above the rest and every
+    LayerNorm's mean / variance is dominated by them; as in trained checkpoints, the LN gains of those channels are small
+    (`ln_gain`), which keeps the network well conditioned (with LARGE gains on them even two fp32 implementations
+    disagree by > 1 on the scores: attention logits of 1e4 make the soft-max a chaotic arg-max).  Used to test the 16-bit
+    modes' range and precision behaviour (tests/golden/g8_outlier_*.npz holds the reference's outputs for it)."""
+    cfg = cfg or RadZeroConfig()
+    ch = np.sort(_rng(seed, "outlier_channels").choice(cfg.hidden_size, size=n_channels, replace=False))
+    out = OrderedDict((k, np.array(v, np.float32, copy=True)) for k, v in sd.items())
+    for k in out:
+        if not (k.startswith("vision_model.") or k.startswith("align_transformer.")):
+            continue
+        if k.endswith("norm1.weight") or k.endswith("norm2.weight") or k == "vision_model.layernorm.weight":
+            out[k][ch] *= np.float32(ln_gain)
+        elif k.endswith("mlp.fc2.weight"):
+            out[k][ch, :] *= np.float32(fc2_gain)
+        elif k.endswith("mlp.fc2.bias"):
+            out[k][ch] *= np.float32(fc2_gain)
+    return out
+
+
 def state_dict_digest(sd) -> str:
     """Order-independent fingerprint of a checkpoint (used to pin goldens to the generator)."""
     acc = 0

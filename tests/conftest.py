@@ -40,3 +40,15 @@ def load_golden(name):
 
 GOLDEN_CASES = ["g1_s224_b1_t1", "g2_s224_b2_t3", "g2_s224_b1_t14", "g2_s224_b3_t1",
                 "g3_s266_b2_t3", "g3_s518_b1_t14", "g5_s224_b1_t64_l32", "g7_s1024_b1_t14"]
+
+
+def post_map_cases():
+    """tests/golden/post_maps.npz (tools/make_goldens_post.py: the reference's own interpolate_similarity_scores /
+    get_grounding_point): yields (golden_name, (H, W), keep_aspect_ratio, moments (T,3) f64, samples (T,n) f32, points (T,2))."""
+    import numpy as np
+    z = np.load(os.path.join(GOLDEN_DIR, "post_maps.npz"), allow_pickle=False)
+    stride = int(z["sample_stride"])
+    for key in [str(k) for k in z["cases"]]:
+        gname, size, proc = key.split("|")
+        h, w = (int(v) for v in size.split("x"))
+        yield gname, (h, w), proc == "aspect", z[key + "|moments"], z[key + "|samples"], z[key + "|points"], stride

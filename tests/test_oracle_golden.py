@@ -87,3 +87,37 @@ def test_position_ids_skip_padding():
     from oracle.radzero_oracle import mpnet_position_ids
     ids = torch.tensor([[0, 7, 8, 2, 1, 1]])
     assert mpnet_position_ids(ids).tolist() == [[2, 3, 4, 5, 1, 1]]
+
+
+def test_oracle_postprocessing_matches_reference_functions():
+    """Oracle restatement of interpolate_similarity_scores / get_grounding_point vs the outputs of the reference's own
+    functions (both image-processor branches, square and non-square originals): same torch op, so bit-equal."""
+    from conftest import post_map_cases
+    from oracle.radzero_oracle import get_grounding_point, interpolate_similarity_scores
+    n = 0
+    for gname, (h, w), aspect, moments, samples, points, stride in post_map_cases():
+        scores = torch.from_numpy(load_golden(gname)["similarity_scores"])[0]
+        for t in range(scores.shape[0]):
+            m = interpolate_similarity_scores(scores[t], (h, w), keep_aspect_ratio=aspect)
+            assert tuple(m.shape) == (1, h, w)
+            assert np.array_equal(m[0].reshape(-1)[::stride].numpy(), samples[t])
+            assert float(m[0].double().sum()) == moments[t][0]
+            assert get_grounding_point(scores[t], (h, w), keep_aspect_ratio=aspect) == tuple(int(v) for v in points[t])
+            n += 1
+    assert n == 10 * 14
+
+
+def test_oracle_matches_reference_on_outlier_checkpoint(cfg, state_dict):
+    """G8: massive-activation channels (weights.add_outlier_channels; residual |max| ~ 470 in the reference run)."""
+    from oracle.radzero_oracle import OracleModel
+    from radzero_amd.weights import add_outlier_channels
+    g = load_golden("g8_outlier_s224_b2_t3")
+    sd = add_outlier_channels(state_dict, cfg)
+    assert state_dict_digest(sd) == str(g["weights_digest"])
+    px = synthetic_pixels(2, 224, int(g["px_seed"]))
+    enc = {"input_ids": torch.from_numpy(g["input_ids"]), "attention_mask": torch.from_numpy(g["attention_mask"])}
+    with torch.no_grad():
+        out = OracleModel(sd, cfg, attn_impl="eager").compute_logits(px, [enc])
+    assert np.abs(out["logits"].numpy() - g["logits"]).max() <= TOL
+    assert np.abs(out["similarity_scores"].numpy() - g["similarity_scores"]).max() <= 5 * TOL
+    assert float(g["residual_absmax_per_layer"].max()) > 400.0

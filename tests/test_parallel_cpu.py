@@ -69,6 +69,68 @@ def test_sharded_text_features_gloo(world, n_prompts):
     assert all(ok_t and ok_g for _, ok_t, ok_g in res), res
 
 
+class _FakeModel:
+    """CPU stand-in with the model protocol calculate_similarities uses (device, config.hidden_size,
+    forward_text_model / encode_prompts / compute_logits): logits are a deterministic function of (image, prompt)."""
+
+    class config:
+        hidden_size = 8
+
+    device = torch.device("cpu")
+
+    def forward_text_model(self, enc):
+        return {"text_features_wo_l2_norm": _encode(enc)}
+
+    def encode_prompts(self, enc):
+        return _encode(enc)
+
+    def compute_logits(self, pixel_values, encoded_key_phrases, text_features=None, **_):
+        img = pixel_values.double().mean(dim=(1, 2, 3))                       # (B,)
+        return {"logits": (img[:, None] * text_features.double().sum(1)[None, :] + text_features.double()[:, 0][None, :]).float()}
+
+
+def _batches(n_images, batch):
+    g = torch.Generator().manual_seed(5)
+    px = torch.randn(n_images, 3, 4, 4, generator=g)
+    return [px[i:i + batch] for i in range(0, n_images, batch)]
+
+
+def _driver_worker(rank, world, port, n_images, batch, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from radzero_amd.inference import calculate_similarities
+        g = torch.Generator().manual_seed(1)
+        enc = {"input_ids": torch.randint(4, 30000, (5, 7), generator=g), "attention_mask": torch.ones(5, 7, dtype=torch.long)}
+        got = calculate_similarities(_batches(n_images, batch), {"encoded_key_phrases": enc}, _FakeModel(), distributed=True)
+        q.put((rank, None if got is None else got.tolist()))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,n_images,batch", [(2, 7, 2), (3, 7, 2), (3, 2, 2), (2, 5, 8), (4, 9, 1)])
+def test_batch_driver_shards_images_and_restores_order(world, n_images, batch):
+    """every rank passes the same batches; ranks compute disjoint shares (uneven, some empty) and rank 0
+    gets exactly the single-process result, in the original image order."""
+    from radzero_amd.inference import calculate_similarities
+    g = torch.Generator().manual_seed(1)
+    enc = {"input_ids": torch.randint(4, 30000, (5, 7), generator=g), "attention_mask": torch.ones(5, 7, dtype=torch.long)}
+    want = calculate_similarities(_batches(n_images, batch), {"encoded_key_phrases": enc}, _FakeModel())
+    assert want.shape == (n_images, 5)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_driver_worker, args=(r, world, port, n_images, batch, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(res[r] is None for r in range(1, world))
+    assert np.array_equal(np.asarray(res[0], np.float32), want)
+
+
 def test_shard_range_covers_everything():
     for n in (1, 2, 14, 64, 193):
         for w in (1, 2, 3, 4, 8):
