@@ -33,14 +33,15 @@ DTYPES = {"bf16": torch.bfloat16, "f16": torch.float16, "f32": torch.float32}
 def pmc_traffic(kernel, batch, side, dtype):
     """HBM bytes per launch of `kernel` from the committed PMC passes (a separate rocprofv3 --pmc run cannot happen inside
     this process); null unless the passes were taken on exactly this workload."""
-    try:
-        rec = json.load(open(os.path.join(ROOT, "profiles", "r01", "hbm_traffic_pmc.json")))
-        c = rec["config"]
-        if (c["batch"], c["image_side"], c["dtype"]) == (batch, side, dtype):
-            return rec["kernels"][kernel]["hbm_bytes_per_launch"]
-    except (OSError, KeyError, ValueError):
-        pass
-    return None
+    for rnd in ("r02", "r01"):
+        try:
+            rec = json.load(open(os.path.join(ROOT, "profiles", rnd, "hbm_traffic_pmc.json")))
+            c = rec["config"]
+            if (c["batch"], c["image_side"], c["dtype"]) == (batch, side, dtype):
+                return rec["kernels"][kernel]["hbm_bytes_per_launch"], rnd
+        except (OSError, KeyError, ValueError):
+            pass
+    return None, None
 
 
 def usable_cores():
@@ -61,30 +62,110 @@ def usable_cores():
     return n
 
 
+def cpu_model_name():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown CPU"
+
+
 def cpu_baseline(cfg, sd, side, n_prompts, ids, mask):
-    """Oracle (CPU port of the reference path, oracle/radzero_oracle.py) timed on this host's cores on a bounded
-    sample: ONE image of the same workload, prompts encoded once, best of SDPA / eager attention."""
+    """Oracle (CPU port of the reference path, oracle/radzero_oracle.py) timed on this host's cores on a bounded sample of
+    the same workload: prompts encoded once, one warm-up pass, then the MEDIAN of 3 timed passes for each
+    attention implementation — SDPA (transformers-5 default) on 2 images, eager (the pinned transformers 4.39.3 is eager
+    only; it materialises the 12 x N x N scores) on 1 image.  `value` is the FASTER of the two (the denominator of any
+    speed-up claim); both are printed in `sample` with the CPU model and the thread count.  About 60 s."""
     from oracle.radzero_oracle import OracleModel      # baseline leg only; never on the product path
     from radzero_amd.synthetic import synthetic_pixels
     cores = usable_cores()
     torch.set_num_threads(cores)
-    nimg = 4                                      # bounded sample: ~10-20 s of CPU work on the box's 16-core share
-    px = torch.from_numpy(synthetic_pixels(nimg, side, 1234))
     enc = {"input_ids": torch.from_numpy(ids), "attention_mask": torch.from_numpy(mask)}
-    best = None
-    for impl in ("sdpa",):                        # faster than the eager path of the pinned transformers 4.39.3
+    res = {}
+    for impl, nimg in (("sdpa", 2), ("eager", 1)):
         om = OracleModel(sd, cfg, attn_impl=impl)
+        px = torch.from_numpy(synthetic_pixels(nimg, side, 1234))
         with torch.no_grad():
             tf = om.text_features(enc, split_rows=False)
-            om.compute_logits(torch.from_numpy(synthetic_pixels(1, 224, 1)), [enc], text_features=tf)   # warm-up (thread pool, allocator)
-            t0 = time.time()
-            om.compute_logits(px, [enc], text_features=tf)
-            dt = time.time() - t0
-        if best is None or dt < best[0]:
-            best = (dt, impl)
-    return {"value": round(nimg / best[0], 5), "unit": "images/s", "cores": cores, "kind": "port",
-            "sample": f"{nimg} images {side}x{side} x {n_prompts} cached prompts in one batch, fp32, torch CPU "
-                      f"({best[1]} attention), {cores} threads, {best[0]:.1f} s"}
+            om.compute_logits(px[:1, :, : side // 2, : side // 2], [enc], text_features=tf)   # warm-up (thread pool, allocator)
+            times = []
+            for _ in range(3):
+                t0 = time.time()
+                om.compute_logits(px, [enc], text_features=tf)
+                times.append(time.time() - t0)
+        med = sorted(times)[1]
+        res[impl] = (nimg / med, nimg, med)
+    best = max(res, key=lambda k: res[k][0])
+    desc = "; ".join(f"{k}: {v[0]:.4f} images/s (median of 3 x {v[1]} image(s), {v[2]:.1f} s per pass)" for k, v in res.items())
+    return {"value": round(res[best][0], 5), "unit": "images/s", "cores": cores, "kind": "port",
+            "sample": f"{side}x{side} x {n_prompts} cached prompts, fp32, torch CPU, {cores} threads on {cpu_model_name()}, "
+                      f"1 warm-up + median of 3 per attention path; {desc}; value = {best}"}
+
+
+def workload_label(B, S, T, dtype, maps, n_tok):
+    """Which BASELINE.json config a (batch, side, prompts, dtype, maps) tuple is — never a fixed string."""
+    if (B, S, T, dtype, maps) == (32, 1024, 14, "bf16", "none"):
+        tag = "BASELINE configs[1] (per-GPU shape of configs[2])"
+    elif (B, S, T, dtype) == (16, 1024, 64, "bf16") and maps != "none":
+        tag = "BASELINE configs[3] (grounding, per-pixel maps)" if maps == "upsample" else "BASELINE configs[3] variant (fused grounding points instead of maps)"
+    elif (S, T, dtype) == (1536, 193, "f16"):
+        tag = "BASELINE configs[4] per-GPU shape (8 images over 8 GPUs)" if B == 1 else f"BASELINE configs[4] shape at batch {B}/GPU"
+    elif (B, S, T, maps) == (32, 1024, 14, "none"):
+        tag = f"BASELINE configs[1] shape in {dtype} (configs[1] itself is bf16)"
+    else:
+        tag = "custom shape (not a BASELINE config)"
+    return (f"{tag}: batch={B}/GPU {S}x{S} synthetic CXR, {T} prompts, N={n_tok} tokens/image, 12 ViT + 2 align blocks, "
+            f"VL-CABS head; text embeddings cached; maps={maps}")
+
+
+def short_run(sd, cfg, device, dtype, B, S, T, maps, min_len, max_len, steps=3, warmup=1):
+    """A few steps of another BASELINE config inside the same process (rank 0, N=1 only), so that the driver's clock and
+    the JSON line cover it: same timed-region rules as the main workload."""
+    from radzero_amd.modeling import RadZeroModel
+    model = RadZeroModel.from_state_dict(sd, cfg, torch_dtype=DTYPES[dtype], device=device).eval()
+    try:
+        g = torch.Generator(device=device).manual_seed(4242)
+        px = torch.randn((B, 3, S, S), generator=g, device=device, dtype=torch.float32)
+        ids, mask = synthetic_prompts(T, min_len, max_len, 4321)
+        enc = {"input_ids": torch.from_numpy(ids).to(device), "attention_mask": torch.from_numpy(mask).to(device)}
+        tf = model.forward_text_model(enc)["text_features_wo_l2_norm"]
+
+        def step():
+            out = model.compute_logits(px, [enc], text_features=tf)
+            if maps == "upsample":
+                out["similarity_maps"] = model.upsample_similarity(out["similarity_scores"], (S, S))
+            elif maps == "points":
+                out["grounding_points"] = model.grounding_points(out["similarity_scores"], (S, S))
+            return out
+
+        for _ in range(warmup):
+            step()
+        torch.cuda.synchronize()
+        model.profile(True)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            out = step()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        prof = model.profile_read()
+        model.profile(False)
+        assert bool(torch.isfinite(out["logits"]).all())
+        ips = B * steps / dt
+        f_img = flops_per_image(cfg, S, T)
+        attn_ms = prof["attn"]["ms"] / max(1, prof["attn"]["launches"])
+        attn_tf = B * attention_flops_per_image_layer(cfg, S) / (attn_ms * 1e-3) / 1e12 if attn_ms > 0 else None
+        return {"workload": workload_label(B, S, T, dtype, maps, cfg.tokens(S)), "dtype": dtype, "steps": steps, "warmup": warmup,
+                "images_per_s": round(ips, 3), "similarity_maps_per_s": round(ips * T, 2), "ms_per_step": round(dt / steps * 1e3, 3),
+                "model_tflops_per_s": round(ips * f_img / 1e12, 2),
+                "frac_of_mfma_peak_whole_path": round(ips * f_img / 1e12 / PEAK_TFLOPS[dtype], 4),
+                "attention_tflops_per_s": None if attn_tf is None else round(attn_tf, 1),
+                "kernel_family_ms_per_step": {k: round(v["ms"] / steps, 3) for k, v in prof.items()}}
+    finally:
+        model.close()
+        del model
+        torch.cuda.empty_cache()
 
 
 def main():
@@ -103,6 +184,7 @@ def main():
     ap.add_argument("--force-dist", action="store_true", help="rehearsal: initialise the RCCL process group even with one rank")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true")
+    ap.add_argument("--no-other-configs", action="store_true", help="skip the short runs of BASELINE configs[3], configs[4] per-GPU shape and the fp32 mode")
     ap.add_argument("--attn-variant", type=int, default=None, help="A/B switch (rz_set_option): 1 = default 16x16x32 4 waves, 16 = same with VALU row sums, 8 = 8 waves, 64/264 = 64 query rows per wave, 2/3 = 32x32x16 kernel")
     ap.add_argument("--vision-chunk", type=int, default=None, help="images per internal pass of the vision encoder (0 = whole batch)")
     ap.add_argument("--mlp-chunk", type=int, default=None, help="images per fc1->fc2 pass (-1 = auto, 0 = whole batch)")
@@ -110,6 +192,10 @@ def main():
     ap.add_argument("--gemm-variant", type=int, default=None, help="A/B switch: 0 auto, 1..4 force a GEMM tile variant")
     args = ap.parse_args()
 
+    # HSA reads its environment at hsa_init, i.e. at the first torch.cuda call below: set these before anything touches the GPU
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29511")
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -120,9 +206,6 @@ def main():
     device = torch.device("cuda", local_rank)
     use_dist = world > 1 or args.force_dist
     if use_dist:
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29511")
         dist.init_process_group(backend="nccl", device_id=device, rank=rank, world_size=world)
 
     from radzero_amd.modeling import RadZeroModel
@@ -197,12 +280,11 @@ def main():
         ips = total_images / elapsed
         f_img = flops_per_image(cfg, S, T)
         res = {
-            "metric": "images/sec, zero-shot classification (vision encoder + VL-CABS), 1024x1024 CXR x 14 prompts",
+            "metric": f"images/sec, zero-shot classification (vision encoder + VL-CABS), {S}x{S} CXR x {T} prompts",
             "value": round(ips, 3), "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": f"BASELINE configs[1]: batch={B}/GPU {S}x{S} synthetic CXR, {T} prompts, "
-                                   f"N={n_tok} tokens/image, 12 ViT + 2 align blocks, VL-CABS head; text embeddings cached",
+            "config": {"workload": workload_label(B, S, T, args.dtype, args.maps, n_tok),
                        "global_batch": world * B, "image_side": S, "n_prompts": T, "parallelism": f"dp{world}",
                        "map_postprocessing": args.maps},
             "similarity_maps_per_s": round(ips * T, 2),
@@ -218,14 +300,27 @@ def main():
             # (robust to --vision-chunk: total attention FLOPs of the timed region / number of launches)
             flops_launch = args.steps * cfg.num_blocks * B * attention_flops_per_image_layer(cfg, S) / launches
             achieved = flops_launch / (avg_ms * 1e-3) / 1e12
+            traffic, traffic_rnd = pmc_traffic("flash_attn_kernel", B, S, args.dtype)
             res["roofline"] = {"kernel": "flash_attn_kernel", "bound": "mfma", "achieved": round(achieved, 2),
                                "peak": PEAK_TFLOPS[args.dtype], "unit": "TFLOP/s",
                                "frac": round(achieved / PEAK_TFLOPS[args.dtype], 4),
-                               "traffic": pmc_traffic("flash_attn_kernel", B, S, args.dtype),
-                               "traffic_unit": "HBM bytes per launch (rocprofv3 PMC: 2*FETCH_SIZE + WRITE_SIZE, KiB -> B; profiles/r01/hbm_traffic_pmc.json)",
+                               "traffic": traffic,
+                               "traffic_unit": "HBM bytes per launch; RECORDED by separate rocprofv3 --pmc passes of this command "
+                                               f"(2*FETCH_SIZE + WRITE_SIZE, KiB -> B; profiles/{traffic_rnd}/hbm_traffic_pmc.json), not measured in this run",
                                "algorithmic_bytes": int(B * cfg.tokens(S) * 768 * 2 * 4),
                                "avg_launch_ms": round(avg_ms, 4), "launches": launches}
             res["kernel_family_ms_per_step"] = {k: round(v["ms"] / args.steps, 3) for k, v in prof.items()}
+        if world == 1 and not args.no_other_configs:
+            # the other single-GPU BASELINE configs + the 1e-3-compliant fp32 mode, a few steps each (not bench lines of
+            # their own: the driver times the whole process; parity for these shapes is in tests/test_gpu_fullsize.py)
+            del pixels, out
+            model.close()
+            torch.cuda.empty_cache()
+            res["other_configs"] = [
+                short_run(sd, cfg, device, "bf16", 16, 1024, 64, "upsample", 8, 32),
+                short_run(sd, cfg, device, "f16", 1, 1536, 193, "none", 6, 16),
+                short_run(sd, cfg, device, "f32", 32, 1024, 14, "none", 6, 10, steps=2),
+            ]
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(cfg, sd, S, T, ids, mask)
         print(json.dumps(res), flush=True)

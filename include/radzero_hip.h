@@ -145,6 +145,12 @@ int rz_gemm(int dtype, int epilogue, const void* a_dev, const void* w_dev, const
 int rz_gemm_ex(int dtype, int epilogue, const void* a_dev, int64_t lda, const void* w_dev, int64_t ldw, const float* bias_dev,
                void* out_dev, int64_t ldo, const float* scale_dev, float* resid_dev, int64_t ldr, int rows_per_image,
                int heads_total, int m, int n, int k, void* stream);
+/* The block's q|k|v projection as the model launches it (TF:dinov2/modeling_dinov2.py:199-213; replaces three nn.Linear):
+ * x[M,K] times w_qkv[3K,K]^T (rows q | k | v) + bias[3K]  ->  qk_out (B, 2*heads, rows_per_image, 64) and
+ * v_t_out (B, heads, 64, rows_per_image), K = heads*64.  ONE launch where the persistent 256x256 kernel applies
+ * (16-bit dtype, M % 256 == 0, enough tiles), otherwise the q|k and v launches; *fused_out (may be NULL) reports which. */
+int rz_gemm_qkv(int dtype, const void* x_dev, const void* w_qkv_dev, const float* bias_dev, void* qk_out_dev, void* v_t_out_dev,
+                int rows_per_image, int heads, int m, int* fused_out, void* stream);
 /* LayerNorm rows of `dim` (=768) fp32 -> out_t_dev (dtype, may be NULL) and/or out_f32_dev (may alias in) */
 int rz_layernorm(int dtype, const float* in_dev, const float* gamma_dev, const float* beta_dev, float eps, void* out_t_dev,
                  float* out_f32_dev, int64_t rows, int dim, void* stream);
@@ -155,6 +161,7 @@ int rz_flash_attention(int dtype, const void* q_dev, const void* k_dev, const vo
 
 /* process-wide tuning / A-B switches (measurement only; defaults are the measured-fastest choices, 0 restores them):
  *   "gemm_variant"     0 auto | 1 128x128 two-stage | 3 256x256 two-stage | 7 256x256 staggered 8-phase (16-bit, gemm7.hip)
+ *                      | 8 the same K loop as a persistent kernel, one workgroup per CU (16-bit, gemm8.hip; default for big shapes)
  *                      | 9 = 7 with in-kernel s_memtime stamps (EPI_STORE only; stamps land in the `resid_dev` buffer)
  *   "gemm_v1_only"     1 = same as gemm_variant 1
  *   "gemm_debug_flags" bit 2 skip the epilogue, bit 3 per-wave fp32 LDS epilogue, bit 4 direct epilogue, bit 6 skip the K loop

@@ -91,7 +91,7 @@ struct Tensor {          // one packed checkpoint tensor on the device
 };
 
 struct DinoBlock {       // TF:dinov2/modeling_dinov2.py:342-380
-    Tensor ln1_g, ln1_b, wqk, bqk, wv, bv, wo, bo, ls1, ln2_g, ln2_b, w1, b1, w2, b2, ls2;
+    Tensor ln1_g, ln1_b, wqkv, bqkv, wo, bo, ls1, ln2_g, ln2_b, w1, b1, w2, b2, ls2;   // wqkv: [3D][D] rows q | k | v
     int qkv_parts = 0;   // bit mask of loaded q/k/v weight (1,2,4) and bias (8,16,32) pieces
 };
 struct TextLayer {       // TF:mpnet/modeling_mpnet.py:234-261
@@ -239,16 +239,14 @@ int load_dino_block(rz_model* m, DinoBlock& b, const char* rest, const float* da
         snprintf(bn, sizeof bn, "attention.attention.%s.bias", names[i]);
         if (!strcmp(rest, wn)) {
             if ((size_t)numel != D * D) return fail(RZ_ERR_INVALID, "bad numel for qkv weight");
-            int rc = (i < 2) ? put_rows(m, b.wqk, 2 * D, D, i * D, data, D, i == 0 ? qscale : 1.f, true)
-                             : put_rows(m, b.wv, D, D, 0, data, D, 1.f, true);
+            int rc = put_rows(m, b.wqkv, 3 * D, D, i * D, data, D, i == 0 ? qscale : 1.f, true);
             if (rc) return rc;
             b.qkv_parts |= (1 << i);
             return 0;
         }
         if (!strcmp(rest, bn)) {
             if ((size_t)numel != D) return fail(RZ_ERR_INVALID, "bad numel for qkv bias");
-            int rc = (i < 2) ? put_rows(m, b.bqk, 2, D, i, data, 1, i == 0 ? qscale : 1.f, false)
-                             : put_rows(m, b.bv, 1, D, 0, data, 1, 1.f, false);
+            int rc = put_rows(m, b.bqkv, 3, D, i, data, 1, i == 0 ? qscale : 1.f, false);
             if (rc) return rc;
             b.qkv_parts |= (8 << i);
             return 0;
@@ -313,6 +311,23 @@ int gemm(rz_model* m, int epi, const void* A, int64_t lda, const void* W, int64_
     ProfScope ps(m, RZ_PROF_GEMM, s);
     RZ_HIP(launch_gemm(m->dt, epi, g, s));
     return 0;
+}
+
+int gemm_qkv(rz_model* m, const void* xn, const DinoBlock& b, int M, int np, void* qk, void* vt, hipStream_t s) {
+    const int D = m->D, H = m->H;
+    GemmArgs g;
+    g.A = xn; g.lda = D; g.W = b.wqkv.p; g.ldw = D; g.M = M; g.N = 3 * D; g.K = D; g.bias = (const float*)b.bqkv.p;
+    g.out = qk; g.ldo = 0; g.scale = nullptr; g.resid = nullptr; g.ldr = 0; g.rows_per_image = np; g.heads_total = 2 * H;
+    g.out2 = vt; g.heads_total2 = H; g.split_n = 2 * D; g.debug_flags = 0;
+    if (gemm_qkv_fused_ok(m->dt, g)) {
+        ProfScope ps(m, RZ_PROF_GEMM, s);
+        RZ_HIP(launch_gemm(m->dt, EPI_QKV, g, s));
+        return 0;
+    }
+    const char* wv = (const char*)b.wqkv.p + (size_t)2 * D * D * dsize(m->dt);
+    int rc;
+    if ((rc = gemm(m, EPI_HEADS, xn, D, b.wqkv.p, D, M, 2 * D, D, (const float*)b.bqkv.p, qk, 0, nullptr, nullptr, 0, np, 2 * H, s))) return rc;
+    return gemm(m, EPI_VT, xn, D, wv, D, M, D, D, (const float*)b.bqkv.p + 2 * D, vt, 0, nullptr, nullptr, 0, np, H, s);
 }
 
 }  // namespace
@@ -560,8 +575,9 @@ int rz_vision_forward(rz_handle_t m, const float* px, int B, int C, int Himg, in
                 ProfScope ps(m, RZ_PROF_ROWOPS, s);
                 RZ_HIP(launch_layernorm(m->dt, h, (const float*)b.ln1_g.p, (const float*)b.ln1_b.p, eps, xn, nullptr, M, D, s));
             }
-            if ((rc = gemm(m, EPI_HEADS, xn, D, b.wqk.p, D, M, 2 * D, D, (const float*)b.bqk.p, qkb, 0, nullptr, nullptr, 0, np, 2 * H, s))) return rc;
-            if ((rc = gemm(m, EPI_VT, xn, D, b.wv.p, D, M, D, D, (const float*)b.bv.p, vtb, 0, nullptr, nullptr, 0, np, H, s))) return rc;
+            // q | k | v projection (TF:dinov2/modeling_dinov2.py:199-213): ONE launch over N = 3D where the persistent kernel
+            // applies (q, k -> per-head rows, v -> transposed, chosen per 256-column tile), else q|k and v separately
+            if ((rc = gemm_qkv(m, xn, b, M, np, qkb, vtb, s))) return rc;
             {
                 ProfScope ps(m, RZ_PROF_ATTN, s);
                 // q heads are heads [0,H) and k heads [H,2H) of the [B][2H][np][64] tensor
@@ -770,6 +786,30 @@ int rz_gemm_ex(int dtype, int epilogue, const void* a, int64_t lda, const void* 
     g.A = a; g.lda = lda; g.W = w; g.ldw = ldw; g.M = M; g.N = N; g.K = K; g.bias = bias; g.out = out; g.ldo = ldo;
     g.scale = scale; g.resid = resid; g.ldr = ldr; g.rows_per_image = rows_per_image > 0 ? rows_per_image : M; g.heads_total = heads_total;
     RZ_HIP(launch_gemm(dtype, epilogue, g, (hipStream_t)stream));
+    return 0;
+}
+
+int rz_gemm_qkv(int dtype, const void* x, const void* w, const float* bias, void* qk, void* vt, int rows_per_image, int heads, int M,
+                int* fused_out, void* stream) {
+    if (!x || !w || !qk || !vt) return fail(RZ_ERR_INVALID, "rz_gemm_qkv: null argument");
+    if (dtype < 0 || dtype > 2 || heads <= 0 || M <= 0 || M % 128 || rows_per_image <= 0 || rows_per_image % 128 || M % rows_per_image)
+        return fail(RZ_ERR_INVALID, "rz_gemm_qkv: M and rows_per_image must be multiples of 128, rows_per_image dividing M");
+    const int D = heads * 64;
+    GemmArgs g;
+    g.A = x; g.lda = D; g.W = w; g.ldw = D; g.M = M; g.N = 3 * D; g.K = D; g.bias = bias; g.out = qk; g.ldo = 0;
+    g.scale = nullptr; g.resid = nullptr; g.ldr = 0; g.rows_per_image = rows_per_image; g.heads_total = 2 * heads;
+    g.out2 = vt; g.heads_total2 = heads; g.split_n = 2 * D; g.debug_flags = 0;
+    const bool fused = gemm_qkv_fused_ok(dtype, g);
+    if (fused_out) *fused_out = fused ? 1 : 0;
+    if (fused) {
+        RZ_HIP(launch_gemm(dtype, EPI_QKV, g, (hipStream_t)stream));
+        return 0;
+    }
+    GemmArgs a = g;
+    a.N = 2 * D; a.out2 = nullptr; a.split_n = 0;
+    RZ_HIP(launch_gemm(dtype, EPI_HEADS, a, (hipStream_t)stream));
+    a.N = D; a.W = (const char*)w + (size_t)2 * D * D * dsize(dtype); a.bias = bias ? bias + 2 * D : nullptr; a.out = vt; a.heads_total = heads;
+    RZ_HIP(launch_gemm(dtype, EPI_VT, a, (hipStream_t)stream));
     return 0;
 }
 

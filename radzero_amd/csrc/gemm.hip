@@ -203,19 +203,36 @@ static int g_variant = 0;      // 0 = auto, 1/2/3 = force that kernel where its 
 void gemm_force_v1(bool on) { g_variant = on ? 1 : 0; }
 void gemm_set_variant(int v) { g_variant = v; }
 
+// big tiles pay off once their rounds over the 256 CUs are >= 55 % full (measured, bench.py --batch 1..7:
+// 126 tiles -> 128x128 kernel 6 % faster; 189 tiles -> 256x256 kernel 7 % faster; 315 tiles -> 1 % faster)
+static bool big_tiles_pay(const GemmArgs& g) {
+    if (g.M % BM2 || g.M < 4 * BM2 || g.N % BN3) return false;
+    const int64_t t256 = (int64_t)(g.M / BM2) * (g.N / BN3);
+    return t256 >= 128 && (double)t256 / (double)(((t256 + 255) / 256) * 256) >= 0.55;
+}
+
+// The merged q|k|v projection (EPI_QKV) exists only in the persistent kernel: callers ask first and fall back to the
+// separate EPI_HEADS + EPI_VT launches (fp32 mode, small batches, forced variants).
+bool gemm_qkv_fused_ok(int dtype, const GemmArgs& g) {
+    return (g_variant == 0 || g_variant == 8) && gemm_v8_ok(dtype, EPI_QKV, g) && (g_variant == 8 || big_tiles_pay(g));
+}
+
 template <typename T>
 static hipError_t launch_gemm_t(int epi, const GemmArgs& g, hipStream_t s) {
     const bool ok3 = (g.M % BM2 == 0) && (g.M >= 4 * BM2) && (g.N % BN3 == 0);
     int variant = g_variant;
     // measured on MI355X (tools/kbench.py, ms per layer of 8 images): v1 0.975, v3 0.825-0.867, v7 0.745-0.755; with fewer
     // than ~200 big tiles (single-image calls) the 128x128 kernel fills the 256 CUs better.
-    // v7 (gemm7.hip, 16-bit only): K loop 1.40 us per 256x256x64 step against 1.68 for v3 (tools/kslope.py)
+    // v7 (gemm7.hip, 16-bit only): K loop 1.40 us per 256x256x64 step against 1.68 for v3 (tools/kslope.py);
+    // v8 (gemm8.hip): the same loop, persistent, operand stream continuous across output tiles.
     if (variant == 0) {
-        // big tiles pay off once their rounds over the 256 CUs are >= 55 % full (measured, bench.py --batch 1..7:
-        // 126 tiles -> 128x128 kernel 6 % faster; 189 tiles -> 256x256 kernel 7 % faster; 315 tiles -> 1 % faster)
-        const int64_t t256 = (int64_t)(g.M / BM2) * (g.N / BN3);
-        const bool big = ok3 && t256 >= 128 && (double)t256 / (double)(((t256 + 255) / 256) * 256) >= 0.55;
-        variant = !big ? 1 : gemm_v7_ok(Traits<T>::kDType, g) ? 7 : 3;
+        const bool big = big_tiles_pay(g);
+        variant = !big ? 1 : gemm_v8_ok(Traits<T>::kDType, epi, g) ? 8 : gemm_v7_ok(Traits<T>::kDType, g) ? 7 : 3;
+    }
+    if (epi == EPI_QKV && variant != 8) return hipErrorInvalidValue;
+    if (variant == 8) {
+        if (gemm_v8_ok(Traits<T>::kDType, epi, g)) return launch_gemm_v8(Traits<T>::kDType, epi, g, s);
+        variant = 7;
     }
     if (variant == 7 || variant == 9) {
         if (gemm_v7_ok(Traits<T>::kDType, g)) return launch_gemm_v7(variant, Traits<T>::kDType, epi, g, s);

@@ -14,6 +14,7 @@ enum Epilogue : int {
     EPI_RESID_ADD = 5,    // out_f32[m][n] = acc + bias + resid[m][n]        (post-LN blocks)
     EPI_PATCH = 6,        // out_f32[m][n] = acc + scale[tok][n]             (patch-embed: pos/cls/bias table)
     EPI_STORE_F32 = 7,    // out_f32[m][n] = acc + bias
+    EPI_QKV = 8,          // merged q|k|v projection: columns < split_n as EPI_HEADS into `out`, the rest as EPI_VT into `out2` (gemm8.hip)
 };
 
 struct GemmArgs {
@@ -26,6 +27,9 @@ struct GemmArgs {
     float* resid; int64_t ldr;    // fp32 residual stream
     int rows_per_image;           // padded tokens per image (EPI_HEADS / EPI_VT / EPI_PATCH)
     int heads_total;              // heads in the destination tensor (EPI_HEADS / EPI_VT)
+    void* out2 = nullptr;         // EPI_QKV: transposed-v destination
+    int heads_total2 = 0;         // EPI_QKV: heads in `out2`
+    int split_n = 0;              // EPI_QKV: first column of the v block (multiple of 256)
     int debug_flags;              // measurement only: bit0 skip MFMA/ds_read body, bit1 skip W staging, bit2 skip epilogue,
                                   // bit3 force the LDS-staged full-line epilogue, bit4 force the direct epilogue (256x256 kernels)
 };
@@ -33,8 +37,11 @@ struct GemmArgs {
 hipError_t launch_gemm(int dtype, int epi, const GemmArgs& g, hipStream_t s);
 void gemm_force_v1(bool on);   // A/B switch: use only the 128x128 two-stage kernel
 void gemm_set_debug_flags(int f);
-void gemm_set_variant(int v);  // 0 auto, 1 = 128x128 two-stage, 3 = 256x256 two-stage, 7 = 256x256 staggered 8-phase (gemm7.hip), 9 = 7 + in-kernel stamps
+void gemm_set_variant(int v);  // 0 auto, 1 = 128x128 two-stage, 3 = 256x256 two-stage, 7 = 256x256 staggered 8-phase (gemm7.hip), 8 = persistent (gemm8.hip), 9 = 7 + in-kernel stamps
 bool gemm_v7_ok(int dtype, const GemmArgs& g);
+bool gemm_v8_ok(int dtype, int epi, const GemmArgs& g);
+bool gemm_qkv_fused_ok(int dtype, const GemmArgs& g);   // may EPI_QKV be launched for this shape (else: EPI_HEADS + EPI_VT)
+hipError_t launch_gemm_v8(int dtype, int epi, const GemmArgs& g, hipStream_t s);   // persistent 256x256 kernel (gemm8.hip)
 hipError_t launch_gemm_v7(int variant, int dtype, int epi, const GemmArgs& g, hipStream_t s);
 
 // Flash attention over per-head tensors: q,k [B][H][Npad][64], vT [B][H][64][Npad] -> ctx [B*Npad][H*64].

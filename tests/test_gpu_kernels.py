@@ -157,7 +157,7 @@ def test_upsample(lib, g, size):
     assert (out_s.cpu() - torch.sigmoid(ref)).abs().max().item() <= 1e-5
 
 
-@pytest.mark.parametrize("variant", [1, 3, 7])
+@pytest.mark.parametrize("variant", [1, 3, 7, 8])
 @pytest.mark.parametrize("dt", ["f32", "bf16", "f16"])
 def test_gemm_variants_agree(lib, variant, dt):
     """All tile variants (128x128 two-stage, 256x256 two-stage, 256x256 staggered 8-phase) against the fp32 reference,
@@ -185,31 +185,38 @@ def test_gemm_variants_agree(lib, variant, dt):
     assert (resid - (resid0 + scale * ref)).abs().max().item() <= 2e-4 * math.sqrt(K / 64)
 
 
-@pytest.mark.parametrize("variant", [7])
-@pytest.mark.parametrize("K", [128, 192, 256, 768, 3072])
+@pytest.mark.parametrize("variant", [7, 8])
+@pytest.mark.parametrize("K", [128, 192, 256, 640, 768, 3072])
 @pytest.mark.parametrize("dt", ["bf16", "f16"])
-def test_gemm_pipelined_variants_bitwise(lib, variant, K, dt):
-    """The deep-pipelined 256x256 kernels (gemm7.hip: counted vmcnt, raw barriers, staggered wave groups) accumulate
+@pytest.mark.parametrize("M", [4096, 33792])
+def test_gemm_pipelined_variants_bitwise(lib, variant, K, dt, M):
+    """The deep-pipelined 256x256 kernels (gemm7.hip: counted vmcnt, raw barriers, staggered wave groups; gemm8.hip: the
+    same loop run persistently, operand stream continuous across output tiles, wave-private epilogues) accumulate
     every output element over K in the same order with the same MFMA as the 256x256 two-stage kernel, so the results
     must be IDENTICAL bit for bit: any LDS-DMA race (a fragment read before its piece landed, a stage overwritten
     before it was read) shows up as a difference.  K = 128 / 192 exercise the tail-only and one-iteration loops;
-    several tiles per CU queue behind each other at M = 4096."""
+    several tiles per CU queue behind each other at M = 4096; M = 33792 gives 396 tiles: the persistent kernel's workgroups
+    take one or two tiles each (tile seams with every epilogue, uneven tile lists per XCD)."""
     code, tdt = DT[dt]
-    M, N = 4096, 768
+    N = 768
+    if M > 4096 and (dt == "f16" or K in (128, 192)):
+        pytest.skip("large-M leg: bf16 and the K values the persistent kernel accepts")
     g = torch.Generator(device="cpu").manual_seed(K + variant)
     a = (torch.randn(M, K, generator=g) * 0.7).to(tdt).cuda()
     w = (torch.randn(N, K, generator=g) / math.sqrt(K)).to(tdt).cuda()
     bias = torch.randn(N, generator=g).cuda()
+    scale = torch.rand(N, generator=g).cuda()
     outs = {}
     for v in (3, variant):
         check(lib, lib.rz_set_option(b"gemm_variant", v))
         try:
             res = []
-            for epi in (0, 1, 2, 3, 7):             # store, GELU, per-head q|k, transposed v, fp32 store
-                out = torch.zeros(M, N, dtype=torch.float32 if epi == 7 else tdt, device="cuda")
+            for epi in (0, 1, 2, 3, 7, 4, 5):       # store, GELU, per-head q|k, transposed v, fp32 store, LayerScale+residual, residual add
+                out = torch.zeros(M, N, dtype=torch.float32 if epi in (7, 5) else tdt, device="cuda")
+                resid = torch.full((M, N), 0.25, device="cuda")
                 for _ in range(3):                  # back-to-back launches: tiles of consecutive kernels overlap on the chip
-                    check(lib, lib.rz_gemm_ex(code, epi, P(a), K, P(w), K, P(bias), P(out), N, None, None, 0, 256, N // 64, M, N, K, stream()))
-                res.append(out)
+                    check(lib, lib.rz_gemm_ex(code, epi, P(a), K, P(w), K, P(bias), P(out), N, P(scale), P(resid), N, 256, N // 64, M, N, K, stream()))
+                res.append(resid if epi == 4 else out)
             torch.cuda.synchronize()
             outs[v] = res
         finally:
@@ -232,12 +239,52 @@ def test_gemm_staggered_race_screen_full_size(lib, shape):
     check(lib, lib.rz_set_option(b"gemm_variant", 3))
     try:
         check(lib, lib.rz_gemm_ex(1, 0, P(a), K, P(w), K, P(bias), P(ref), N, None, None, 0, M, N // 64, M, N, K, stream()))
-        check(lib, lib.rz_set_option(b"gemm_variant", 7))
-        outs = [torch.zeros_like(ref) for _ in range(10)]
-        for o in outs:
-            check(lib, lib.rz_gemm_ex(1, 0, P(a), K, P(w), K, P(bias), P(o), N, None, None, 0, M, N // 64, M, N, K, stream()))
+        outs = []
+        for variant in (7, 8):
+            check(lib, lib.rz_set_option(b"gemm_variant", variant))
+            these = [torch.zeros_like(ref) for _ in range(10)]
+            for o in these:
+                check(lib, lib.rz_gemm_ex(1, 0, P(a), K, P(w), K, P(bias), P(o), N, None, None, 0, M, N // 64, M, N, K, stream()))
+            outs += these
         torch.cuda.synchronize()
     finally:
         lib.rz_set_option(b"gemm_variant", 0)
     for o in outs:
         assert torch.equal(o, ref)
+
+
+@pytest.mark.parametrize("dt", ["bf16", "f16", "f32"])
+@pytest.mark.parametrize("images,rows", [(8, 5376), (3, 1408), (1, 384)])
+def test_gemm_qkv_fused_matches_separate_launches(lib, dt, images, rows):
+    """The block's q|k|v projection: ONE launch of the persistent kernel over N = 3D (columns < 2D in the per-head q|k
+    layout, the rest transposed) must equal the two separate launches bit for bit (same MFMA order over K), and both must
+    match the fp32 reference.  Small batches / fp32 take the two-launch path inside the same entry point."""
+    code, tdt = DT[dt]
+    H, D = 12, 768
+    M = images * rows
+    g = torch.Generator(device="cpu").manual_seed(images * 31 + rows)
+    x = (torch.randn(M, D, generator=g) * 0.8).to(tdt).cuda()
+    w = (torch.randn(3 * D, D, generator=g) / math.sqrt(D)).to(tdt).cuda()
+    bias = torch.randn(3 * D, generator=g).cuda()
+    qk = torch.zeros(images, 2 * H, rows, 64, dtype=tdt, device="cuda")
+    vt = torch.zeros(images, H, 64, rows, dtype=tdt, device="cuda")
+    fused = ctypes.c_int(-1)
+    for _ in range(3):
+        check(lib, lib.rz_gemm_qkv(code, P(x), P(w), P(bias), P(qk), P(vt), rows, H, M, ctypes.byref(fused), stream()))
+    torch.cuda.synchronize()
+    assert fused.value == (1 if (dt != "f32" and images == 8) else 0)
+    ref = x.float() @ w.float().t() + bias                                         # (M, 3D)
+    ref_qk = ref[:, : 2 * D].view(images, rows, 2 * H, 64).permute(0, 2, 1, 3)
+    ref_vt = ref[:, 2 * D:].view(images, rows, H, 64).permute(0, 2, 3, 1)
+    tol = {"f32": 1e-4, "bf16": 2.5e-2, "f16": 3e-3}[dt]
+    assert (qk.float() - ref_qk).abs().max().item() <= tol and (vt.float() - ref_vt).abs().max().item() <= tol
+    if fused.value:
+        qk2, vt2 = torch.zeros_like(qk), torch.zeros_like(vt)
+        check(lib, lib.rz_set_option(b"gemm_variant", 7))
+        try:
+            f2 = ctypes.c_int(-1)
+            check(lib, lib.rz_gemm_qkv(code, P(x), P(w), P(bias), P(qk2), P(vt2), rows, H, M, ctypes.byref(f2), stream()))
+            torch.cuda.synchronize()
+        finally:
+            lib.rz_set_option(b"gemm_variant", 0)
+        assert f2.value == 0 and torch.equal(qk, qk2) and torch.equal(vt, vt2)

@@ -70,6 +70,57 @@ def bench_gemm(images, n=5330, dt=1):
     print(f"gemm per-layer total {tot:.3f} ms for {images} images")
 
 
+def bench_gemm_ab(images, n=5330, dt=1, variants=(7, 8), rounds=3):
+    """A/B of GEMM kernels in ONE process, interleaved rounds (same tensors, same clocks): per shape the median ms of
+    each variant, plus the block's q|k|v projection as one fused launch (variant 8) against the two separate ones."""
+    npad = (n + 127) // 128 * 128
+    M = images * npad
+    tdt = {0: torch.float32, 1: torch.bfloat16, 2: torch.float16}[dt]
+    shapes = [("qk    EPI_HEADS", 2, 1536, 768), ("v     EPI_VT", 3, 768, 768), ("out   EPI_RESID_SCALE", 4, 768, 768),
+              ("fc1   EPI_GELU", 1, 3072, 768), ("fc2   EPI_RESID_SCALE", 4, 768, 3072), ("patch EPI_PATCH", 6, 768, 640)]
+    tot = {v: 0.0 for v in variants}
+    for name, epi, N, K in shapes:
+        a = torch.randn(M, K, device="cuda").to(tdt)
+        w = (torch.randn(N, K, device="cuda") / math.sqrt(K)).to(tdt)
+        bias = torch.randn(N, device="cuda")
+        scale = torch.rand(npad, N, device="cuda") if epi == 6 else torch.rand(N, device="cuda")
+        resid = torch.randn(M, N, device="cuda") if epi == 4 else None
+        out = torch.empty(M, N, device="cuda", dtype=torch.float32 if epi == 6 else tdt)
+        f = lambda: lib.rz_gemm_ex(dt, epi, P(a), K, P(w), K, None if epi == 6 else P(bias), P(out), N, P(scale), P(resid), N, npad, N // 64, M, N, K, ST())
+        ms = {v: [] for v in variants}
+        for _ in range(rounds):
+            for v in variants:
+                lib.rz_set_option(b"gemm_variant", v)
+                assert f() == 0, lib.rz_last_error()
+                ms[v].append(timeit(f, iters=8, warm=2))
+        lib.rz_set_option(b"gemm_variant", 0)
+        line = f"gemm {name:24s} M={M} N={N} K={K}:"
+        for v in variants:
+            med = sorted(ms[v])[len(ms[v]) // 2]
+            if "patch" not in name:
+                tot[v] += med
+            line += f"  v{v} {med:.3f} ms {2.0 * M * N * K / med / 1e9:7.1f} TF"
+        print(line, flush=True)
+    print("gemm per-layer total (qk + v + out + fc1 + fc2): " + "  ".join(f"v{v} {tot[v]:.3f} ms" for v in variants) + f"  for {images} images")
+    x = torch.randn(M, 768, device="cuda").to(tdt)
+    w = (torch.randn(2304, 768, device="cuda") / math.sqrt(768)).to(tdt)
+    bias = torch.randn(2304, device="cuda")
+    qk = torch.empty(images, 24, npad, 64, device="cuda", dtype=tdt)
+    vt = torch.empty(images, 12, 64, npad, device="cuda", dtype=tdt)
+    fused = ctypes.c_int(0)
+    f = lambda: lib.rz_gemm_qkv(dt, P(x), P(w), P(bias), P(qk), P(vt), npad, 12, M, ctypes.byref(fused), ST())
+    res = {}
+    for _ in range(rounds):
+        for v in (0,) + tuple(variants):
+            lib.rz_set_option(b"gemm_variant", v)
+            assert f() == 0, lib.rz_last_error()
+            res.setdefault((v, fused.value), []).append(timeit(f, iters=8, warm=2))
+    lib.rz_set_option(b"gemm_variant", 0)
+    for (v, fu), t in res.items():
+        med = sorted(t)[len(t) // 2]
+        print(f"qkv projection variant {v} ({'ONE fused launch' if fu else 'q|k + v launches'}): {med:.3f} ms {2.0 * M * 2304 * 768 / med / 1e9:7.1f} TF")
+
+
 def bench_library(images, n=5330, dt=1):
     """Calibration only (never on the product path): the vendor libraries at the same shapes -- hipBLASLt through
     F.linear (bias fused, no other epilogue) and torch SDPA (its flash backend) on the padded token count."""
@@ -122,5 +173,7 @@ if __name__ == "__main__":
         bench_attn(a.images, dt=a.dtype, zeros=a.zeros)
     if a.what in ("gemm", "all"):
         bench_gemm(a.images, dt=a.dtype)
+    if a.what == "gemmab":
+        bench_gemm_ab(a.images, dt=a.dtype)
     if a.what == "library":
         bench_library(a.images, dt=a.dtype)
