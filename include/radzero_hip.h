@@ -171,6 +171,9 @@ int rz_flash_attention(int dtype, const void* q_dev, const void* k_dev, const vo
  *   "vision_streams"   2 = two halves of the batch on two internal streams
  *   "mlp_chunk"        images per fc1->fc2 pass (0 = whole batch, -1 = ~126 MiB of hidden activations) */
 int rz_set_option(const char* name, int value);
+/* diagnostic builds only (tools/kstamp8.py): "gemm_v8_stamps" = device buffer of 256 x 8 x 32 uint64 that the stamped build of
+ * the persistent GEMM fills with per-wave K-loop / epilogue times (100 MHz ticks); NULL switches the stamped build off again */
+int rz_debug_buffer(const char* what, void* dev_ptr);
 
 /* ---- measurement: HIP-event timing of kernel families on the launch stream ---- */
 enum rz_prof_family { RZ_PROF_ATTN = 0, RZ_PROF_GEMM = 1, RZ_PROF_ROWOPS = 2, RZ_PROF_VLCABS = 3, RZ_PROF_NFAM = 4 };

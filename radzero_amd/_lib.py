@@ -126,6 +126,7 @@ SYMBOLS = {
     "rz_layernorm": (_I, [_I, _P, _P, _P, _F, _P, _P, _L, _I, _P]),
     "rz_flash_attention": (_I, [_I, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "rz_set_option": (_I, [ctypes.c_char_p, _I]),
+    "rz_debug_buffer": (_I, [ctypes.c_char_p, _P]),
     "rz_profile_enable": (_I, [_P, _I]),
     "rz_profile_read": (_I, [_P, _P, _P]),
 }

@@ -829,11 +829,18 @@ int rz_flash_attention(int dtype, const void* q, const void* k, const void* vt, 
     return 0;
 }
 
+int rz_debug_buffer(const char* what, void* dev_ptr) {
+    if (!what) return fail(RZ_ERR_INVALID, "rz_debug_buffer: null name");
+    if (!strcmp(what, "gemm_v8_stamps")) { gemm_v8_set_stamp_buffer(dev_ptr); return 0; }
+    return fail(RZ_ERR_INVALID, std::string("rz_debug_buffer: unknown buffer ") + what);
+}
+
 int rz_set_option(const char* name, int value) {
     if (!name) return fail(RZ_ERR_INVALID, "rz_set_option: null name");
     if (!strcmp(name, "gemm_v1_only")) { gemm_force_v1(value != 0); return 0; }
     if (!strcmp(name, "gemm_variant")) { gemm_set_variant(value); return 0; }
     if (!strcmp(name, "gemm_debug_flags")) { gemm_set_debug_flags(value); return 0; }
+    if (!strcmp(name, "gemm_skew")) { gemm_set_skew(value); return 0; }
     if (!strcmp(name, "vision_chunk")) { g_vision_chunk = value; return 0; }
     if (!strcmp(name, "vision_streams")) { g_vision_streams = value; return 0; }
     if (!strcmp(name, "mlp_chunk")) { g_mlp_chunk = value; return 0; }

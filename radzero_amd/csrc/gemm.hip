@@ -199,6 +199,8 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel_v3(GemmArgs g) {
 
 static int g_debug_flags = 0;
 void gemm_set_debug_flags(int f) { g_debug_flags = f; }
+static int g_skew = 0;
+void gemm_set_skew(int t) { g_skew = t; }
 static int g_variant = 0;      // 0 = auto, 1/2/3 = force that kernel where its shape constraints hold
 void gemm_force_v1(bool on) { g_variant = on ? 1 : 0; }
 void gemm_set_variant(int v) { g_variant = v; }
@@ -263,6 +265,7 @@ static hipError_t launch_gemm_t(int epi, const GemmArgs& g, hipStream_t s) {
 hipError_t launch_gemm(int dtype, int epi, const GemmArgs& g_in, hipStream_t s) {
     GemmArgs g = g_in;
     g.debug_flags = g_debug_flags;
+    if (g_skew) g.skew_ticks = g_skew;
     if (g.M <= 0 || g.N <= 0 || g.K <= 0) return hipErrorInvalidValue;
     if (g.M % BM || g.N % BN) return hipErrorInvalidValue;
     const int esz = dtype == DT_F32 ? 4 : 2;

@@ -208,7 +208,10 @@ __device__ __forceinline__ void v8_epilogue(const GemmArgs& g, const f32x4 (&acc
     }
 }
 
-template <typename T, int EPI>
+// STAMP: diagnostic build (tools/kstamp8.py; never launched by the model): every wave sums the 100 MHz real-time ticks it
+// spends in K loops and in epilogues and stores them, with the absolute time of its first 24 epilogue starts, into the
+// buffer passed as g.out2 — memory no other code of the kernel reads.
+template <typename T, int EPI, bool STAMP = false>
 __global__ __launch_bounds__(512, 2) void gemm_kernel_v8(GemmArgs g) {
     static_assert(sizeof(T) == 2, "v8 is for 16-bit operands");
     __shared__ __attribute__((aligned(1024))) char lds[2 * V8_STAGE + 8 * V8_WAVE_LDS];     // 160 KB: one workgroup per CU
@@ -263,6 +266,15 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel_v8(GemmArgs g) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) acc[a][i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
+    // Start-up stagger: the workgroups of an XCD start in four groups, a quarter of `skew_ticks` apart, so that the
+    // HBM-bound epilogues of one group run beside the K loops of the others instead of all 256 CUs alternating in step
+    // between "matrix pipe busy, HBM idle" and "HBM saturated, matrix pipe idle".  The relative phase persists because
+    // every tile costs the same.  s_memrealtime ticks at 100 MHz whatever the shader clock does.
+    if (g.skew_ticks > 0) {
+        const unsigned long long wait = (unsigned long long)((slot & 3) * (g.skew_ticks >> 2));
+        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+        while (__builtin_amdgcn_s_memrealtime() - t0 < wait) __builtin_amdgcn_s_sleep(32);
+    }
     int idx = slot, m0, n0;
     tile_origin(idx, m0, n0);
     const char* Ab = reinterpret_cast<const char*>(g.A) + (int64_t)m0 * lda_b;
@@ -285,6 +297,14 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel_v8(GemmArgs g) {
     if (wr == 1) __builtin_amdgcn_s_barrier();          // group 1 runs one barrier behind group 0
 
     bool after_epilogue = false;
+    unsigned long long st_k = 0, st_e = 0, st_n = 0, st_t = 0, st_c = 0, st_c0 = 0;
+    unsigned long long* stamp = nullptr;
+    if constexpr (STAMP) {
+        stamp = reinterpret_cast<unsigned long long*>(g.out2) + ((size_t)blockIdx.x * 8 + wave) * 32;
+        st_t = __builtin_amdgcn_s_memrealtime();
+        st_c0 = __builtin_amdgcn_s_memtime();
+        if (lane == 0) stamp[3] = st_t;
+    }
     for (;;) {
         const bool has_next = idx + stride < cnt;
         int m1 = m0, n1 = n0;
@@ -318,7 +338,24 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel_v8(GemmArgs g) {
             if constexpr (EPI != EPI_VT) {
                 k_loop(std::integral_constant<bool, true>{});
                 __builtin_amdgcn_sched_barrier(0);
+                if constexpr (STAMP) {
+                    const unsigned long long t1 = __builtin_amdgcn_s_memrealtime();
+                    const unsigned long long c1 = __builtin_amdgcn_s_memtime();
+                    st_c += c1 - st_c0;
+                    st_k += t1 - st_t;
+                    if (lane == 0 && st_n < 24) stamp[8 + st_n] = t1;
+                    st_t = t1;
+                    __builtin_amdgcn_sched_barrier(0);
+                }
                 v8_epilogue<T, EPI, true>(g, acc, wl, mw, nw, lane);
+                if constexpr (STAMP) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    const unsigned long long t2 = __builtin_amdgcn_s_memrealtime();
+                    st_c0 = __builtin_amdgcn_s_memtime();
+                    st_e += t2 - st_t;
+                    st_t = t2;
+                    st_n += 1;
+                }
             }
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -335,6 +372,9 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel_v8(GemmArgs g) {
         after_epilogue = true;
     }
     if (wr == 0) __builtin_amdgcn_s_barrier();
+    if constexpr (STAMP) {
+        if (lane == 0) { stamp[0] = st_k; stamp[1] = st_e; stamp[2] = st_n; stamp[4] = __builtin_amdgcn_s_memrealtime(); stamp[5] = st_c; }
+    }
 }
 
 static int v8_grid() {
@@ -348,9 +388,20 @@ static int v8_grid() {
     return grid;
 }
 
+static void* g_stamp_buf = nullptr;
+void gemm_v8_set_stamp_buffer(void* p) { g_stamp_buf = p; }
+
 template <typename T>
-static hipError_t launch_v8_t(int epi, const GemmArgs& g, hipStream_t s) {
+static hipError_t launch_v8_t(int epi, const GemmArgs& g_in, hipStream_t s) {
     dim3 grid(v8_grid()), block(512);
+    GemmArgs g = g_in;
+    if (g_stamp_buf && (epi == EPI_HEADS || epi == EPI_GELU || epi == EPI_RESID_SCALE)) {     // diagnostic build, see STAMP above
+        g.out2 = g_stamp_buf;
+        if (epi == EPI_HEADS) hipLaunchKernelGGL((gemm_kernel_v8<T, EPI_HEADS, true>), grid, block, 0, s, g);
+        else if (epi == EPI_GELU) hipLaunchKernelGGL((gemm_kernel_v8<T, EPI_GELU, true>), grid, block, 0, s, g);
+        else hipLaunchKernelGGL((gemm_kernel_v8<T, EPI_RESID_SCALE, true>), grid, block, 0, s, g);
+        return hipGetLastError();
+    }
 #define RZ_CASE8(E) case E: hipLaunchKernelGGL((gemm_kernel_v8<T, E>), grid, block, 0, s, g); break;
     switch (epi) {
         RZ_CASE8(EPI_STORE)

@@ -24,10 +24,64 @@ __device__ __forceinline__ void tile_coords(int id, int tiles_m, int tiles_n, in
     tn = r / gsz;
 }
 
+// Read-modify-write epilogues on the fp32 residual stream (EPI_RESID_SCALE, EPI_RESID_ADD) and the patch-embedding table
+// add (EPI_PATCH) for one wave's 64x64 block.  These epilogues are LATENCY bound if written as "load, wait, compute,
+// store" per MFMA tile (what the generic loop below compiles to: `if (g.bias)` per tile + s_waitcnt vmcnt(0) before every
+// use => ONE or two 1 KB loads in flight per wave, 32 dependent round trips to HBM per 128x64 wave tile: measured 33 us
+// of epilogue behind a 17 us K loop at K = 768, i.e. 4 MB in flight chip-wide / ~1 us = 4 TB/s).  Here the bias / scale
+// vectors are loaded once and the residual loads are issued in batches of 8 before the first of a batch is consumed:
+// 8 KB in flight per wave, 64 KB per CU, 16 MB chip-wide.
+template <typename T, int EPI>
+__device__ __forceinline__ void gemm_epilogue_rmw(const GemmArgs& g, const f32x4 (&acc)[4][4], int mw, int nw, int l15, int lg) {
+    static_assert(EPI == EPI_RESID_SCALE || EPI == EPI_RESID_ADD || EPI == EPI_PATCH, "fp32 read-modify-write epilogues");
+    f32x4 b4[4], s4[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int n = nw + j * 16 + 4 * lg;
+        b4[j] = g.bias ? *reinterpret_cast<const f32x4*>(g.bias + n) : (f32x4){0.f, 0.f, 0.f, 0.f};
+        if constexpr (EPI == EPI_RESID_SCALE) s4[j] = *reinterpret_cast<const f32x4*>(g.scale + n);
+    }
+    // two batches of 8 loads (two 16-row blocks x four column blocks): 32 VGPRs of staging beside the 128 accumulators
+#pragma unroll
+    for (int ih = 0; ih < 2; ++ih) {
+        f32x4 hv[2][4];
+        float* dst[2];
+#pragma unroll
+        for (int ii = 0; ii < 2; ++ii) {
+            const int m = mw + (ih * 2 + ii) * 16 + l15;
+            const float* src;
+            if constexpr (EPI == EPI_PATCH) {
+                const int b = m / g.rows_per_image, tok = m - b * g.rows_per_image;
+                src = g.scale + (int64_t)tok * g.N + nw + 4 * lg;
+                dst[ii] = reinterpret_cast<float*>(g.out) + (int64_t)m * g.ldo + nw + 4 * lg;
+            } else {
+                src = g.resid + (int64_t)m * g.ldr + nw + 4 * lg;
+                dst[ii] = (EPI == EPI_RESID_SCALE) ? g.resid + (int64_t)m * g.ldr + nw + 4 * lg
+                                                   : reinterpret_cast<float*>(g.out) + (int64_t)m * g.ldo + nw + 4 * lg;
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) hv[ii][j] = *reinterpret_cast<const f32x4*>(src + j * 16);
+        }
+#pragma unroll
+        for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                f32x4 v = acc[ih * 2 + ii][j] + b4[j];
+                if constexpr (EPI == EPI_RESID_SCALE) v = hv[ii][j] + s4[j] * v;      // h += lambda * (acc + bias)
+                else v = v + hv[ii][j];                                              // acc + bias + resid | acc + table
+                *reinterpret_cast<f32x4*>(dst[ii] + j * 16) = v;
+            }
+    }
+}
+
 // Fused epilogue for one wave's 64x64 accumulator block (4x4 MFMA tiles); (mw, nw) = block origin.
 template <typename T, int EPI>
 __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, const f32x4 (&acc)[4][4], int mw, int nw, int l15, int lg) {
     constexpr bool SWAP = (EPI != EPI_VT);
+    if constexpr (EPI == EPI_RESID_SCALE || EPI == EPI_RESID_ADD || EPI == EPI_PATCH) {
+        gemm_epilogue_rmw<T, EPI>(g, acc, mw, nw, l15, lg);
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
 #pragma unroll

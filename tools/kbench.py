@@ -160,6 +160,7 @@ if __name__ == "__main__":
     ap.add_argument("--attn-variant", type=int, default=0)
     ap.add_argument("--gemm-debug", type=int, default=0)
     ap.add_argument("--zeros", action="store_true")
+    ap.add_argument("--skew", type=int, default=0, help="persistent GEMM start-up stagger period, 10 ns ticks")
     a = ap.parse_args()
     if a.v1:
         lib.rz_set_option(b"gemm_v1_only", 1)
@@ -169,6 +170,8 @@ if __name__ == "__main__":
         lib.rz_set_option(b"attn_variant", a.attn_variant)
     if a.variant:
         lib.rz_set_option(b"gemm_variant", a.variant)
+    if a.skew:
+        lib.rz_set_option(b"gemm_skew", a.skew)
     if a.what in ("attn", "all"):
         bench_attn(a.images, dt=a.dtype, zeros=a.zeros)
     if a.what in ("gemm", "all"):
