@@ -30,6 +30,7 @@ int g_vision_chunk = 0;   // images per pass of rz_vision_forward (0 = whole bat
 int g_vision_streams = 1; // 2 = split the batch over two internal HIP streams
 int g_mlp_chunk = 0;      // images per fc1->fc2 pass (0 = whole batch = default, -1 = auto ~126 MiB of hidden rows): run_chunk in rz_vision_forward
 int g_attn_variant = 0;
+int g_ln_fused = 1;       // 1 = fuse the blocks' LayerNorms into the GEMMs either side where the persistent kernel applies (16-bit modes)
 
 hipError_t flash_attn(int dt, const void* q, const void* k, const void* vt, void* ctx, int64_t bs, int B, int H, int nv, int np,
                       hipStream_t s) {
@@ -93,6 +94,11 @@ struct Tensor {          // one packed checkpoint tensor on the device
 struct DinoBlock {       // TF:dinov2/modeling_dinov2.py:342-380
     Tensor ln1_g, ln1_b, wqkv, bqkv, wo, bo, ls1, ln2_g, ln2_b, w1, b1, w2, b2, ls2;   // wqkv: [3D][D] rows q | k | v
     int qkv_parts = 0;   // bit mask of loaded q/k/v weight (1,2,4) and bias (8,16,32) pieces
+    // fused LayerNorm (gemm8.hip): W' = W diag(gamma) in T, c1 = row sums of the rounded W', c2 = W beta + b; built once from
+    // the host copies below (16-bit modes only), which are released afterwards
+    Tensor wqkv_f, c1qkv, c2qkv, w1_f, c1_1, c2_1;
+    std::vector<float> h_wqkv, h_bqkv, h_w1, h_b1, h_g1, h_be1, h_g2, h_be2;
+    bool folded = false;
 };
 struct TextLayer {       // TF:mpnet/modeling_mpnet.py:234-261
     Tensor wqkv, bqkv, wo, bo, lna_g, lna_b, w1, b1, w2, b2, lno_g, lno_b;
@@ -116,7 +122,7 @@ struct rz_model {
     std::map<std::pair<int, int>, PosTable> pos_tables;
     // workspaces
     int cap_batch = 0, cap_npad = 0, cap_trows = 0, cap_prompts = 0;
-    DevBuf h, xn, qk, vt, ctx, mid, vhat, vws, qhat;
+    DevBuf h, xn, qk, vt, ctx, mid, vhat, vws, qhat, lnpart, lnstat;      // xn doubles as the residual's T copy on the fused-LayerNorm path
     DevBuf th, txn, tqkv, tctx, tmid, tsum;
     // state of the last vision forward
     int last_batch = 0, last_nvalid = 0, last_npad = 0;
@@ -220,16 +226,18 @@ int load_dino_block(rz_model* m, DinoBlock& b, const char* rest, const float* da
         t.loaded = true;
         return 0;
     };
-    if (!strcmp(rest, "norm1.weight")) return vec(b.ln1_g, D);
-    if (!strcmp(rest, "norm1.bias")) return vec(b.ln1_b, D);
-    if (!strcmp(rest, "norm2.weight")) return vec(b.ln2_g, D);
-    if (!strcmp(rest, "norm2.bias")) return vec(b.ln2_b, D);
+    const bool keep = m->dt != RZ_F32;       // host copies for the fused-LayerNorm packing (fold_block)
+    b.folded = false;
+    if (!strcmp(rest, "norm1.weight")) { if (keep) b.h_g1.assign(data, data + numel); return vec(b.ln1_g, D); }
+    if (!strcmp(rest, "norm1.bias")) { if (keep) b.h_be1.assign(data, data + numel); return vec(b.ln1_b, D); }
+    if (!strcmp(rest, "norm2.weight")) { if (keep) b.h_g2.assign(data, data + numel); return vec(b.ln2_g, D); }
+    if (!strcmp(rest, "norm2.bias")) { if (keep) b.h_be2.assign(data, data + numel); return vec(b.ln2_b, D); }
     if (!strcmp(rest, "layer_scale1.lambda1")) return vec(b.ls1, D);
     if (!strcmp(rest, "layer_scale2.lambda1")) return vec(b.ls2, D);
     if (!strcmp(rest, "attention.output.dense.weight")) return mat(b.wo, D, D);
     if (!strcmp(rest, "attention.output.dense.bias")) return vec(b.bo, D);
-    if (!strcmp(rest, "mlp.fc1.weight")) return mat(b.w1, F, D);
-    if (!strcmp(rest, "mlp.fc1.bias")) return vec(b.b1, F);
+    if (!strcmp(rest, "mlp.fc1.weight")) { if (keep) b.h_w1.assign(data, data + numel); return mat(b.w1, F, D); }
+    if (!strcmp(rest, "mlp.fc1.bias")) { if (keep) b.h_b1.assign(data, data + numel); return vec(b.b1, F); }
     if (!strcmp(rest, "mlp.fc2.weight")) return mat(b.w2, D, F);
     if (!strcmp(rest, "mlp.fc2.bias")) return vec(b.b2, D);
     const char* names[3] = {"query", "key", "value"};
@@ -241,6 +249,10 @@ int load_dino_block(rz_model* m, DinoBlock& b, const char* rest, const float* da
             if ((size_t)numel != D * D) return fail(RZ_ERR_INVALID, "bad numel for qkv weight");
             int rc = put_rows(m, b.wqkv, 3 * D, D, i * D, data, D, i == 0 ? qscale : 1.f, true);
             if (rc) return rc;
+            if (keep) {
+                b.h_wqkv.resize(3 * D * D);
+                for (size_t e = 0; e < D * D; ++e) b.h_wqkv[i * D * D + e] = data[e] * (i == 0 ? qscale : 1.f);
+            }
             b.qkv_parts |= (1 << i);
             return 0;
         }
@@ -248,6 +260,10 @@ int load_dino_block(rz_model* m, DinoBlock& b, const char* rest, const float* da
             if ((size_t)numel != D) return fail(RZ_ERR_INVALID, "bad numel for qkv bias");
             int rc = put_rows(m, b.bqkv, 3, D, i, data, 1, i == 0 ? qscale : 1.f, false);
             if (rc) return rc;
+            if (keep) {
+                b.h_bqkv.resize(3 * D);
+                for (size_t e = 0; e < D; ++e) b.h_bqkv[i * D + e] = data[e] * (i == 0 ? qscale : 1.f);
+            }
             b.qkv_parts |= (8 << i);
             return 0;
         }
@@ -313,6 +329,79 @@ int gemm(rz_model* m, int epi, const void* A, int64_t lda, const void* W, int64_
     return 0;
 }
 
+float t_to_f32(int dt, uint16_t v) {
+    if (dt == RZ_BF16) { uint32_t u = (uint32_t)v << 16; float f; memcpy(&f, &u, 4); return f; }
+    _Float16 h; memcpy(&h, &v, 2); return (float)h;
+}
+
+// W' = W diag(gamma) rounded to the compute dtype, c1[n] = sum_k W'[n][k] (of the ROUNDED values: the identity
+// LN(x) W^T = rstd (x W'^T - mu c1) + c2 then holds exactly for the weights the MFMAs see), c2 = W beta + b.
+int fold_matrix(rz_model* m, const std::vector<float>& W, const std::vector<float>& bias, const std::vector<float>& gamma,
+                const std::vector<float>& beta, size_t N, size_t K, Tensor& wf, Tensor& c1, Tensor& c2) {
+    if (W.size() != N * K || bias.size() != N || gamma.size() != K || beta.size() != K)
+        return fail(RZ_ERR_STATE, "fused LayerNorm packing: host copies of the block's weights are incomplete");
+    std::vector<uint16_t> wt(N * K);
+    std::vector<float> v1(N), v2(N);
+    for (size_t n = 0; n < N; ++n) {
+        double s1 = 0.0, s2 = 0.0;
+        for (size_t k = 0; k < K; ++k) {
+            const float w = W[n * K + k];
+            const uint16_t r = m->dt == RZ_BF16 ? f32_to_bf16(w * gamma[k]) : f32_to_f16(w * gamma[k]);
+            wt[n * K + k] = r;
+            s1 += (double)t_to_f32(m->dt, r);
+            s2 += (double)w * (double)beta[k];
+        }
+        v1[n] = (float)s1;
+        v2[n] = (float)(s2 + (double)bias[n]);
+    }
+    if (!wf.p) { RZ_HIP(hipMalloc(&wf.p, N * K * 2)); m->allocs.push_back(wf.p); }
+    RZ_HIP(hipMemcpy(wf.p, wt.data(), N * K * 2, hipMemcpyHostToDevice));
+    RZ_HIP(m->upload(c1, v1.data(), N, false));
+    RZ_HIP(m->upload(c2, v2.data(), N, false));
+    wf.loaded = c1.loaded = c2.loaded = true;
+    return 0;
+}
+
+int fold_block(rz_model* m, DinoBlock& b) {
+    if (b.folded) return 0;
+    const size_t D = m->D, F = m->F;
+    int rc;
+    if ((rc = fold_matrix(m, b.h_wqkv, b.h_bqkv, b.h_g1, b.h_be1, 3 * D, D, b.wqkv_f, b.c1qkv, b.c2qkv))) return rc;
+    if ((rc = fold_matrix(m, b.h_w1, b.h_b1, b.h_g2, b.h_be2, F, D, b.w1_f, b.c1_1, b.c2_1))) return rc;
+    for (auto* v : {&b.h_wqkv, &b.h_bqkv, &b.h_w1, &b.h_b1, &b.h_g1, &b.h_be1, &b.h_g2, &b.h_be2}) std::vector<float>().swap(*v);
+    b.folded = true;
+    return 0;
+}
+
+// GEMM that follows a LayerNorm, fused form: A = un-normalised residual copy, per-row (mean, rstd) in `stat`
+int gemm_ln(rz_model* m, int epi, const void* hb, const Tensor& wf, const Tensor& c1, const Tensor& c2, const float* stat, int M, int N,
+            int np, void* out, int64_t ldo, int heads, void* out2, int heads2, int split_n, hipStream_t s) {
+    GemmArgs g;
+    g.A = hb; g.lda = m->D; g.W = wf.p; g.ldw = m->D; g.M = M; g.N = N; g.K = m->D; g.bias = (const float*)c2.p; g.out = out; g.ldo = ldo;
+    g.scale = (const float*)c1.p; g.resid = nullptr; g.ldr = 0; g.rows_per_image = np; g.heads_total = heads;
+    g.out2 = out2; g.heads_total2 = heads2; g.split_n = split_n; g.ln_stat = stat; g.debug_flags = 0;
+    ProfScope ps(m, RZ_PROF_GEMM, s);
+    RZ_HIP(launch_gemm(m->dt, epi, g, s));
+    return 0;
+}
+
+// residual GEMM that precedes a LayerNorm, fused form: also writes the T copy of the new residual and partial statistics,
+// then the 12 partials per row are merged into (mean, rstd)
+int gemm_resid_ln(rz_model* m, const void* A, int64_t lda, const Tensor& W, const Tensor& bias, const Tensor& ls, int M, int K, float* h,
+                  int np, void* hb, float* part, float* stat, float eps, hipStream_t s) {
+    GemmArgs g;
+    g.A = A; g.lda = lda; g.W = W.p; g.ldw = K; g.M = M; g.N = m->D; g.K = K; g.bias = (const float*)bias.p; g.out = nullptr; g.ldo = 0;
+    g.scale = (const float*)ls.p; g.resid = h; g.ldr = m->D; g.rows_per_image = np; g.heads_total = 0; g.ln_part = part; g.ln_hb = hb;
+    g.debug_flags = 0;
+    {
+        ProfScope ps(m, RZ_PROF_GEMM, s);
+        RZ_HIP(launch_gemm(m->dt, EPI_RESID_SCALE_LN, g, s));
+    }
+    ProfScope ps(m, RZ_PROF_ROWOPS, s);
+    RZ_HIP(launch_ln_finalize(part, stat, eps, M, s));
+    return 0;
+}
+
 int gemm_qkv(rz_model* m, const void* xn, const DinoBlock& b, int M, int np, void* qk, void* vt, hipStream_t s) {
     const int D = m->D, H = m->H;
     GemmArgs g;
@@ -368,7 +457,7 @@ int rz_destroy(rz_handle_t m) {
     (void)hipDeviceSynchronize();        // nothing of this handle may still be in flight when its buffers go away
     for (void* p : m->allocs) (void)hipFree(p);
     for (auto& kv : m->pos_tables) kv.second.buf.release();
-    DevBuf* bufs[] = {&m->h, &m->xn, &m->qk, &m->vt, &m->ctx, &m->mid, &m->vhat, &m->vws, &m->qhat,
+    DevBuf* bufs[] = {&m->h, &m->xn, &m->qk, &m->vt, &m->ctx, &m->mid, &m->vhat, &m->vws, &m->qhat, &m->lnpart, &m->lnstat,
                       &m->th, &m->txn, &m->tqkv, &m->tctx, &m->tmid, &m->tsum};
     for (DevBuf* b : bufs) b->release();
     for (auto& e : m->ev_pool) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
@@ -501,6 +590,10 @@ int rz_reserve(rz_handle_t m, int max_batch, int max_tokens, int max_prompts, in
         RZ_HIP(m->ctx.ensure(rows * D * es, true));
         RZ_HIP(m->mid.ensure(rows * std::max(F, (size_t)m->KPAD) * es, true));
         RZ_HIP(m->vhat.ensure(rows * D * 4, true));
+        if (m->dt != RZ_F32) {
+            RZ_HIP(m->lnpart.ensure(rows * 24 * 4, true));
+            RZ_HIP(m->lnstat.ensure(rows * 2 * 4, true));
+        }
         m->cap_batch = B;
         m->cap_npad = NP;
     }
@@ -569,15 +662,37 @@ int rz_vision_forward(rz_handle_t m, const float* px, int B, int C, int Himg, in
                        (const float*)it->second.buf.p, nullptr, 0, np, 0, s))) return rc;
 
         const int nblocks = (int)m->blocks.size();
+        // LayerNorm fused into the GEMMs either side of it (gemm8.hip): every block of this chunk or none
+        const bool fused = g_ln_fused && nblocks > 0 && gemm_ln_fused_ok(m->dt, M, D, F);
+        float* part = fused ? (float*)m->lnpart.p + row0 * 24 : nullptr;
+        float* stat = fused ? (float*)m->lnstat.p + row0 * 2 : nullptr;
+        if (fused) {
+            for (auto& b : m->blocks)
+                if ((rc = fold_block(m, b))) return rc;
+        }
+        if (m->cfg.vit_layers == 0) {
+            // no ViT blocks: Dinov2Model.layernorm (TF:dinov2/modeling_dinov2.py:469) acts on the embeddings, align blocks follow
+            ProfScope ps(m, RZ_PROF_ROWOPS, s);
+            if (fused) RZ_HIP(launch_ln_prepare(m->dt, h, (const float*)m->vit_ln_g.p, (const float*)m->vit_ln_b.p, eps, h, xn, stat, eps, M, D, s));
+            else RZ_HIP(launch_layernorm(m->dt, h, (const float*)m->vit_ln_g.p, (const float*)m->vit_ln_b.p, eps, nullptr, h, M, D, s));
+        } else if (fused) {                   // block 0 reads the patch-embedding output: copy + statistics by the row kernel
+            ProfScope ps(m, RZ_PROF_ROWOPS, s);
+            RZ_HIP(launch_ln_prepare(m->dt, h, nullptr, nullptr, 0.f, nullptr, xn, stat, eps, M, D, s));
+        }
         for (int li = 0; li < nblocks; ++li) {
             const DinoBlock& b = m->blocks[li];
-            {
-                ProfScope ps(m, RZ_PROF_ROWOPS, s);
-                RZ_HIP(launch_layernorm(m->dt, h, (const float*)b.ln1_g.p, (const float*)b.ln1_b.p, eps, xn, nullptr, M, D, s));
+            const bool last_vit = (li == m->cfg.vit_layers - 1), last = (li == nblocks - 1);
+            if (!fused) {
+                {
+                    ProfScope ps(m, RZ_PROF_ROWOPS, s);
+                    RZ_HIP(launch_layernorm(m->dt, h, (const float*)b.ln1_g.p, (const float*)b.ln1_b.p, eps, xn, nullptr, M, D, s));
+                }
+                // q | k | v projection (TF:dinov2/modeling_dinov2.py:199-213): ONE launch over N = 3D where the persistent kernel
+                // applies (q, k -> per-head rows, v -> transposed, chosen per 256-column tile), else q|k and v separately
+                if ((rc = gemm_qkv(m, xn, b, M, np, qkb, vtb, s))) return rc;
+            } else {
+                if ((rc = gemm_ln(m, EPI_QKV_LN, xn, b.wqkv_f, b.c1qkv, b.c2qkv, stat, M, 3 * D, np, qkb, 0, 2 * H, vtb, H, 2 * D, s))) return rc;
             }
-            // q | k | v projection (TF:dinov2/modeling_dinov2.py:199-213): ONE launch over N = 3D where the persistent kernel
-            // applies (q, k -> per-head rows, v -> transposed, chosen per 256-column tile), else q|k and v separately
-            if ((rc = gemm_qkv(m, xn, b, M, np, qkb, vtb, s))) return rc;
             {
                 ProfScope ps(m, RZ_PROF_ATTN, s);
                 // q heads are heads [0,H) and k heads [H,2H) of the [B][2H][np][64] tensor
@@ -585,30 +700,42 @@ int rz_vision_forward(rz_handle_t m, const float* px, int B, int C, int Himg, in
                 const char* kb = qb + (size_t)H * np * 64 * es;
                 RZ_HIP(flash_attn(m->dt, qb, kb, vtb, ctxb, (int64_t)2 * H * np * 64, Bc, H, nv, np, s));
             }
-            if ((rc = gemm(m, EPI_RESID_SCALE, ctxb, D, b.wo.p, D, M, D, D, (const float*)b.bo.p, nullptr, 0, (const float*)b.ls1.p, h, D, np, 0, s))) return rc;
-            {
-                ProfScope ps(m, RZ_PROF_ROWOPS, s);
-                RZ_HIP(launch_layernorm(m->dt, h, (const float*)b.ln2_g.p, (const float*)b.ln2_b.p, eps, xn, nullptr, M, D, s));
+            if (!fused) {
+                if ((rc = gemm(m, EPI_RESID_SCALE, ctxb, D, b.wo.p, D, M, D, D, (const float*)b.bo.p, nullptr, 0, (const float*)b.ls1.p, h, D, np, 0, s))) return rc;
+                {
+                    ProfScope ps(m, RZ_PROF_ROWOPS, s);
+                    RZ_HIP(launch_layernorm(m->dt, h, (const float*)b.ln2_g.p, (const float*)b.ln2_b.p, eps, xn, nullptr, M, D, s));
+                }
+            } else {
+                if ((rc = gemm_resid_ln(m, ctxb, D, b.wo, b.bo, b.ls1, M, D, h, np, xn, part, stat, eps, s))) return rc;
             }
             // MLP in row chunks that all reuse the FIRST rows of `mid`: the GELU'd hidden activations of a few images
             // (4 x 5376 x 3072 bf16 = 126 MiB) stay in the 256 MB Infinity Cache between fc1's stores and fc2's loads and
             // the same lines are overwritten by the next chunk, instead of 1 GB per layer going out to HBM and back.
             // Measured: tools/kmlp.py 2.05 -> 1.83 ms per layer of 32 images in isolation, but no gain inside the model
             // (372-374 vs 375-376 images/s), so the default is one pass over the whole chunk (option "mlp_chunk").
-            for (int i0 = 0; i0 < Bc; i0 += mlp_images) {
-                const int Mi = std::min(mlp_images, Bc - i0) * np;
-                const size_t r0 = (size_t)i0 * np;
-                if ((rc = gemm(m, EPI_GELU, xn + r0 * D * es, D, b.w1.p, D, Mi, F, D, (const float*)b.b1.p, mid, F, nullptr, nullptr, 0, np, 0, s))) return rc;
-                if ((rc = gemm(m, EPI_RESID_SCALE, mid, F, b.w2.p, F, Mi, D, F, (const float*)b.b2.p, nullptr, 0, (const float*)b.ls2.p, h + r0 * D, D, np, 0, s))) return rc;
+            if (fused) {
+                if ((rc = gemm_ln(m, EPI_GELU_LN, xn, b.w1_f, b.c1_1, b.c2_1, stat, M, F, np, mid, F, 0, nullptr, 0, 0, s))) return rc;
+                if (last || last_vit) {     // nobody reads this block's output through a fused LayerNorm: plain residual epilogue
+                    if ((rc = gemm(m, EPI_RESID_SCALE, mid, F, b.w2.p, F, M, D, F, (const float*)b.b2.p, nullptr, 0, (const float*)b.ls2.p, h, D, np, 0, s))) return rc;
+                } else {
+                    if ((rc = gemm_resid_ln(m, mid, F, b.w2, b.b2, b.ls2, M, F, h, np, xn, part, stat, eps, s))) return rc;
+                }
+            } else {
+                for (int i0 = 0; i0 < Bc; i0 += mlp_images) {
+                    const int Mi = std::min(mlp_images, Bc - i0) * np;
+                    const size_t r0 = (size_t)i0 * np;
+                    if ((rc = gemm(m, EPI_GELU, xn + r0 * D * es, D, b.w1.p, D, Mi, F, D, (const float*)b.b1.p, mid, F, nullptr, nullptr, 0, np, 0, s))) return rc;
+                    if ((rc = gemm(m, EPI_RESID_SCALE, mid, F, b.w2.p, F, Mi, D, F, (const float*)b.b2.p, nullptr, 0, (const float*)b.ls2.p, h + r0 * D, D, np, 0, s))) return rc;
+                }
             }
-            if (li == m->cfg.vit_layers - 1) {   // Dinov2Model.layernorm (TF:dinov2/modeling_dinov2.py:469); align blocks follow
+            if (last_vit) {   // Dinov2Model.layernorm (TF:dinov2/modeling_dinov2.py:469); align blocks follow
                 ProfScope ps(m, RZ_PROF_ROWOPS, s);
-                RZ_HIP(launch_layernorm(m->dt, h, (const float*)m->vit_ln_g.p, (const float*)m->vit_ln_b.p, eps, nullptr, h, M, D, s));
+                if (fused && !last)
+                    RZ_HIP(launch_ln_prepare(m->dt, h, (const float*)m->vit_ln_g.p, (const float*)m->vit_ln_b.p, eps, h, xn, stat, eps, M, D, s));
+                else
+                    RZ_HIP(launch_layernorm(m->dt, h, (const float*)m->vit_ln_g.p, (const float*)m->vit_ln_b.p, eps, nullptr, h, M, D, s));
             }
-        }
-        if (m->cfg.vit_layers == 0) {
-            ProfScope ps(m, RZ_PROF_ROWOPS, s);
-            RZ_HIP(launch_layernorm(m->dt, h, (const float*)m->vit_ln_g.p, (const float*)m->vit_ln_b.p, eps, nullptr, h, M, D, s));
         }
         return 0;
     };
@@ -845,6 +972,7 @@ int rz_set_option(const char* name, int value) {
     if (!strcmp(name, "vision_streams")) { g_vision_streams = value; return 0; }
     if (!strcmp(name, "mlp_chunk")) { g_mlp_chunk = value; return 0; }
     if (!strcmp(name, "attn_variant")) { g_attn_variant = value; return 0; }
+    if (!strcmp(name, "ln_fused")) { g_ln_fused = value; return 0; }
     return fail(RZ_ERR_INVALID, std::string("rz_set_option: unknown option ") + name);
 }
 

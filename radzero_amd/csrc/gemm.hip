@@ -11,6 +11,8 @@
 // 128 bytes per step (64 x 16-bit or 32 x f32), two LDS stages filled by global_load_lds_dwordx4 with
 // the panel XOR swizzle of rz_common.h.  M must be a multiple of 128 (callers pad rows per image),
 // N a multiple of 128, K*sizeof(T) a multiple of 128.
+#include <cstring>
+
 #include "gemm_common.h"
 
 namespace rz {
@@ -219,6 +221,20 @@ bool gemm_qkv_fused_ok(int dtype, const GemmArgs& g) {
     return (g_variant == 0 || g_variant == 8) && gemm_v8_ok(dtype, EPI_QKV, g) && (g_variant == 8 || big_tiles_pay(g));
 }
 
+// May a whole Dinov2 block run on the persistent kernel with its LayerNorms fused into the GEMMs (EPI_QKV_LN, EPI_GELU_LN,
+// EPI_RESID_SCALE_LN)?  All four shapes of the block must qualify, otherwise the caller keeps the stand-alone LayerNorms.
+bool gemm_ln_fused_ok(int dtype, int M, int D, int F) {
+    if (dtype == DT_F32 || !(g_variant == 0 || g_variant == 8) || M <= 0 || M % 256 || D != 768) return false;
+    const int shapes[4][2] = {{3 * D, D}, {D, D}, {F, D}, {D, F}};
+    for (const auto& nk : shapes) {
+        GemmArgs g;
+        memset(&g, 0, sizeof g);
+        g.M = M; g.N = nk[0]; g.K = nk[1]; g.lda = nk[1]; g.ldw = nk[1];
+        if (!gemm_v8_ok(dtype, EPI_STORE, g) || !(g_variant == 8 || big_tiles_pay(g))) return false;
+    }
+    return true;
+}
+
 template <typename T>
 static hipError_t launch_gemm_t(int epi, const GemmArgs& g, hipStream_t s) {
     const bool ok3 = (g.M % BM2 == 0) && (g.M >= 4 * BM2) && (g.N % BN3 == 0);
@@ -231,7 +247,7 @@ static hipError_t launch_gemm_t(int epi, const GemmArgs& g, hipStream_t s) {
         const bool big = big_tiles_pay(g);
         variant = !big ? 1 : gemm_v8_ok(Traits<T>::kDType, epi, g) ? 8 : gemm_v7_ok(Traits<T>::kDType, g) ? 7 : 3;
     }
-    if (epi == EPI_QKV && variant != 8) return hipErrorInvalidValue;
+    if (epi >= EPI_QKV && variant != 8) return hipErrorInvalidValue;       // EPI_QKV and the fused-LayerNorm epilogues: persistent kernel only
     if (variant == 8) {
         if (gemm_v8_ok(Traits<T>::kDType, epi, g)) return launch_gemm_v8(Traits<T>::kDType, epi, g, s);
         variant = 7;

@@ -73,6 +73,84 @@ hipError_t launch_layernorm(int dtype, const float* in, const float* gamma, cons
     return hipGetLastError();
 }
 
+// ---- fused-LayerNorm support (gemm8.hip "Fused LayerNorm") ----
+// ln_finalize: one thread per row merges the 12 (mean, M2) partials of 64 columns each that EPI_RESID_SCALE_LN wrote
+// (equal counts: mean = average of means, M2 = sum M2_p + 64 * sum (mean_p - mean)^2 — Chan et al., exact) into (mean, rstd).
+__global__ __launch_bounds__(256) void ln_finalize_kernel(const float* __restrict__ part, float* __restrict__ stat, float eps, int64_t rows) {
+    const int64_t row = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (row >= rows) return;
+    const f32x4* p = reinterpret_cast<const f32x4*>(part + row * 24);
+    f32x4 v[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) v[i] = p[i];
+    float mean = 0.f;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) mean += v[i][0] + v[i][2];
+    mean *= (1.0f / 12.0f);
+    float m2 = 0.f, dev = 0.f;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        m2 += v[i][1] + v[i][3];
+        const float d0 = v[i][0] - mean, d1 = v[i][2] - mean;
+        dev += d0 * d0 + d1 * d1;
+    }
+    const float var = (m2 + 64.0f * dev) * (1.0f / 768.0f);
+    *reinterpret_cast<f32x2*>(stat + row * 2) = (f32x2){mean, rsqrtf(var + eps)};
+}
+
+hipError_t launch_ln_finalize(const float* part, float* stat, float eps, int64_t rows, hipStream_t s) {
+    if (rows <= 0) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(ln_finalize_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, s, part, stat, eps, rows);
+    return hipGetLastError();
+}
+
+// ln_prepare: what a fused-LayerNorm consumer needs of a residual-stream row that no GEMM epilogue produced: its copy in T
+// and (mean, rstd).  With gamma != nullptr the row is first LayerNorm'ed (eps_in) into out_f32 — the ViT's final LayerNorm,
+// whose OUTPUT is the residual stream of the align blocks — and copy / statistics are those of the normalised row.
+template <typename T, int NV>
+__global__ __launch_bounds__(256) void ln_prepare_kernel(const float* __restrict__ in, const float* __restrict__ gamma,
+                                                         const float* __restrict__ beta, float eps_in, float* out_f32,
+                                                         T* __restrict__ copy_t, float* __restrict__ stat, float eps_stat, int64_t rows) {
+    constexpr int D = 256 * NV;
+    constexpr float invD = 1.0f / D;
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    RowRegs<NV> r = load_row<NV>(in + row * D, lane);
+    if (gamma) {
+        row_layernorm<NV>(r, gamma, beta, eps_in, lane);
+#pragma unroll
+        for (int i = 0; i < NV; ++i) *reinterpret_cast<f32x4*>(out_f32 + row * D + (lane + 64 * i) * 4) = r.v[i];
+    }
+    float sm = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) sm += (r.v[i][0] + r.v[i][1]) + (r.v[i][2] + r.v[i][3]);
+    const float mu = wave_sum(sm) * invD;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const f32x4 d = r.v[i] - mu;
+        q += (d[0] * d[0] + d[1] * d[1]) + (d[2] * d[2] + d[3] * d[3]);
+    }
+    const float rstd = rsqrtf(wave_sum(q) * invD + eps_stat);
+    if (lane == 0) *reinterpret_cast<f32x2*>(stat + row * 2) = (f32x2){mu, rstd};
+#pragma unroll
+    for (int i = 0; i < NV; ++i)
+        *reinterpret_cast<typename Traits<T>::vec4*>(copy_t + row * D + (lane + 64 * i) * 4) = pack4<T>(r.v[i][0], r.v[i][1], r.v[i][2], r.v[i][3]);
+}
+
+hipError_t launch_ln_prepare(int dtype, const float* in, const float* gamma, const float* beta, float eps_in, float* out_f32,
+                             void* copy_t, float* stat, float eps_stat, int64_t rows, int D, hipStream_t s) {
+    if (D != 768 || rows <= 0 || !copy_t || !stat || (gamma && (!beta || !out_f32))) return hipErrorInvalidValue;
+    dim3 grid((unsigned)((rows + 3) / 4)), block(256);
+    switch (dtype) {
+        case DT_BF16: hipLaunchKernelGGL((ln_prepare_kernel<bf16_t, 3>), grid, block, 0, s, in, gamma, beta, eps_in, out_f32, (bf16_t*)copy_t, stat, eps_stat, rows); break;
+        case DT_F16: hipLaunchKernelGGL((ln_prepare_kernel<f16_t, 3>), grid, block, 0, s, in, gamma, beta, eps_in, out_f32, (f16_t*)copy_t, stat, eps_stat, rows); break;
+        default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
 // ---- shared LayerNorm + L2 normalisation (exp/cxr_pt/model/losses.py:90-91,163-164 then :212-213) ----
 template <int NV>
 __global__ __launch_bounds__(256) void ln_l2norm_kernel(const float* __restrict__ in, int64_t ld_in,

@@ -15,6 +15,10 @@ enum Epilogue : int {
     EPI_PATCH = 6,        // out_f32[m][n] = acc + scale[tok][n]             (patch-embed: pos/cls/bias table)
     EPI_STORE_F32 = 7,    // out_f32[m][n] = acc + bias
     EPI_QKV = 8,          // merged q|k|v projection: columns < split_n as EPI_HEADS into `out`, the rest as EPI_VT into `out2` (gemm8.hip)
+    // ---- LayerNorm fused into the GEMMs either side of it (gemm8.hip only; see "Fused LayerNorm" there) ----
+    EPI_RESID_SCALE_LN = 9,   // EPI_RESID_SCALE + the next LayerNorm's inputs: ln_hb<T>[m][n] = new resid, ln_part[m][12] = (mean, M2) of 64-column slices
+    EPI_QKV_LN = 10,          // EPI_QKV on the UN-normalised operand: (acc - mu[m]*scale[n]) * rstd[m] + bias[n], (mu, rstd) = ln_stat[m]
+    EPI_GELU_LN = 11,         // EPI_GELU likewise
 };
 
 struct GemmArgs {
@@ -30,6 +34,9 @@ struct GemmArgs {
     void* out2 = nullptr;         // EPI_QKV: transposed-v destination
     int heads_total2 = 0;         // EPI_QKV: heads in `out2`
     int split_n = 0;              // EPI_QKV: first column of the v block (multiple of 256)
+    const float* ln_stat = nullptr;  // EPI_*_LN consumers: [M][2] = (mean, rstd) of every operand row; `scale` = c1[N], `bias` = c2[N]
+    float* ln_part = nullptr;        // EPI_RESID_SCALE_LN: [M][12][2] partial statistics (N must be 768)
+    void* ln_hb = nullptr;           // EPI_RESID_SCALE_LN: [M][N] copy of the new residual in the compute dtype
     int skew_ticks = 0;           // persistent kernel: start-up stagger period in 10 ns ticks (0 = none), see gemm8.hip
     int debug_flags;              // measurement only: bit0 skip MFMA/ds_read body, bit1 skip W staging, bit2 skip epilogue,
                                   // bit3 force the LDS-staged full-line epilogue, bit4 force the direct epilogue (256x256 kernels)
@@ -43,7 +50,8 @@ void gemm_set_skew(int ticks);  // experiment: start-up stagger of the persisten
 void gemm_set_variant(int v);  // 0 auto, 1 = 128x128 two-stage, 3 = 256x256 two-stage, 7 = 256x256 staggered 8-phase (gemm7.hip), 8 = persistent (gemm8.hip), 9 = 7 + in-kernel stamps
 bool gemm_v7_ok(int dtype, const GemmArgs& g);
 bool gemm_v8_ok(int dtype, int epi, const GemmArgs& g);
-bool gemm_qkv_fused_ok(int dtype, const GemmArgs& g);   // may EPI_QKV be launched for this shape (else: EPI_HEADS + EPI_VT)
+bool gemm_qkv_fused_ok(int dtype, const GemmArgs& g);
+bool gemm_ln_fused_ok(int dtype, int M, int D, int F);   // may a Dinov2 block of M token rows use the fused-LayerNorm epilogues   // may EPI_QKV be launched for this shape (else: EPI_HEADS + EPI_VT)
 hipError_t launch_gemm_v8(int dtype, int epi, const GemmArgs& g, hipStream_t s);   // persistent 256x256 kernel (gemm8.hip)
 hipError_t launch_gemm_v7(int variant, int dtype, int epi, const GemmArgs& g, hipStream_t s);
 
@@ -61,6 +69,13 @@ hipError_t launch_flash_attn32(int dtype, const void* q, const void* k, const vo
 // host to rel_bias[H][L][L], key-padding mask [T][L]; ctx [T*L][H*64].
 hipError_t launch_text_attn(int dtype, const void* qkv, const float* rel_bias, const int64_t* attn_mask, void* ctx, int T, int L,
                             int H, hipStream_t s);
+
+// Fused-LayerNorm support (rowops.hip).  ln_finalize: partial statistics [rows][12][2] (mean, M2 of 64-column slices, as
+// EPI_RESID_SCALE_LN writes them) -> stat [rows][2] = (mean, rstd).  ln_prepare: rows of 768 fp32 -> T copy + stat; with
+// gamma/beta != nullptr the row is first LayerNorm'ed in place (out_f32, may alias in) and copy / stat describe the result.
+hipError_t launch_ln_finalize(const float* part, float* stat, float eps, int64_t rows, hipStream_t s);
+hipError_t launch_ln_prepare(int dtype, const float* in, const float* gamma, const float* beta, float eps_in, float* out_f32,
+                             void* copy_t, float* stat, float eps_stat, int64_t rows, int D, hipStream_t s);
 
 // LayerNorm over rows of 768: fp32 in; writes T-typed normalized copy (out_t, may be null) and/or
 // fp32 (out_f32, may alias in).
