@@ -691,7 +691,18 @@ int rz_vision_forward(rz_handle_t m, const float* px, int B, int C, int Himg, in
                 // applies (q, k -> per-head rows, v -> transposed, chosen per 256-column tile), else q|k and v separately
                 if ((rc = gemm_qkv(m, xn, b, M, np, qkb, vtb, s))) return rc;
             } else {
-                if ((rc = gemm_ln(m, EPI_QKV_LN, xn, b.wqkv_f, b.c1qkv, b.c2qkv, stat, M, 3 * D, np, qkb, 0, 2 * H, vtb, H, 2 * D, s))) return rc;
+                GemmArgs probe;
+                probe.A = xn; probe.lda = D; probe.W = b.wqkv_f.p; probe.ldw = D; probe.M = M; probe.N = 3 * D; probe.K = D; probe.out2 = vtb; probe.split_n = 2 * D;
+                if (gemm_qkv_fused_ok(m->dt, probe)) {
+                    if ((rc = gemm_ln(m, EPI_QKV_LN, xn, b.wqkv_f, b.c1qkv, b.c2qkv, stat, M, 3 * D, np, qkb, 0, 2 * H, vtb, H, 2 * D, s))) return rc;
+                } else {        // small batches: the same projection as q|k and v launches of the 128x128 kernel
+                    Tensor wv = b.wqkv_f, c1v = b.c1qkv, c2v = b.c2qkv;
+                    wv.p = (char*)b.wqkv_f.p + (size_t)2 * D * D * es;
+                    c1v.p = (float*)b.c1qkv.p + 2 * D;
+                    c2v.p = (float*)b.c2qkv.p + 2 * D;
+                    if ((rc = gemm_ln(m, EPI_HEADS_LN, xn, b.wqkv_f, b.c1qkv, b.c2qkv, stat, M, 2 * D, np, qkb, 0, 2 * H, nullptr, 0, 0, s))) return rc;
+                    if ((rc = gemm_ln(m, EPI_VT_LN, xn, wv, c1v, c2v, stat, M, D, np, vtb, 0, H, nullptr, 0, 0, s))) return rc;
+                }
             }
             {
                 ProfScope ps(m, RZ_PROF_ATTN, s);

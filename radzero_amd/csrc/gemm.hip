@@ -21,7 +21,7 @@ namespace rz {
 template <typename T, int EPI>
 __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs g) {
     __shared__ __attribute__((aligned(1024))) char lds[4 * PANEL_BYTES];  // A0 A1 B0 B1
-    constexpr bool SWAP = (EPI != EPI_VT);
+    constexpr bool SWAP = (EPI != EPI_VT && EPI != EPI_VT_LN);
     constexpr int KS = 128 / (32 * (int)sizeof(T));  // MFMA k-steps (of 32 elements) per panel
     typedef typename Traits<T>::frag frag_t;
 
@@ -221,18 +221,10 @@ bool gemm_qkv_fused_ok(int dtype, const GemmArgs& g) {
     return (g_variant == 0 || g_variant == 8) && gemm_v8_ok(dtype, EPI_QKV, g) && (g_variant == 8 || big_tiles_pay(g));
 }
 
-// May a whole Dinov2 block run on the persistent kernel with its LayerNorms fused into the GEMMs (EPI_QKV_LN, EPI_GELU_LN,
-// EPI_RESID_SCALE_LN)?  All four shapes of the block must qualify, otherwise the caller keeps the stand-alone LayerNorms.
+// May a Dinov2 block run with its LayerNorms fused into the GEMMs (EPI_*_LN)?  Every 16-bit shape does: the persistent kernel
+// takes the large ones, the 128x128 kernel the rest, with bit-identical arithmetic (gemm_common.h::gemm_epilogue_ln).
 bool gemm_ln_fused_ok(int dtype, int M, int D, int F) {
-    if (dtype == DT_F32 || !(g_variant == 0 || g_variant == 8) || M <= 0 || M % 256 || D != 768) return false;
-    const int shapes[4][2] = {{3 * D, D}, {D, D}, {F, D}, {D, F}};
-    for (const auto& nk : shapes) {
-        GemmArgs g;
-        memset(&g, 0, sizeof g);
-        g.M = M; g.N = nk[0]; g.K = nk[1]; g.lda = nk[1]; g.ldw = nk[1];
-        if (!gemm_v8_ok(dtype, EPI_STORE, g) || !(g_variant == 8 || big_tiles_pay(g))) return false;
-    }
-    return true;
+    return dtype != DT_F32 && (g_variant == 0 || g_variant == 1 || g_variant == 8) && M > 0 && M % BM == 0 && D == 768 && F % BN == 0;
 }
 
 template <typename T>
@@ -247,10 +239,12 @@ static hipError_t launch_gemm_t(int epi, const GemmArgs& g, hipStream_t s) {
         const bool big = big_tiles_pay(g);
         variant = !big ? 1 : gemm_v8_ok(Traits<T>::kDType, epi, g) ? 8 : gemm_v7_ok(Traits<T>::kDType, g) ? 7 : 3;
     }
-    if (epi >= EPI_QKV && variant != 8) return hipErrorInvalidValue;       // EPI_QKV and the fused-LayerNorm epilogues: persistent kernel only
+    if ((epi == EPI_QKV || epi == EPI_QKV_LN) && variant != 8) return hipErrorInvalidValue;     // merged projection: persistent kernel only
+    if ((epi == EPI_HEADS_LN || epi == EPI_VT_LN) && variant == 8) variant = 1;                  // its two halves: 128x128 kernel only
+    if (epi > EPI_QKV && variant != 8) variant = 1;                                               // fused-LayerNorm epilogues: those two kernels
     if (variant == 8) {
         if (gemm_v8_ok(Traits<T>::kDType, epi, g)) return launch_gemm_v8(Traits<T>::kDType, epi, g, s);
-        variant = 7;
+        variant = epi > EPI_QKV ? 1 : 7;
     }
     if (variant == 7 || variant == 9) {
         if (gemm_v7_ok(Traits<T>::kDType, g)) return launch_gemm_v7(variant, Traits<T>::kDType, epi, g, s);
@@ -263,6 +257,8 @@ static hipError_t launch_gemm_t(int epi, const GemmArgs& g, hipStream_t s) {
 #define RZ_CASE(E) \
     case E: if (variant == 3) hipLaunchKernelGGL((gemm_kernel_v3<T, E>), grid, block, 0, s, g); \
             else hipLaunchKernelGGL((gemm_kernel<T, E>), grid, block, 0, s, g); break;
+#define RZ_CASE1(E) case E: if (variant != 1 || sizeof(T) != 2) return hipErrorInvalidValue; \
+                       if constexpr (sizeof(T) == 2) hipLaunchKernelGGL((gemm_kernel<T, E>), grid, block, 0, s, g); break;
     switch (epi) {
         RZ_CASE(EPI_STORE)
         RZ_CASE(EPI_GELU)
@@ -272,9 +268,14 @@ static hipError_t launch_gemm_t(int epi, const GemmArgs& g, hipStream_t s) {
         RZ_CASE(EPI_RESID_ADD)
         RZ_CASE(EPI_PATCH)
         RZ_CASE(EPI_STORE_F32)
+        RZ_CASE1(EPI_RESID_SCALE_LN)
+        RZ_CASE1(EPI_GELU_LN)
+        RZ_CASE1(EPI_HEADS_LN)
+        RZ_CASE1(EPI_VT_LN)
         default: return hipErrorInvalidValue;
     }
 #undef RZ_CASE
+#undef RZ_CASE1
     return hipGetLastError();
 }
 

@@ -61,17 +61,17 @@ template <int N> __device__ __forceinline__ void v8_wait_vm() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-// One K tile.  s1: a K tile T+1 exists (issue its U2, U3 into `nxt`), s2: T+2 exists (its U0, U1 into `cur`); T+1 / T+2
-// may belong to the next output tile.  a1 / w1 (a2 / w2): wave-uniform source bases at the K offset of T+1 (T+2).
-// extra: this is the first K tile after an epilogue (see header).  All three flags are wave-uniform run-time values so
-// that the kernel holds ONE copy of this body inside one simple loop (several inlined variants made hipcc rename the
-// accumulators between copies and spill them): a scalar branch selects the wait, and the last two K tiles of a workgroup
-// (s2 false), where fewer units are in flight than the counted waits assume, simply wait for everything.
+// One K tile.  a1 / w1 (a2 / w2): wave-uniform source bases at the K offset of K tile T+1 (T+2), which may belong to the next
+// output tile; the units of T+1 / T+2 are ALWAYS issued, so the counted waits hold everywhere — behind a workgroup's last
+// output tile they re-fetch operands of that same tile into buffers nobody reads again (128 KB per workgroup per launch),
+// and the kernel drains them before it ends.  extra (wave-uniform, run time): this is the first K tile after an epilogue
+// (see header); one scalar branch per phase selects the wait.  ONE copy of this body exists in the kernel, inside one
+// simple loop: with one inlined variant per case hipcc renamed the accumulators between the copies and spilled them.
 template <typename T, bool SWAP, int EXTRA>
 __device__ __forceinline__ void v8_tile(f32x4 (&acc)[2][4][4], char* cur, char* nxt, unsigned a_rd, unsigned b_rd,
                                         const char* a1, const char* w1, const char* a2, const char* w2,
                                         const unsigned (&a_off)[2], const unsigned (&w_off)[2], int64_t a_sub, int64_t w_sub,
-                                        unsigned a_dst, unsigned w_dst, bool s1, bool s2, bool extra) {
+                                        unsigned a_dst, unsigned w_dst, bool extra) {
     typedef typename Traits<T>::frag frag_t;
     frag_t fa[2][4], fb0[2][2], fb1[2][2];          // [k-half][fragment]
 #pragma unroll
@@ -96,14 +96,12 @@ __device__ __forceinline__ void v8_tile(f32x4 (&acc)[2][4][4], char* cur, char* 
 #pragma unroll
                 for (int j = 0; j < 2; ++j) fb1[ks][j] = *reinterpret_cast<const frag_t*>(cur + (((b_rd + 32 * 128) ^ (ks * 64)) + j * 2048));
         }
-        if ((u < 2 && s1) || (u >= 2 && s2)) {
 #pragma unroll
-            for (int e = 0; e < 2; ++e) {
-                if (u == 0) v8_glds(w1 + w_sub, w_off[e], nxt + w_dst + 32 * 128 + e * 1024);     // U2(T+1)
-                if (u == 1) v8_glds(a1 + a_sub, a_off[e], nxt + a_dst + 64 * 128 + e * 1024);     // U3(T+1)
-                if (u == 2) v8_glds(a2, a_off[e], cur + a_dst + e * 1024);                        // U0(T+2)
-                if (u == 3) v8_glds(w2, w_off[e], cur + w_dst + e * 1024);                        // U1(T+2)
-            }
+        for (int e = 0; e < 2; ++e) {
+            if (u == 0) v8_glds(w1 + w_sub, w_off[e], nxt + w_dst + 32 * 128 + e * 1024);     // U2(T+1)
+            if (u == 1) v8_glds(a1 + a_sub, a_off[e], nxt + a_dst + 64 * 128 + e * 1024);     // U3(T+1)
+            if (u == 2) v8_glds(a2, a_off[e], cur + a_dst + e * 1024);                        // U0(T+2)
+            if (u == 3) v8_glds(w2, w_off[e], cur + w_dst + e * 1024);                        // U1(T+2)
         }
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();
@@ -122,8 +120,7 @@ __device__ __forceinline__ void v8_tile(f32x4 (&acc)[2][4][4], char* cur, char* 
         __builtin_amdgcn_sched_barrier(0);
         // everything issued three or more phases ago must have landed: the three youngest units (6 instructions) may stay
         // in flight (+ EXTRA epilogue stores while they can still be among the youngest: phases 0-2 after an epilogue)
-        if (!s2) v8_wait_vm<0>();
-        else if (u < 3 && extra) v8_wait_vm<6 + EXTRA>();
+        if (u < 3 && extra) v8_wait_vm<6 + EXTRA>();
         else v8_wait_vm<6>();
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();
@@ -439,7 +436,7 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel_v8(GemmArgs g) {
                 const char* a2 = in2 ? Ab + (int64_t)(kt + 2) * 128 : An + (int64_t)(kt + 2 - nk) * 128;
                 const char* w2 = in2 ? Wb + (int64_t)(kt + 2) * 128 : Wn + (int64_t)(kt + 2 - nk) * 128;
                 v8_tile<T, SWAP, EXTRA>(acc, cur, nxt, a_rd, b_rd, a1, w1, a2, w2, a_off, w_off, a_sub, w_sub, a_dst, w_dst,
-                                        in1 || has_next, in2 || has_next, kt == 0 && after_epilogue);
+                                        kt == 0 && after_epilogue);
             }
         };
         const int mw = m0 + wr * 128, nw = n0 + wc * 64;
@@ -486,6 +483,7 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel_v8(GemmArgs g) {
         Ab = An; Wb = Wn;
         after_epilogue = true;
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the units issued past the last output tile (see v8_tile)
     if (wr == 0) __builtin_amdgcn_s_barrier();
     if constexpr (STAMP) {
         if (lane == 0) { stamp[0] = st_k; stamp[1] = st_e; stamp[2] = st_n; stamp[4] = __builtin_amdgcn_s_memrealtime(); stamp[5] = st_c; }

@@ -74,12 +74,114 @@ __device__ __forceinline__ void gemm_epilogue_rmw(const GemmArgs& g, const f32x4
     }
 }
 
+// Fused-LayerNorm epilogues (gemm8.hip "Fused LayerNorm") for one wave's 64x64 block, direct stores: the 128x128 kernel's
+// versions.  Element for element the arithmetic is the persistent kernel's (v8_epilogue16 / v8_epilogue_resid_ln), so
+// which kernel a batch size selects does not change a single bit of the result.
+template <typename T, int EPI>
+__device__ __forceinline__ void gemm_epilogue_ln(const GemmArgs& g, const f32x4 (&acc)[4][4], int mw, int nw, int l15, int lg) {
+    typedef typename Traits<T>::vec4 vec4_t;
+    if constexpr (EPI == EPI_RESID_SCALE_LN) {
+        f32x4 b4[4], s4[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int n = nw + j * 16 + 4 * lg;
+            b4[j] = g.bias ? *reinterpret_cast<const f32x4*>(g.bias + n) : (f32x4){0.f, 0.f, 0.f, 0.f};
+            s4[j] = *reinterpret_cast<const f32x4*>(g.scale + n);
+        }
+        const int slice = nw >> 6;
+#pragma unroll
+        for (int ih = 0; ih < 2; ++ih) {
+            f32x4 hv[2][4];
+            float* dst[2];
+#pragma unroll
+            for (int ii = 0; ii < 2; ++ii) {
+                const int m = mw + (ih * 2 + ii) * 16 + l15;
+                dst[ii] = g.resid + (int64_t)m * g.ldr + nw + 4 * lg;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) hv[ii][j] = *reinterpret_cast<const f32x4*>(dst[ii] + j * 16);
+            }
+#pragma unroll
+            for (int ii = 0; ii < 2; ++ii) {
+                const int i = ih * 2 + ii;
+                const int m = mw + i * 16 + l15;
+                float sum = 0.f;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    hv[ii][j] = hv[ii][j] + s4[j] * (acc[i][j] + b4[j]);
+                    *reinterpret_cast<f32x4*>(dst[ii] + j * 16) = hv[ii][j];
+                    sum += (hv[ii][j][0] + hv[ii][j][1]) + (hv[ii][j][2] + hv[ii][j][3]);
+                }
+                sum += __shfl_xor(sum, 16, 64);
+                sum += __shfl_xor(sum, 32, 64);
+                const float mean = sum * (1.0f / 64.0f);
+                float m2 = 0.f;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const f32x4 d = hv[ii][j] - mean;
+                    m2 += (d[0] * d[0] + d[1] * d[1]) + (d[2] * d[2] + d[3] * d[3]);
+                }
+                m2 += __shfl_xor(m2, 16, 64);
+                m2 += __shfl_xor(m2, 32, 64);
+                if (lg == 0) *reinterpret_cast<f32x2*>(g.ln_part + ((int64_t)m * 12 + slice) * 2) = (f32x2){mean, m2};
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    *reinterpret_cast<vec4_t*>(reinterpret_cast<T*>(g.ln_hb) + (int64_t)m * g.N + nw + j * 16 + 4 * lg) =
+                        pack4<T>(hv[ii][j][0], hv[ii][j][1], hv[ii][j][2], hv[ii][j][3]);
+            }
+        }
+    } else if constexpr (EPI == EPI_VT_LN) {
+        // lane owns column n, rows m..m+3 (4 consecutive tokens of one image)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int m = mw + i * 16 + 4 * lg;
+            const f32x4 p0 = *reinterpret_cast<const f32x4*>(g.ln_stat + 2 * (int64_t)m);
+            const f32x4 p1 = *reinterpret_cast<const f32x4*>(g.ln_stat + 2 * (int64_t)m + 4);
+            const f32x4 mu = (f32x4){p0[0], p0[2], p1[0], p1[2]}, rs = (f32x4){p0[1], p0[3], p1[1], p1[3]};
+            const int b = m / g.rows_per_image, tok = m - b * g.rows_per_image;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int n = nw + j * 16 + l15;
+                const f32x4 v = (acc[i][j] - mu * g.scale[n]) * rs + g.bias[n];
+                T* o = reinterpret_cast<T*>(g.out) + (((int64_t)b * g.heads_total + (n >> 6)) * 64 + (n & 63)) * g.rows_per_image + tok;
+                *reinterpret_cast<vec4_t*>(o) = pack4<T>(v[0], v[1], v[2], v[3]);
+            }
+        }
+    } else {
+        static_assert(EPI == EPI_HEADS_LN || EPI == EPI_GELU_LN, "fused-LayerNorm consumer epilogues");
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int m = mw + i * 16 + l15;
+            const f32x2 st = *reinterpret_cast<const f32x2*>(g.ln_stat + 2 * (int64_t)m);
+            const int b = m / g.rows_per_image, tok = m - b * g.rows_per_image;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int n = nw + j * 16 + 4 * lg;
+                const f32x4 c1 = *reinterpret_cast<const f32x4*>(g.scale + n), c2 = *reinterpret_cast<const f32x4*>(g.bias + n);
+                f32x4 v = (acc[i][j] - c1 * st[0]) * st[1] + c2;
+                T* o;
+                if constexpr (EPI == EPI_GELU_LN) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = gelu_for<T>(v[e]);
+                    o = reinterpret_cast<T*>(g.out) + (int64_t)m * g.ldo + n;
+                } else {
+                    o = reinterpret_cast<T*>(g.out) + (((int64_t)b * g.heads_total + (n >> 6)) * g.rows_per_image + tok) * 64 + (n & 63);
+                }
+                *reinterpret_cast<vec4_t*>(o) = pack4<T>(v[0], v[1], v[2], v[3]);
+            }
+        }
+    }
+}
+
 // Fused epilogue for one wave's 64x64 accumulator block (4x4 MFMA tiles); (mw, nw) = block origin.
 template <typename T, int EPI>
 __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, const f32x4 (&acc)[4][4], int mw, int nw, int l15, int lg) {
-    constexpr bool SWAP = (EPI != EPI_VT);
+    constexpr bool SWAP = (EPI != EPI_VT && EPI != EPI_VT_LN);
     if constexpr (EPI == EPI_RESID_SCALE || EPI == EPI_RESID_ADD || EPI == EPI_PATCH) {
         gemm_epilogue_rmw<T, EPI>(g, acc, mw, nw, l15, lg);
+        return;
+    }
+    if constexpr (EPI == EPI_RESID_SCALE_LN || EPI == EPI_HEADS_LN || EPI == EPI_VT_LN || EPI == EPI_GELU_LN) {
+        gemm_epilogue_ln<T, EPI>(g, acc, mw, nw, l15, lg);
         return;
     }
 #pragma unroll

@@ -19,6 +19,8 @@ enum Epilogue : int {
     EPI_RESID_SCALE_LN = 9,   // EPI_RESID_SCALE + the next LayerNorm's inputs: ln_hb<T>[m][n] = new resid, ln_part[m][12] = (mean, M2) of 64-column slices
     EPI_QKV_LN = 10,          // EPI_QKV on the UN-normalised operand: (acc - mu[m]*scale[n]) * rstd[m] + bias[n], (mu, rstd) = ln_stat[m]
     EPI_GELU_LN = 11,         // EPI_GELU likewise
+    EPI_HEADS_LN = 12,        // EPI_HEADS / EPI_VT likewise: the two halves of EPI_QKV_LN as separate launches of the 128x128 kernel
+    EPI_VT_LN = 13,           //   (small batches, where the persistent 256x256 kernel would leave CUs idle)
 };
 
 struct GemmArgs {

@@ -288,3 +288,37 @@ def test_gemm_qkv_fused_matches_separate_launches(lib, dt, images, rows):
         finally:
             lib.rz_set_option(b"gemm_variant", 0)
         assert f2.value == 0 and torch.equal(qk, qk2) and torch.equal(vt, vt2)
+
+
+@pytest.mark.parametrize("dt", ["bf16", "f16"])
+@pytest.mark.parametrize("rows,images", [(5376, 8), (1408, 3), (384, 1)])
+def test_fused_layernorm_model_path_matches_standalone(lib, dt, rows, images):
+    """The fused-LayerNorm path (LN folded into the GEMM that follows, statistics + T copy produced by the GEMM that
+    precedes; gemm8.hip) against the stand-alone LayerNorm kernels through the whole vision encoder at reduced depth:
+    same fp32 oracle semantics, two different roundings of the same 16-bit arithmetic -> close to each other at the
+    16-bit noise level, and the choice of GEMM kernel by batch size (persistent 256x256 / 128x128) must not change a bit."""
+    from radzero_amd.config import RadZeroConfig
+    from radzero_amd.modeling import RadZeroModel
+    from radzero_amd.weights import make_state_dict
+    tdt = DT[dt][1]
+    side = {5376: 1024, 1408: 518, 384: 224}[rows]
+    cfg = RadZeroConfig(vit_layers=2, align_layers=1, text_layers=1)
+    m = RadZeroModel.from_state_dict(make_state_dict(cfg, 11), cfg, torch_dtype=tdt, device="cuda:0").eval()
+    try:
+        g = torch.Generator(device="cuda").manual_seed(rows + images)
+        px = torch.randn((images, 3, side, side), generator=g, device="cuda")
+        outs = {}
+        for fused in (1, 0):
+            check(lib, lib.rz_set_option(b"ln_fused", fused))
+            outs[fused] = m.forward_vision_model(px)["vision_tokens"].clone()
+        check(lib, lib.rz_set_option(b"ln_fused", 1))
+        rms = outs[0].pow(2).mean().sqrt().item()
+        rel = (outs[1] - outs[0]).abs().max().item() / rms
+        assert torch.isfinite(outs[1]).all() and rel <= {"bf16": 0.06, "f16": 0.008}[dt], rel
+        # kernel choice by batch size: the first image alone (128x128 kernel) == the first image of the batch
+        if images > 1:
+            one = m.forward_vision_model(px[:1])["vision_tokens"]
+            assert torch.equal(one[0], outs[1][0])
+    finally:
+        lib.rz_set_option(b"ln_fused", 1)
+        m.close()
