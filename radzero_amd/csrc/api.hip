@@ -94,9 +94,9 @@ struct Tensor {          // one packed checkpoint tensor on the device
 struct DinoBlock {       // TF:dinov2/modeling_dinov2.py:342-380
     Tensor ln1_g, ln1_b, wqkv, bqkv, wo, bo, ls1, ln2_g, ln2_b, w1, b1, w2, b2, ls2;   // wqkv: [3D][D] rows q | k | v
     int qkv_parts = 0;   // bit mask of loaded q/k/v weight (1,2,4) and bias (8,16,32) pieces
-    // fused LayerNorm (gemm8.hip): W' = W diag(gamma) in T, c1 = row sums of the rounded W', c2 = W beta + b; built once from
-    // the host copies below (16-bit modes only), which are released afterwards
-    Tensor wqkv_f, c1qkv, c2qkv, w1_f, c1_1, c2_1;
+    // fused LayerNorm (gemm8.hip): c1[n] = sum_k gamma[k] W[n][k] over the ROUNDED weights, c2 = W beta + b; built once from the
+    // host copies below (16-bit modes only), which are released afterwards
+    Tensor c1qkv, c2qkv, c1_1, c2_1;
     std::vector<float> h_wqkv, h_bqkv, h_w1, h_b1, h_g1, h_be1, h_g2, h_be2;
     bool folded = false;
 };
@@ -122,7 +122,7 @@ struct rz_model {
     std::map<std::pair<int, int>, PosTable> pos_tables;
     // workspaces
     int cap_batch = 0, cap_npad = 0, cap_trows = 0, cap_prompts = 0;
-    DevBuf h, xn, qk, vt, ctx, mid, vhat, vws, qhat, lnpart, lnstat;      // xn doubles as the residual's T copy on the fused-LayerNorm path
+    DevBuf h, xn, qk, vt, ctx, mid, vhat, vws, qhat, lnpart, lnstat, lnmu;      // xn doubles as the residual's T copy on the fused-LayerNorm path
     DevBuf th, txn, tqkv, tctx, tmid, tsum;
     // state of the last vision forward
     int last_batch = 0, last_nvalid = 0, last_npad = 0;
@@ -334,31 +334,27 @@ float t_to_f32(int dt, uint16_t v) {
     _Float16 h; memcpy(&h, &v, 2); return (float)h;
 }
 
-// W' = W diag(gamma) rounded to the compute dtype, c1[n] = sum_k W'[n][k] (of the ROUNDED values: the identity
-// LN(x) W^T = rstd (x W'^T - mu c1) + c2 then holds exactly for the weights the MFMAs see), c2 = W beta + b.
+// c1[n] = sum_k gamma[k] T(W[n][k]) (over the weights as the MFMAs see them, so that LN(x) W^T = rstd ((x gamma) W^T - mu c1) + c2
+// holds exactly for them), c2 = W beta + b.
 int fold_matrix(rz_model* m, const std::vector<float>& W, const std::vector<float>& bias, const std::vector<float>& gamma,
-                const std::vector<float>& beta, size_t N, size_t K, Tensor& wf, Tensor& c1, Tensor& c2) {
+                const std::vector<float>& beta, size_t N, size_t K, Tensor& c1, Tensor& c2) {
     if (W.size() != N * K || bias.size() != N || gamma.size() != K || beta.size() != K)
         return fail(RZ_ERR_STATE, "fused LayerNorm packing: host copies of the block's weights are incomplete");
-    std::vector<uint16_t> wt(N * K);
     std::vector<float> v1(N), v2(N);
     for (size_t n = 0; n < N; ++n) {
         double s1 = 0.0, s2 = 0.0;
         for (size_t k = 0; k < K; ++k) {
             const float w = W[n * K + k];
-            const uint16_t r = m->dt == RZ_BF16 ? f32_to_bf16(w * gamma[k]) : f32_to_f16(w * gamma[k]);
-            wt[n * K + k] = r;
-            s1 += (double)t_to_f32(m->dt, r);
+            const float wr = t_to_f32(m->dt, m->dt == RZ_BF16 ? f32_to_bf16(w) : f32_to_f16(w));
+            s1 += (double)wr * (double)gamma[k];
             s2 += (double)w * (double)beta[k];
         }
         v1[n] = (float)s1;
         v2[n] = (float)(s2 + (double)bias[n]);
     }
-    if (!wf.p) { RZ_HIP(hipMalloc(&wf.p, N * K * 2)); m->allocs.push_back(wf.p); }
-    RZ_HIP(hipMemcpy(wf.p, wt.data(), N * K * 2, hipMemcpyHostToDevice));
     RZ_HIP(m->upload(c1, v1.data(), N, false));
     RZ_HIP(m->upload(c2, v2.data(), N, false));
-    wf.loaded = c1.loaded = c2.loaded = true;
+    c1.loaded = c2.loaded = true;
     return 0;
 }
 
@@ -366,8 +362,8 @@ int fold_block(rz_model* m, DinoBlock& b) {
     if (b.folded) return 0;
     const size_t D = m->D, F = m->F;
     int rc;
-    if ((rc = fold_matrix(m, b.h_wqkv, b.h_bqkv, b.h_g1, b.h_be1, 3 * D, D, b.wqkv_f, b.c1qkv, b.c2qkv))) return rc;
-    if ((rc = fold_matrix(m, b.h_w1, b.h_b1, b.h_g2, b.h_be2, F, D, b.w1_f, b.c1_1, b.c2_1))) return rc;
+    if ((rc = fold_matrix(m, b.h_wqkv, b.h_bqkv, b.h_g1, b.h_be1, 3 * D, D, b.c1qkv, b.c2qkv))) return rc;
+    if ((rc = fold_matrix(m, b.h_w1, b.h_b1, b.h_g2, b.h_be2, F, D, b.c1_1, b.c2_1))) return rc;
     for (auto* v : {&b.h_wqkv, &b.h_bqkv, &b.h_w1, &b.h_b1, &b.h_g1, &b.h_be1, &b.h_g2, &b.h_be2}) std::vector<float>().swap(*v);
     b.folded = true;
     return 0;
@@ -388,17 +384,17 @@ int gemm_ln(rz_model* m, int epi, const void* hb, const Tensor& wf, const Tensor
 // residual GEMM that precedes a LayerNorm, fused form: also writes the T copy of the new residual and partial statistics,
 // then the 12 partials per row are merged into (mean, rstd)
 int gemm_resid_ln(rz_model* m, const void* A, int64_t lda, const Tensor& W, const Tensor& bias, const Tensor& ls, int M, int K, float* h,
-                  int np, void* hb, float* part, float* stat, float eps, hipStream_t s) {
+                  int np, const Tensor& next_gamma, void* hb, float* part, float* mu, float* stat, float eps, hipStream_t s) {
     GemmArgs g;
     g.A = A; g.lda = lda; g.W = W.p; g.ldw = K; g.M = M; g.N = m->D; g.K = K; g.bias = (const float*)bias.p; g.out = nullptr; g.ldo = 0;
-    g.scale = (const float*)ls.p; g.resid = h; g.ldr = m->D; g.rows_per_image = np; g.heads_total = 0; g.ln_part = part; g.ln_hb = hb;
+    g.scale = (const float*)ls.p; g.resid = h; g.ldr = m->D; g.rows_per_image = np; g.heads_total = 0; g.ln_part = part; g.ln_hb = hb; g.ln_gamma = (const float*)next_gamma.p; g.ln_mu = mu;
     g.debug_flags = 0;
     {
         ProfScope ps(m, RZ_PROF_GEMM, s);
         RZ_HIP(launch_gemm(m->dt, EPI_RESID_SCALE_LN, g, s));
     }
     ProfScope ps(m, RZ_PROF_ROWOPS, s);
-    RZ_HIP(launch_ln_finalize(part, stat, eps, M, s));
+    RZ_HIP(launch_ln_finalize(part, mu, stat, eps, M, s));
     return 0;
 }
 
@@ -457,7 +453,7 @@ int rz_destroy(rz_handle_t m) {
     (void)hipDeviceSynchronize();        // nothing of this handle may still be in flight when its buffers go away
     for (void* p : m->allocs) (void)hipFree(p);
     for (auto& kv : m->pos_tables) kv.second.buf.release();
-    DevBuf* bufs[] = {&m->h, &m->xn, &m->qk, &m->vt, &m->ctx, &m->mid, &m->vhat, &m->vws, &m->qhat, &m->lnpart, &m->lnstat,
+    DevBuf* bufs[] = {&m->h, &m->xn, &m->qk, &m->vt, &m->ctx, &m->mid, &m->vhat, &m->vws, &m->qhat, &m->lnpart, &m->lnstat, &m->lnmu,
                       &m->th, &m->txn, &m->tqkv, &m->tctx, &m->tmid, &m->tsum};
     for (DevBuf* b : bufs) b->release();
     for (auto& e : m->ev_pool) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
@@ -593,6 +589,7 @@ int rz_reserve(rz_handle_t m, int max_batch, int max_tokens, int max_prompts, in
         if (m->dt != RZ_F32) {
             RZ_HIP(m->lnpart.ensure(rows * 24 * 4, true));
             RZ_HIP(m->lnstat.ensure(rows * 2 * 4, true));
+            RZ_HIP(m->lnmu.ensure(rows * 4, true));
         }
         m->cap_batch = B;
         m->cap_npad = NP;
@@ -666,6 +663,7 @@ int rz_vision_forward(rz_handle_t m, const float* px, int B, int C, int Himg, in
         const bool fused = g_ln_fused && nblocks > 0 && gemm_ln_fused_ok(m->dt, M, D, F);
         float* part = fused ? (float*)m->lnpart.p + row0 * 24 : nullptr;
         float* stat = fused ? (float*)m->lnstat.p + row0 * 2 : nullptr;
+        float* lnmu = fused ? (float*)m->lnmu.p + row0 : nullptr;
         if (fused) {
             for (auto& b : m->blocks)
                 if ((rc = fold_block(m, b))) return rc;
@@ -673,11 +671,11 @@ int rz_vision_forward(rz_handle_t m, const float* px, int B, int C, int Himg, in
         if (m->cfg.vit_layers == 0) {
             // no ViT blocks: Dinov2Model.layernorm (TF:dinov2/modeling_dinov2.py:469) acts on the embeddings, align blocks follow
             ProfScope ps(m, RZ_PROF_ROWOPS, s);
-            if (fused) RZ_HIP(launch_ln_prepare(m->dt, h, (const float*)m->vit_ln_g.p, (const float*)m->vit_ln_b.p, eps, h, xn, stat, eps, M, D, s));
+            if (fused) RZ_HIP(launch_ln_prepare(m->dt, h, (const float*)m->vit_ln_g.p, (const float*)m->vit_ln_b.p, eps, h, (const float*)m->blocks[0].ln1_g.p, xn, lnmu, stat, eps, M, D, s));
             else RZ_HIP(launch_layernorm(m->dt, h, (const float*)m->vit_ln_g.p, (const float*)m->vit_ln_b.p, eps, nullptr, h, M, D, s));
         } else if (fused) {                   // block 0 reads the patch-embedding output: copy + statistics by the row kernel
             ProfScope ps(m, RZ_PROF_ROWOPS, s);
-            RZ_HIP(launch_ln_prepare(m->dt, h, nullptr, nullptr, 0.f, nullptr, xn, stat, eps, M, D, s));
+            RZ_HIP(launch_ln_prepare(m->dt, h, nullptr, nullptr, 0.f, nullptr, (const float*)m->blocks[0].ln1_g.p, xn, lnmu, stat, eps, M, D, s));
         }
         for (int li = 0; li < nblocks; ++li) {
             const DinoBlock& b = m->blocks[li];
@@ -692,15 +690,15 @@ int rz_vision_forward(rz_handle_t m, const float* px, int B, int C, int Himg, in
                 if ((rc = gemm_qkv(m, xn, b, M, np, qkb, vtb, s))) return rc;
             } else {
                 GemmArgs probe;
-                probe.A = xn; probe.lda = D; probe.W = b.wqkv_f.p; probe.ldw = D; probe.M = M; probe.N = 3 * D; probe.K = D; probe.out2 = vtb; probe.split_n = 2 * D;
+                probe.A = xn; probe.lda = D; probe.W = b.wqkv.p; probe.ldw = D; probe.M = M; probe.N = 3 * D; probe.K = D; probe.out2 = vtb; probe.split_n = 2 * D;
                 if (gemm_qkv_fused_ok(m->dt, probe)) {
-                    if ((rc = gemm_ln(m, EPI_QKV_LN, xn, b.wqkv_f, b.c1qkv, b.c2qkv, stat, M, 3 * D, np, qkb, 0, 2 * H, vtb, H, 2 * D, s))) return rc;
+                    if ((rc = gemm_ln(m, EPI_QKV_LN, xn, b.wqkv, b.c1qkv, b.c2qkv, stat, M, 3 * D, np, qkb, 0, 2 * H, vtb, H, 2 * D, s))) return rc;
                 } else {        // small batches: the same projection as q|k and v launches of the 128x128 kernel
-                    Tensor wv = b.wqkv_f, c1v = b.c1qkv, c2v = b.c2qkv;
-                    wv.p = (char*)b.wqkv_f.p + (size_t)2 * D * D * es;
+                    Tensor wv = b.wqkv, c1v = b.c1qkv, c2v = b.c2qkv;
+                    wv.p = (char*)b.wqkv.p + (size_t)2 * D * D * es;
                     c1v.p = (float*)b.c1qkv.p + 2 * D;
                     c2v.p = (float*)b.c2qkv.p + 2 * D;
-                    if ((rc = gemm_ln(m, EPI_HEADS_LN, xn, b.wqkv_f, b.c1qkv, b.c2qkv, stat, M, 2 * D, np, qkb, 0, 2 * H, nullptr, 0, 0, s))) return rc;
+                    if ((rc = gemm_ln(m, EPI_HEADS_LN, xn, b.wqkv, b.c1qkv, b.c2qkv, stat, M, 2 * D, np, qkb, 0, 2 * H, nullptr, 0, 0, s))) return rc;
                     if ((rc = gemm_ln(m, EPI_VT_LN, xn, wv, c1v, c2v, stat, M, D, np, vtb, 0, H, nullptr, 0, 0, s))) return rc;
                 }
             }
@@ -718,7 +716,7 @@ int rz_vision_forward(rz_handle_t m, const float* px, int B, int C, int Himg, in
                     RZ_HIP(launch_layernorm(m->dt, h, (const float*)b.ln2_g.p, (const float*)b.ln2_b.p, eps, xn, nullptr, M, D, s));
                 }
             } else {
-                if ((rc = gemm_resid_ln(m, ctxb, D, b.wo, b.bo, b.ls1, M, D, h, np, xn, part, stat, eps, s))) return rc;
+                if ((rc = gemm_resid_ln(m, ctxb, D, b.wo, b.bo, b.ls1, M, D, h, np, b.ln2_g, xn, part, lnmu, stat, eps, s))) return rc;
             }
             // MLP in row chunks that all reuse the FIRST rows of `mid`: the GELU'd hidden activations of a few images
             // (4 x 5376 x 3072 bf16 = 126 MiB) stay in the 256 MB Infinity Cache between fc1's stores and fc2's loads and
@@ -726,11 +724,11 @@ int rz_vision_forward(rz_handle_t m, const float* px, int B, int C, int Himg, in
             // Measured: tools/kmlp.py 2.05 -> 1.83 ms per layer of 32 images in isolation, but no gain inside the model
             // (372-374 vs 375-376 images/s), so the default is one pass over the whole chunk (option "mlp_chunk").
             if (fused) {
-                if ((rc = gemm_ln(m, EPI_GELU_LN, xn, b.w1_f, b.c1_1, b.c2_1, stat, M, F, np, mid, F, 0, nullptr, 0, 0, s))) return rc;
+                if ((rc = gemm_ln(m, EPI_GELU_LN, xn, b.w1, b.c1_1, b.c2_1, stat, M, F, np, mid, F, 0, nullptr, 0, 0, s))) return rc;
                 if (last || last_vit) {     // nobody reads this block's output through a fused LayerNorm: plain residual epilogue
                     if ((rc = gemm(m, EPI_RESID_SCALE, mid, F, b.w2.p, F, M, D, F, (const float*)b.b2.p, nullptr, 0, (const float*)b.ls2.p, h, D, np, 0, s))) return rc;
                 } else {
-                    if ((rc = gemm_resid_ln(m, mid, F, b.w2, b.b2, b.ls2, M, F, h, np, xn, part, stat, eps, s))) return rc;
+                    if ((rc = gemm_resid_ln(m, mid, F, b.w2, b.b2, b.ls2, M, F, h, np, m->blocks[li + 1].ln1_g, xn, part, lnmu, stat, eps, s))) return rc;
                 }
             } else {
                 for (int i0 = 0; i0 < Bc; i0 += mlp_images) {
@@ -743,7 +741,7 @@ int rz_vision_forward(rz_handle_t m, const float* px, int B, int C, int Himg, in
             if (last_vit) {   // Dinov2Model.layernorm (TF:dinov2/modeling_dinov2.py:469); align blocks follow
                 ProfScope ps(m, RZ_PROF_ROWOPS, s);
                 if (fused && !last)
-                    RZ_HIP(launch_ln_prepare(m->dt, h, (const float*)m->vit_ln_g.p, (const float*)m->vit_ln_b.p, eps, h, xn, stat, eps, M, D, s));
+                    RZ_HIP(launch_ln_prepare(m->dt, h, (const float*)m->vit_ln_g.p, (const float*)m->vit_ln_b.p, eps, h, (const float*)m->blocks[li + 1].ln1_g.p, xn, lnmu, stat, eps, M, D, s));
                 else
                     RZ_HIP(launch_layernorm(m->dt, h, (const float*)m->vit_ln_g.p, (const float*)m->vit_ln_b.p, eps, nullptr, h, M, D, s));
             }

@@ -20,15 +20,18 @@
 //     allows fewer outstanding operations than are really younger is always safe, one that allows more is a race.
 //   * K / 64 must be even and >= 4 (buffer parity restarts at every tile): 640, 768, 3072 on this path.
 // Fused LayerNorm (TF:dinov2/modeling_dinov2.py:348-353 norm1 / norm2 -> :199-213 q|k|v and :281-297 fc1): LN(x) W^T + b
-//   = rstd_m * ( x W'^T - mu_m * c1 ) + c2   with  W' = W diag(gamma),  c1[n] = sum_k W'[n][k],  c2 = W beta + b,
-// so the GEMM that FOLLOWS a LayerNorm multiplies the un-normalised residual (EPI_QKV_LN, EPI_GELU_LN: W', c1, c2 are packed
-// by the host once, per-row (mu, rstd) come in ln_stat), and the GEMM that PRECEDES it (EPI_RESID_SCALE_LN: out-proj, fc2)
-// writes, beside the fp32 residual stream, its copy in the compute dtype and per-row partial statistics of each 64-column
+//   = rstd_m * ( (x gamma) W^T - mu_m * c1 ) + c2   with  c1[n] = sum_k gamma[k] W[n][k],  c2 = W beta + b,
+// so the GEMM that FOLLOWS a LayerNorm multiplies the un-normalised, gain-scaled residual with the block's ordinary weights
+// (EPI_QKV_LN, EPI_GELU_LN: c1, c2 are packed by the host once, per-row (mu, rstd) come in ln_stat), and the GEMM that
+// PRECEDES it (EPI_RESID_SCALE_LN: out-proj, fc2) writes, beside the fp32 residual stream, x gamma in the compute dtype (the
+// gain goes on the activation BEFORE rounding, exactly where the un-fused path applies it: massive-activation channels with
+// small gains are then rounded at their scaled size; it is also centred with the row's PREVIOUS mean, so that the
+// consumer's mu_m is only the small change of the mean and acc - mu_m c1 cannot cancel) and per-row partial statistics of each 64-column
 // slice (two-pass in registers: mean, then M2 about it; merged exactly by Chan's formula in rowops.hip::ln_finalize).  The 29
 // stand-alone LayerNorm passes over the residual stream shrink to two row kernels per forward (before block 0 and the ViT's
 // final LayerNorm).  Accuracy is that of the un-fused 16-bit path as long as |mu| is small against sigma for every token
-// (the operand is rounded relative to |x| instead of |x - mu|): measured identical on the benign and the outlier-channel
-// checkpoints (|mu|/sigma <= 0.12), see DESIGN.md.
+// (the operand is rounded relative to |x gamma| instead of |(x - mu) gamma|): measured identical on the benign and the
+// outlier-channel checkpoints (|mu|/sigma <= 0.12), see DESIGN.md.
 // Tile order: XCD x owns the logical tile ids of xcd_remap's range x; its `grid/8` workgroups take consecutive ids
 // round after round, so the 32 CUs of an XCD always work on one compact GROUP_M x n block of tiles (gemm_common.h).
 #include <type_traits>
@@ -276,12 +279,15 @@ __device__ __forceinline__ void v8_epilogue_resid_ln(const GemmArgs& g, const f3
             m2 += __shfl_xor(m2, 16, 64);
             m2 += __shfl_xor(m2, 32, 64);
             if (lg == 0) *reinterpret_cast<f32x2*>(g.ln_part + ((int64_t)m * 12 + slice) * 2) = (f32x2){mean, m2};
-            // T copy: 16 rows x 64 columns through the wave's LDS image, whole 128-byte row pieces out
+            // T copy, centred with the row's previous mean and scaled by the consuming LayerNorm's gain BEFORE rounding:
+            // 16 rows x 64 columns through the wave's LDS image, whole 128-byte row pieces out
+            const float cm = g.ln_mu[m];
             char* img = wl + (i & 1) * 2048;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int c = j * 2 + (lg >> 1);
-                *reinterpret_cast<vec4_t*>(img + wr_off + ((c ^ (l15 & 7)) << 4)) = pack4<T>(hv[ii][j][0], hv[ii][j][1], hv[ii][j][2], hv[ii][j][3]);
+                const f32x4 gv = (hv[ii][j] - cm) * *reinterpret_cast<const f32x4*>(g.ln_gamma + nw + j * 16 + 4 * lg);
+                *reinterpret_cast<vec4_t*>(img + wr_off + ((c ^ (l15 & 7)) << 4)) = pack4<T>(gv[0], gv[1], gv[2], gv[3]);
             }
             asm volatile("" ::: "memory");
 #pragma unroll
@@ -542,7 +548,7 @@ bool gemm_v8_ok(int dtype, int epi, const GemmArgs& g) {
     if ((int64_t)256 * g.lda * 2 >= ((int64_t)1 << 32) || (int64_t)256 * g.ldw * 2 >= ((int64_t)1 << 32)) return false;
     if ((epi == EPI_QKV || epi == EPI_QKV_LN) && (g.split_n % V8_BN || g.split_n <= 0 || g.split_n >= g.N || !g.out2)) return false;
     if ((epi == EPI_QKV_LN || epi == EPI_GELU_LN) && (!g.ln_stat || !g.scale || !g.bias)) return false;
-    if (epi == EPI_RESID_SCALE_LN && (g.N != 768 || !g.ln_part || !g.ln_hb || !g.scale || !g.resid)) return false;
+    if (epi == EPI_RESID_SCALE_LN && (g.N != 768 || !g.ln_part || !g.ln_hb || !g.ln_gamma || !g.ln_mu || !g.scale || !g.resid)) return false;
     return true;
 }
 

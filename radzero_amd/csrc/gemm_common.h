@@ -123,10 +123,13 @@ __device__ __forceinline__ void gemm_epilogue_ln(const GemmArgs& g, const f32x4 
                 m2 += __shfl_xor(m2, 16, 64);
                 m2 += __shfl_xor(m2, 32, 64);
                 if (lg == 0) *reinterpret_cast<f32x2*>(g.ln_part + ((int64_t)m * 12 + slice) * 2) = (f32x2){mean, m2};
+                const float cm = g.ln_mu[m];
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
+                for (int j = 0; j < 4; ++j) {
+                    const f32x4 gv = (hv[ii][j] - cm) * *reinterpret_cast<const f32x4*>(g.ln_gamma + nw + j * 16 + 4 * lg);
                     *reinterpret_cast<vec4_t*>(reinterpret_cast<T*>(g.ln_hb) + (int64_t)m * g.N + nw + j * 16 + 4 * lg) =
-                        pack4<T>(hv[ii][j][0], hv[ii][j][1], hv[ii][j][2], hv[ii][j][3]);
+                        pack4<T>(gv[0], gv[1], gv[2], gv[3]);
+                }
             }
         }
     } else if constexpr (EPI == EPI_VT_LN) {

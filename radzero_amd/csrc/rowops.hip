@@ -76,7 +76,7 @@ hipError_t launch_layernorm(int dtype, const float* in, const float* gamma, cons
 // ---- fused-LayerNorm support (gemm8.hip "Fused LayerNorm") ----
 // ln_finalize: one thread per row merges the 12 (mean, M2) partials of 64 columns each that EPI_RESID_SCALE_LN wrote
 // (equal counts: mean = average of means, M2 = sum M2_p + 64 * sum (mean_p - mean)^2 — Chan et al., exact) into (mean, rstd).
-__global__ __launch_bounds__(256) void ln_finalize_kernel(const float* __restrict__ part, float* __restrict__ stat, float eps, int64_t rows) {
+__global__ __launch_bounds__(256) void ln_finalize_kernel(const float* __restrict__ part, float* __restrict__ mu_inout, float* __restrict__ stat, float eps, int64_t rows) {
     const int64_t row = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (row >= rows) return;
     const f32x4* p = reinterpret_cast<const f32x4*>(part + row * 24);
@@ -95,22 +95,25 @@ __global__ __launch_bounds__(256) void ln_finalize_kernel(const float* __restric
         dev += d0 * d0 + d1 * d1;
     }
     const float var = (m2 + 64.0f * dev) * (1.0f / 768.0f);
-    *reinterpret_cast<f32x2*>(stat + row * 2) = (f32x2){mean, rsqrtf(var + eps)};
+    // the producer centred its T copy with the row's previous mean: consumers subtract only the remainder
+    *reinterpret_cast<f32x2*>(stat + row * 2) = (f32x2){mean - mu_inout[row], rsqrtf(var + eps)};
+    mu_inout[row] = mean;
 }
 
-hipError_t launch_ln_finalize(const float* part, float* stat, float eps, int64_t rows, hipStream_t s) {
-    if (rows <= 0) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(ln_finalize_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, s, part, stat, eps, rows);
+hipError_t launch_ln_finalize(const float* part, float* mu_inout, float* stat, float eps, int64_t rows, hipStream_t s) {
+    if (rows <= 0 || !mu_inout) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(ln_finalize_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, s, part, mu_inout, stat, eps, rows);
     return hipGetLastError();
 }
 
-// ln_prepare: what a fused-LayerNorm consumer needs of a residual-stream row that no GEMM epilogue produced: its copy in T
-// and (mean, rstd).  With gamma != nullptr the row is first LayerNorm'ed (eps_in) into out_f32 — the ViT's final LayerNorm,
+// ln_prepare: what a fused-LayerNorm consumer needs of a residual-stream row that no GEMM epilogue produced: its copy in T,
+// times the consuming LayerNorm's gain, and (mean, rstd).  With gamma != nullptr the row is first LayerNorm'ed (eps_in) into out_f32 — the ViT's final LayerNorm,
 // whose OUTPUT is the residual stream of the align blocks — and copy / statistics are those of the normalised row.
 template <typename T, int NV>
 __global__ __launch_bounds__(256) void ln_prepare_kernel(const float* __restrict__ in, const float* __restrict__ gamma,
                                                          const float* __restrict__ beta, float eps_in, float* out_f32,
-                                                         T* __restrict__ copy_t, float* __restrict__ stat, float eps_stat, int64_t rows) {
+                                                         const float* __restrict__ copy_gain, T* __restrict__ copy_t,
+                                                         float* __restrict__ mu_out, float* __restrict__ stat, float eps_stat, int64_t rows) {
     constexpr int D = 256 * NV;
     constexpr float invD = 1.0f / D;
     const int lane = threadIdx.x & 63;
@@ -133,19 +136,24 @@ __global__ __launch_bounds__(256) void ln_prepare_kernel(const float* __restrict
         q += (d[0] * d[0] + d[1] * d[1]) + (d[2] * d[2] + d[3] * d[3]);
     }
     const float rstd = rsqrtf(wave_sum(q) * invD + eps_stat);
-    if (lane == 0) *reinterpret_cast<f32x2*>(stat + row * 2) = (f32x2){mu, rstd};
+    if (lane == 0) {            // the copy is centred with the exact mean: nothing left for the consumer to subtract
+        *reinterpret_cast<f32x2*>(stat + row * 2) = (f32x2){0.f, rstd};
+        mu_out[row] = mu;
+    }
 #pragma unroll
-    for (int i = 0; i < NV; ++i)
-        *reinterpret_cast<typename Traits<T>::vec4*>(copy_t + row * D + (lane + 64 * i) * 4) = pack4<T>(r.v[i][0], r.v[i][1], r.v[i][2], r.v[i][3]);
+    for (int i = 0; i < NV; ++i) {
+        const f32x4 gv = (r.v[i] - mu) * *reinterpret_cast<const f32x4*>(copy_gain + (lane + 64 * i) * 4);
+        *reinterpret_cast<typename Traits<T>::vec4*>(copy_t + row * D + (lane + 64 * i) * 4) = pack4<T>(gv[0], gv[1], gv[2], gv[3]);
+    }
 }
 
 hipError_t launch_ln_prepare(int dtype, const float* in, const float* gamma, const float* beta, float eps_in, float* out_f32,
-                             void* copy_t, float* stat, float eps_stat, int64_t rows, int D, hipStream_t s) {
-    if (D != 768 || rows <= 0 || !copy_t || !stat || (gamma && (!beta || !out_f32))) return hipErrorInvalidValue;
+                             const float* copy_gain, void* copy_t, float* mu_out, float* stat, float eps_stat, int64_t rows, int D, hipStream_t s) {
+    if (D != 768 || rows <= 0 || !copy_t || !copy_gain || !stat || !mu_out || (gamma && (!beta || !out_f32))) return hipErrorInvalidValue;
     dim3 grid((unsigned)((rows + 3) / 4)), block(256);
     switch (dtype) {
-        case DT_BF16: hipLaunchKernelGGL((ln_prepare_kernel<bf16_t, 3>), grid, block, 0, s, in, gamma, beta, eps_in, out_f32, (bf16_t*)copy_t, stat, eps_stat, rows); break;
-        case DT_F16: hipLaunchKernelGGL((ln_prepare_kernel<f16_t, 3>), grid, block, 0, s, in, gamma, beta, eps_in, out_f32, (f16_t*)copy_t, stat, eps_stat, rows); break;
+        case DT_BF16: hipLaunchKernelGGL((ln_prepare_kernel<bf16_t, 3>), grid, block, 0, s, in, gamma, beta, eps_in, out_f32, copy_gain, (bf16_t*)copy_t, mu_out, stat, eps_stat, rows); break;
+        case DT_F16: hipLaunchKernelGGL((ln_prepare_kernel<f16_t, 3>), grid, block, 0, s, in, gamma, beta, eps_in, out_f32, copy_gain, (f16_t*)copy_t, mu_out, stat, eps_stat, rows); break;
         default: return hipErrorInvalidValue;
     }
     return hipGetLastError();

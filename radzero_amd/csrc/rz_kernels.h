@@ -16,7 +16,7 @@ enum Epilogue : int {
     EPI_STORE_F32 = 7,    // out_f32[m][n] = acc + bias
     EPI_QKV = 8,          // merged q|k|v projection: columns < split_n as EPI_HEADS into `out`, the rest as EPI_VT into `out2` (gemm8.hip)
     // ---- LayerNorm fused into the GEMMs either side of it (gemm8.hip only; see "Fused LayerNorm" there) ----
-    EPI_RESID_SCALE_LN = 9,   // EPI_RESID_SCALE + the next LayerNorm's inputs: ln_hb<T>[m][n] = new resid, ln_part[m][12] = (mean, M2) of 64-column slices
+    EPI_RESID_SCALE_LN = 9,   // EPI_RESID_SCALE + the next LayerNorm's inputs: ln_hb<T>[m][n] = ln_gamma[n] * new resid, ln_part[m][12] = (mean, M2) of 64-column slices
     EPI_QKV_LN = 10,          // EPI_QKV on the UN-normalised operand: (acc - mu[m]*scale[n]) * rstd[m] + bias[n], (mu, rstd) = ln_stat[m]
     EPI_GELU_LN = 11,         // EPI_GELU likewise
     EPI_HEADS_LN = 12,        // EPI_HEADS / EPI_VT likewise: the two halves of EPI_QKV_LN as separate launches of the 128x128 kernel
@@ -36,9 +36,11 @@ struct GemmArgs {
     void* out2 = nullptr;         // EPI_QKV: transposed-v destination
     int heads_total2 = 0;         // EPI_QKV: heads in `out2`
     int split_n = 0;              // EPI_QKV: first column of the v block (multiple of 256)
-    const float* ln_stat = nullptr;  // EPI_*_LN consumers: [M][2] = (mean, rstd) of every operand row; `scale` = c1[N], `bias` = c2[N]
+    const float* ln_stat = nullptr;  // EPI_*_LN consumers: [M][2] = (mean - centring constant, rstd) of every operand row; `scale` = c1[N], `bias` = c2[N]
     float* ln_part = nullptr;        // EPI_RESID_SCALE_LN: [M][12][2] partial statistics (N must be 768)
-    void* ln_hb = nullptr;           // EPI_RESID_SCALE_LN: [M][N] copy of the new residual in the compute dtype
+    void* ln_hb = nullptr;           // EPI_RESID_SCALE_LN: [M][N] copy of the new residual TIMES ln_gamma[n], in the compute dtype
+    const float* ln_gamma = nullptr; // EPI_RESID_SCALE_LN: gain of the LayerNorm that will consume ln_hb
+    const float* ln_mu = nullptr;    // EPI_RESID_SCALE_LN: [M] centring constant of each row (its mean before this update): ln_hb = T((x - ln_mu[m]) * ln_gamma[n])
     int skew_ticks = 0;           // persistent kernel: start-up stagger period in 10 ns ticks (0 = none), see gemm8.hip
     int debug_flags;              // measurement only: bit0 skip MFMA/ds_read body, bit1 skip W staging, bit2 skip epilogue,
                                   // bit3 force the LDS-staged full-line epilogue, bit4 force the direct epilogue (256x256 kernels)
@@ -72,12 +74,15 @@ hipError_t launch_flash_attn32(int dtype, const void* q, const void* k, const vo
 hipError_t launch_text_attn(int dtype, const void* qkv, const float* rel_bias, const int64_t* attn_mask, void* ctx, int T, int L,
                             int H, hipStream_t s);
 
-// Fused-LayerNorm support (rowops.hip).  ln_finalize: partial statistics [rows][12][2] (mean, M2 of 64-column slices, as
-// EPI_RESID_SCALE_LN writes them) -> stat [rows][2] = (mean, rstd).  ln_prepare: rows of 768 fp32 -> T copy + stat; with
+// Fused-LayerNorm support (rowops.hip).  The T copy of a residual row is CENTRED before rounding: (x - c_m) * gain with c_m a
+// per-row constant close to the row mean (its mean before the last residual update, kept in mu[rows]); consumers get
+// stat [rows][2] = (mean - c_m, rstd).  ln_finalize: partial statistics [rows][12][2] (mean, M2 of 64-column slices, as
+// EPI_RESID_SCALE_LN writes them) + the constant that producer used (mu_inout) -> stat, and mu_inout = the new mean.  ln_prepare: rows of 768 fp32 -> T copy + stat; with
 // gamma/beta != nullptr the row is first LayerNorm'ed in place (out_f32, may alias in) and copy / stat describe the result.
-hipError_t launch_ln_finalize(const float* part, float* stat, float eps, int64_t rows, hipStream_t s);
+// The T copy is multiplied by `copy_gain` (the gain of the LayerNorm that will consume it).
+hipError_t launch_ln_finalize(const float* part, float* mu_inout, float* stat, float eps, int64_t rows, hipStream_t s);
 hipError_t launch_ln_prepare(int dtype, const float* in, const float* gamma, const float* beta, float eps_in, float* out_f32,
-                             void* copy_t, float* stat, float eps_stat, int64_t rows, int D, hipStream_t s);
+                             const float* copy_gain, void* copy_t, float* mu_out, float* stat, float eps_stat, int64_t rows, int D, hipStream_t s);
 
 // LayerNorm over rows of 768: fp32 in; writes T-typed normalized copy (out_t, may be null) and/or
 // fp32 (out_f32, may alias in).
