@@ -120,7 +120,7 @@ def workload_label(B, S, T, dtype, maps, n_tok):
             f"VL-CABS head; text embeddings cached; maps={maps}")
 
 
-def short_run(sd, cfg, device, dtype, B, S, T, maps, min_len, max_len, steps=3, warmup=1):
+def short_run(sd, cfg, device, dtype, B, S, T, maps, min_len, max_len, steps=5, warmup=2):
     """A few steps of another BASELINE config inside the same process (rank 0, N=1 only), so that the driver's clock and
     the JSON line cover it: same timed-region rules as the main workload."""
     from radzero_amd.modeling import RadZeroModel

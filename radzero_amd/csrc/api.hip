@@ -122,7 +122,7 @@ struct rz_model {
     std::map<std::pair<int, int>, PosTable> pos_tables;
     // workspaces
     int cap_batch = 0, cap_npad = 0, cap_trows = 0, cap_prompts = 0;
-    DevBuf h, xn, qk, vt, ctx, mid, vhat, vws, qhat, lnpart, lnstat, lnmu;      // xn doubles as the residual's T copy on the fused-LayerNorm path
+    DevBuf h, xn, qk, vt, ctx, mid, vws, qhat, lnpart, lnstat, lnmu;      // xn doubles as the residual's T copy on the fused-LayerNorm path
     DevBuf th, txn, tqkv, tctx, tmid, tsum;
     // state of the last vision forward
     int last_batch = 0, last_nvalid = 0, last_npad = 0;
@@ -453,7 +453,7 @@ int rz_destroy(rz_handle_t m) {
     (void)hipDeviceSynchronize();        // nothing of this handle may still be in flight when its buffers go away
     for (void* p : m->allocs) (void)hipFree(p);
     for (auto& kv : m->pos_tables) kv.second.buf.release();
-    DevBuf* bufs[] = {&m->h, &m->xn, &m->qk, &m->vt, &m->ctx, &m->mid, &m->vhat, &m->vws, &m->qhat, &m->lnpart, &m->lnstat, &m->lnmu,
+    DevBuf* bufs[] = {&m->h, &m->xn, &m->qk, &m->vt, &m->ctx, &m->mid, &m->vws, &m->qhat, &m->lnpart, &m->lnstat, &m->lnmu,
                       &m->th, &m->txn, &m->tqkv, &m->tctx, &m->tmid, &m->tsum};
     for (DevBuf* b : bufs) b->release();
     for (auto& e : m->ev_pool) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
@@ -585,7 +585,6 @@ int rz_reserve(rz_handle_t m, int max_batch, int max_tokens, int max_prompts, in
         RZ_HIP(m->vt.ensure(rows * D * es, true));
         RZ_HIP(m->ctx.ensure(rows * D * es, true));
         RZ_HIP(m->mid.ensure(rows * std::max(F, (size_t)m->KPAD) * es, true));
-        RZ_HIP(m->vhat.ensure(rows * D * 4, true));
         if (m->dt != RZ_F32) {
             RZ_HIP(m->lnpart.ensure(rows * 24 * 4, true));
             RZ_HIP(m->lnstat.ensure(rows * 2 * 4, true));
@@ -839,7 +838,7 @@ int rz_vlcabs(rz_handle_t m, const float* text_features, int T, int B, float* sc
     RZ_HIP(launch_ln_l2norm(text_features, D, (const float*)m->shared_ln_g.p, (const float*)m->shared_ln_b.p,
                             m->cfg.shared_layer_norm_eps, (float*)m->qhat.p, T, D, s));
     RZ_HIP(launch_vlcabs((const float*)m->h.p, (const float*)m->shared_ln_g.p, (const float*)m->shared_ln_b.p,
-                         m->cfg.shared_layer_norm_eps, (const float*)m->qhat.p, m->tau, (float*)m->vhat.p, (float*)m->vws.p,
+                         m->cfg.shared_layer_norm_eps, (const float*)m->qhat.p, m->tau, (float*)m->vws.p,
                          scores, t2i, logits, B, T, m->last_nvalid, m->last_npad, D, s));
     return 0;
 }

@@ -106,11 +106,11 @@ hipError_t launch_masked_meanpool(const float* h, const int64_t* mask, float* ou
 hipError_t launch_ln_l2norm(const float* in, int64_t ld_in, const float* gamma, const float* beta, float eps,
                             float* out, int64_t rows, int D, hipStream_t s);
 
-// VL-CABS: vhat [B][Npad][D] (LN+L2-normalised tokens), qhat [T][D] -> scores [B][T][N] (= cos/tau),
+// VL-CABS: tokens [B][Npad][D] fp32 (shared LN + L2 normalisation applied inside), qhat [T][D] -> scores [B][T][N] (= cos/tau),
 // t2i_logits [T][B], logits [B][T] (= t2i^T / tau).  ws: float workspace.
 size_t vlcabs_workspace_floats(int B, int T, int n_pad, int D);
 hipError_t launch_vlcabs(const float* tokens, const float* ln_gamma, const float* ln_beta, float ln_eps,
-                         const float* qhat, float tau, float* vhat, float* ws, float* scores, float* t2i_logits,
+                         const float* qhat, float tau, float* ws, float* scores, float* t2i_logits,
                          float* logits, int B, int T, int n_valid, int n_pad, int D, hipStream_t s);
 
 // bilinear upsample (align_corners=False) of patch-grid maps [M][g][g] -> [M][H][W], optional sigmoid;

@@ -1,45 +1,60 @@
 // radzero_hip — VL-CABS head (the reference's own arithmetic: exp/cxr_pt/model/losses.py:71-105 and
 // SimilarityLogit :187-240, final scaling exp/cxr_pt/model/modeling.py:311-328), always in fp32.
 //
-//   vhat  = l2norm(LN_shared(tokens))                     (losses.py:90-91, :213)      [scores kernel]
-//   S     = qhat . vhat / tau                             (losses.py:219-221)          [scores kernel]
-//   p     = softmax_N(S); agg = p . vhat                  (losses.py:222-224)          [partial + finalize]
+//   vhat  = l2norm(LN_shared(tokens))                     (losses.py:90-91, :213)      [vlcabs_kernel, in LDS only]
+//   S     = qhat . vhat / tau                             (losses.py:219-221)          [vlcabs_kernel]
+//   p     = softmax_N(S); agg = p . vhat                  (losses.py:222-224)          [vlcabs_kernel + finalize]
 //   logit = qhat . agg/||agg||                            (losses.py:226-233)          [finalize]
 //
 // Softmax over N tokens is split into 128-token chunks (online-softmax partials m, l, agg[D]) that the
-// finalize kernel merges, so the token tensor is streamed once per stage and nothing of size N x N exists.
+// finalize kernel merges, so the token tensor is streamed once and nothing of size N x N exists.
 // Also: bilinear similarity-map upsample (exp/cxr_pt/inference/segmentation_utils.py:62-70).
 #include "rz_common.h"
 #include "rz_kernels.h"
 
 namespace rz {
 
-constexpr int VC_ROWS = 64;     // token rows per workgroup in the scores kernel
-constexpr int VC_CHUNK = 128;   // token rows per softmax chunk
-constexpr int VC_TG = 16;       // prompts per workgroup in the partial kernel
-
-// ---- scores ----
-// A workgroup handles VC_ROWS token rows in sub-blocks of 16.  Per sub-block: each wave normalises four rows in registers
-// (shared LayerNorm, then L2), writes vhat to global memory and to an LDS tile [16][768] (row stride 772 floats);
-// then S[16 tokens][16 prompts] tiles are computed on the matrix pipe with the exact-fp32 MFMA (v_mfma_f32_16x16x4_f32):
-// A = vhat rows from LDS, B = qhat rows straight from global/L2 (T x 768 fp32, cached), one 16-byte read of each per
-// 16-wide K block feeding four MFMAs.  The former version reduced every (token, prompt) dot product with a 6-step
-// cross-lane sum of its own: 0.50 ms at T=14 and 1.7 ms at T=64 against 0.2 ms of HBM time for tokens + vhat.
+constexpr int VC_CHUNK = 128;   // token rows per workgroup = per softmax chunk
+constexpr int VC_TG = 16;       // prompts per workgroup
 constexpr int VC_LDS_STRIDE = 772;      // floats; 772 mod 64 = 4 spreads the 16 rows of an A-fragment read over the banks
 
-__global__ __launch_bounds__(256) void vlcabs_scores_kernel(const float* __restrict__ tokens, const float* __restrict__ gamma,
-                                                            const float* __restrict__ beta, float eps,
-                                                            const float* __restrict__ qhat, float inv_tau,
-                                                            float* __restrict__ vhat, float* __restrict__ scores, int T,
-                                                            int n_valid, int n_pad) {
+// ---- fused scores + per-chunk online-softmax partials: ws[b][chunk][t] = {m, l, agg[768]} ----
+// One workgroup = (128-token chunk, image, group of 16 prompts), walked as eight 16-token tiles.  Per tile:
+//   1. every wave normalises four token rows in registers (shared LayerNorm, then L2) into an LDS tile [16][768] — the
+//      normalised tokens never go to HBM (the former version wrote 524 MB of them at cfg 2 and read them back once per 16 prompts);
+//   2. S[16 prompts][16 tokens] on the matrix pipe with the exact-fp32 MFMA (v_mfma_f32_16x16x4_f32), K = 768 split over the
+//      four waves and summed through LDS; wave 0 stores S (= cos / tau) as the similarity scores;
+//   3. online softmax over the tiles (running max / sum per prompt, redundantly in every wave), P^T through a wave-private
+//      LDS tile into the A-operand layout;
+//   4. agg[16 prompts][768] += P V on the matrix pipe, each wave owning 192 channels (12 accumulator tiles).
+// Token traffic: each token row is read once per prompt group — from HBM by the first group's workgroup, from L2 / the
+// Infinity Cache by the others (a 128-token chunk is 393 KB; cfg 5 reads its 36 MB of tokens 13 times, on chip).
+__global__ __launch_bounds__(256) void vlcabs_kernel(const float* __restrict__ tokens, const float* __restrict__ gamma,
+                                                     const float* __restrict__ beta, float eps, const float* __restrict__ qhat,
+                                                     float inv_tau, float* __restrict__ ws, float* __restrict__ scores, int T,
+                                                     int n_valid, int n_pad) {
+    constexpr int D = 768, REC = D + 2;
     __shared__ __attribute__((aligned(16))) float vs[16 * VC_LDS_STRIDE];
-    constexpr int D = 768;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    __shared__ float sred[4][16][17];        // [wave][prompt][token]: K-quarter partial scores
+    __shared__ float pT[4][16][17];          // [wave][prompt][token]: wave-private P for the aggregation MFMAs
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l15 = lane & 15, lg = lane >> 4;
-    const int b = blockIdx.y, row0 = blockIdx.x * VC_ROWS;
-    const int ttiles = (T + 15) / 16;
-    for (int sub = 0; sub < VC_ROWS / 16; ++sub) {
-        const int tok0 = row0 + sub * 16;
+    // prompt group fastest: the workgroups that share a token chunk are dispatched together and read it once from HBM
+    const int c = blockIdx.y, b = blockIdx.z, t0 = blockIdx.x * VC_TG;
+    const int nchunks = gridDim.y;
+    // B operand of the score MFMAs: qhat row of prompt t0 + l15 (clamped: rows >= T are computed and dropped)
+    const int tq = t0 + l15;
+    const float* qrow = qhat + (int64_t)(tq < T ? tq : T - 1) * D + 4 * lg;
+    f32x4 acc[12];
+#pragma unroll
+    for (int i = 0; i < 12; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    f32x4 m_run = (f32x4){-INFINITY, -INFINITY, -INFINITY, -INFINITY}, l_run = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    for (int tile = 0; tile < VC_CHUNK / 16; ++tile) {
+        const int tok0 = c * VC_CHUNK + tile * 16;
+        // ---- 1. shared LayerNorm (eps 1e-5, two-pass) + L2 normalisation of 16 token rows -> LDS (rows one after the other:
+        // four rows side by side, or the next tile's rows prefetched under the matrix phases, cost registers = occupancy and
+        // measured slower: 0.39 against 0.33 ms at cfg 2)
 #pragma unroll 1
         for (int rr = 0; rr < 4; ++rr) {
             const int rl = wave * 4 + rr;
@@ -47,11 +62,10 @@ __global__ __launch_bounds__(256) void vlcabs_scores_kernel(const float* __restr
             f32x4 v[3];
 #pragma unroll
             for (int i = 0; i < 3; ++i) v[i] = *reinterpret_cast<const f32x4*>(tokens + row * D + (lane + 64 * i) * 4);
-            // shared LayerNorm (eps 1e-5), two-pass
-            float s = 0.f;
+            float sm = 0.f;
 #pragma unroll
-            for (int i = 0; i < 3; ++i) s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
-            const float mu = wave_sum(s) * (1.0f / D);
+            for (int i = 0; i < 3; ++i) sm += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
+            const float mu = wave_sum(sm) * (1.0f / D);
             float q = 0.f;
 #pragma unroll
             for (int i = 0; i < 3; ++i) {
@@ -62,105 +76,83 @@ __global__ __launch_bounds__(256) void vlcabs_scores_kernel(const float* __restr
             float n2 = 0.f;
 #pragma unroll
             for (int i = 0; i < 3; ++i) {
-                const f32x4 g = *reinterpret_cast<const f32x4*>(gamma + (lane + 64 * i) * 4);
+                const f32x4 gm = *reinterpret_cast<const f32x4*>(gamma + (lane + 64 * i) * 4);
                 const f32x4 be = *reinterpret_cast<const f32x4*>(beta + (lane + 64 * i) * 4);
-                v[i] = v[i] * rstd * g + be;
+                v[i] = v[i] * rstd * gm + be;
                 n2 += (v[i][0] * v[i][0] + v[i][1] * v[i][1]) + (v[i][2] * v[i][2] + v[i][3] * v[i][3]);
             }
             const float inv = 1.0f / fmaxf(sqrtf(wave_sum(n2)), 1e-12f);
 #pragma unroll
-            for (int i = 0; i < 3; ++i) {
-                v[i] *= inv;
-                *reinterpret_cast<f32x4*>(vhat + row * D + (lane + 64 * i) * 4) = v[i];
-                *reinterpret_cast<f32x4*>(vs + rl * VC_LDS_STRIDE + (lane + 64 * i) * 4) = v[i];
-            }
+            for (int i = 0; i < 3; ++i) *reinterpret_cast<f32x4*>(vs + rl * VC_LDS_STRIDE + (lane + 64 * i) * 4) = v[i] * inv;
         }
         __syncthreads();
-        // S tile: D[token 4*lg + r][prompt l15]; K is walked in blocks of 16 (lane (., lg) supplies k = 16*kb + 4*lg + u
-        // for the u-th of four MFMAs: a permuted but consistent K order for both operands)
-        for (int tt = wave; tt < ttiles; tt += 4) {
-            const int t = tt * 16 + l15;
-            const float* qrow = qhat + (int64_t)(t < T ? t : T - 1) * D + 4 * lg;
+        // ---- 2. S^T tile: D[prompt 4*lg + r][token l15], this wave's quarter of K (walked in blocks of 16: lane (., lg)
+        // supplies k = 16*kb + 4*lg + u for the u-th of four MFMAs — a permuted but consistent K order for both operands)
+        {
             const float* arow = vs + l15 * VC_LDS_STRIDE + 4 * lg;
-            f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+            f32x4 sp = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll 4
-            for (int kb = 0; kb < D / 16; ++kb) {
-                const f32x4 av = *reinterpret_cast<const f32x4*>(arow + kb * 16);
-                const f32x4 bv = *reinterpret_cast<const f32x4*>(qrow + kb * 16);
+            for (int kb = wave * 12; kb < wave * 12 + 12; ++kb) {
+                const f32x4 tv = *reinterpret_cast<const f32x4*>(arow + kb * 16);     // token row l15
+                const f32x4 qv = *reinterpret_cast<const f32x4*>(qrow + kb * 16);     // prompt row l15
 #pragma unroll
-                for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u], bv[u], acc, 0, 0, 0);
+                for (int u = 0; u < 4; ++u) sp = __builtin_amdgcn_mfma_f32_16x16x4f32(qv[u], tv[u], sp, 0, 0, 0);
             }
-            if (t < T) {
-                float* o = scores + ((int64_t)b * T + t) * n_valid + tok0 + 4 * lg;
 #pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    if (tok0 + 4 * lg + r < n_valid) o[r] = acc[r] * inv_tau;
-            }
+            for (int r = 0; r < 4; ++r) sred[wave][4 * lg + r][l15] = sp[r];
         }
         __syncthreads();
-    }
-}
-
-// ---- per-chunk online-softmax partials: ws[b][chunk][t] = {m, l, agg[768]} ----
-__global__ __launch_bounds__(256) void vlcabs_partial_kernel(const float* __restrict__ vhat, const float* __restrict__ scores,
-                                                             float* __restrict__ ws, int T, int n_valid, int n_pad) {
-    constexpr int D = 768, REC = D + 2;
-    __shared__ float p[VC_TG][VC_CHUNK];
-    __shared__ float mstat[VC_TG], lstat[VC_TG];
-    const int tid = threadIdx.x;
-    const int c = blockIdx.x, b = blockIdx.y, t0 = blockIdx.z * VC_TG;
-    const int nchunks = gridDim.x;
-    const int row0 = c * VC_CHUNK;
-    // step 1: 16 threads per prompt, 8 rows each
-    {
-        const int tl = tid >> 4, sub = tid & 15;
-        const int t = t0 + tl;
-        float sv[8];
-        float mx = -INFINITY;
+        f32x4 sv;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int tok = row0 + sub + 16 * i;
-            sv[i] = (t < T && tok < n_valid) ? scores[((int64_t)b * T + t) * n_valid + tok] : -INFINITY;
-            mx = fmaxf(mx, sv[i]);
+        for (int r = 0; r < 4; ++r)
+            sv[r] = ((sred[0][4 * lg + r][l15] + sred[1][4 * lg + r][l15]) + (sred[2][4 * lg + r][l15] + sred[3][4 * lg + r][l15])) * inv_tau;
+        const bool live_tok = tok0 + l15 < n_valid;
+        if (wave == 0 && live_tok) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (t0 + 4 * lg + r < T) scores[((int64_t)b * T + t0 + 4 * lg + r) * n_valid + tok0 + l15] = sv[r];
+        }
+        // ---- 3. online softmax over the token tiles (every wave keeps the same running statistics)
+        f32x4 p;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float s = live_tok ? sv[r] : -INFINITY;
+            float tm = s;
+#pragma unroll
+            for (int o = 8; o > 0; o >>= 1) tm = fmaxf(tm, __shfl_xor(tm, o, 64));          // max over the tile's 16 tokens
+            const float mn = fmaxf(m_run[r], tm);
+            const float alpha = (m_run[r] == -INFINITY) ? 0.f : expf(m_run[r] - mn);
+            const float e = (s == -INFINITY) ? 0.f : expf(s - mn);
+            float es = e;
+#pragma unroll
+            for (int o = 8; o > 0; o >>= 1) es += __shfl_xor(es, o, 64);
+            l_run[r] = l_run[r] * alpha + es;
+            m_run[r] = mn;
+            p[r] = e;
+#pragma unroll
+            for (int i = 0; i < 12; ++i) acc[i][r] *= alpha;
         }
 #pragma unroll
-        for (int o = 8; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
-        float sum = 0.f;
+        for (int r = 0; r < 4; ++r) pT[wave][4 * lg + r][l15] = p[r];
+        // same wave, in-order LDS queue: the reads below see the writes above
+        // ---- 4. agg[prompt 4*lg + r][channel wave*192 + 16*i + l15] += sum_token P[prompt][token] vhat[token][channel]
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const float e = (mx == -INFINITY) ? 0.f : expf(sv[i] - mx);
-            p[tl][sub + 16 * i] = e;
-            sum += e;
+        for (int ks = 0; ks < 4; ++ks) {
+            const float a = pT[wave][l15][4 * ks + lg];
+            const float* brow = vs + (4 * ks + lg) * VC_LDS_STRIDE + wave * 192 + l15;
+#pragma unroll
+            for (int i = 0; i < 12; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, brow[i * 16], acc[i], 0, 0, 0);
         }
-#pragma unroll
-        for (int o = 8; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
-        if (sub == 0) { mstat[tl] = mx; lstat[tl] = sum; }
-    }
-    __syncthreads();
-    // step 2: thread owns columns tid, tid+256, tid+512
-    float acc[VC_TG][3];
-#pragma unroll
-    for (int t = 0; t < VC_TG; ++t) acc[t][0] = acc[t][1] = acc[t][2] = 0.f;
-    const float* vb = vhat + ((int64_t)b * n_pad + row0) * D;
-    for (int r = 0; r < VC_CHUNK; ++r) {
-        const float v0 = vb[(int64_t)r * D + tid], v1 = vb[(int64_t)r * D + tid + 256], v2 = vb[(int64_t)r * D + tid + 512];
-#pragma unroll
-        for (int t = 0; t < VC_TG; ++t) {
-            const float pw = p[t][r];
-            acc[t][0] = fmaf(pw, v0, acc[t][0]);
-            acc[t][1] = fmaf(pw, v1, acc[t][1]);
-            acc[t][2] = fmaf(pw, v2, acc[t][2]);
-        }
+        __syncthreads();          // vs and sred are rewritten by the next tile
     }
 #pragma unroll
-    for (int tl = 0; tl < VC_TG; ++tl) {
-        const int t = t0 + tl;
-        if (t >= T) break;
+    for (int r = 0; r < 4; ++r) {
+        const int t = t0 + 4 * lg + r;
+        if (t >= T) continue;
         float* rec = ws + (((int64_t)b * nchunks + c) * T + t) * REC;
-        if (tid == 0) { rec[0] = mstat[tl]; rec[1] = lstat[tl]; }
-        rec[2 + tid] = acc[tl][0];
-        rec[2 + tid + 256] = acc[tl][1];
-        rec[2 + tid + 512] = acc[tl][2];
+        if (wave == 0 && l15 == 0) { rec[0] = m_run[r]; rec[1] = l_run[r]; }
+#pragma unroll
+        for (int i = 0; i < 12; ++i) rec[2 + wave * 192 + i * 16 + l15] = acc[i][r];
     }
 }
 
@@ -207,14 +199,12 @@ size_t vlcabs_workspace_floats(int B, int T, int n_pad, int D) {
 }
 
 hipError_t launch_vlcabs(const float* tokens, const float* ln_gamma, const float* ln_beta, float ln_eps,
-                         const float* qhat, float tau, float* vhat, float* ws, float* scores, float* t2i_logits,
+                         const float* qhat, float tau, float* ws, float* scores, float* t2i_logits,
                          float* logits, int B, int T, int n_valid, int n_pad, int D, hipStream_t s) {
     if (D != 768 || B <= 0 || T <= 0 || n_pad % VC_CHUNK || n_valid > n_pad) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(vlcabs_scores_kernel, dim3(n_pad / VC_ROWS, B), dim3(256), 0, s, tokens, ln_gamma, ln_beta, ln_eps,
-                       qhat, 1.0f / tau, vhat, scores, T, n_valid, n_pad);
     const int nchunks = n_pad / VC_CHUNK;
-    hipLaunchKernelGGL(vlcabs_partial_kernel, dim3(nchunks, B, (T + VC_TG - 1) / VC_TG), dim3(256), 0, s, vhat, scores, ws, T,
-                       n_valid, n_pad);
+    hipLaunchKernelGGL(vlcabs_kernel, dim3((T + VC_TG - 1) / VC_TG, nchunks, B), dim3(256), 0, s, tokens, ln_gamma, ln_beta, ln_eps,
+                       qhat, 1.0f / tau, ws, scores, T, n_valid, n_pad);
     hipLaunchKernelGGL(vlcabs_finalize_kernel, dim3(T, B), dim3(256), 0, s, ws, qhat, tau, t2i_logits, logits, T, B, nchunks);
     return hipGetLastError();
 }

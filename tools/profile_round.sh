@@ -1,0 +1,27 @@
+#!/bin/bash
+# GPU box: the profiling passes whose summaries are committed under profiles/<round>/ (run from the repo root via gpurun):
+#   bash tools/profile_round.sh r02
+# 1. rocprofv3 --kernel-trace --stats of the default bench command           -> kernel_stats.csv (+ the bench line it printed)
+# 2. two --pmc passes (FETCH_SIZE, WRITE_SIZE: they do not fit one pass)      -> HBM bytes per launch (tools/pmc_summary.py)
+# 3. one --pmc pass of SQ / GRBM counters                                     -> MFMA busy, VALU active, wait fractions, clock
+# Counter passes carry --kernel-trace only (no other trace domain), and python3 is the program after `--`.
+set -e -o pipefail
+R=${1:-r02}
+OUT=gpurun_out/prof_$R
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp && cd - > /dev/null
+BENCH="python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-other-configs"
+PMCB="python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-other-configs --no-kernel-events"
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- $BENCH > $OUT/bench_under_rocprof.json 2> $OUT/trace.err
+echo "[profile] kernel trace done"
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- $PMCB > $OUT/pmc_fetch.json 2> $OUT/pmc_fetch.err
+echo "[profile] FETCH_SIZE pass done"
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- $PMCB > $OUT/pmc_write.json 2> $OUT/pmc_write.err
+echo "[profile] WRITE_SIZE pass done"
+rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU --output-format csv -d $OUT/pmc_sq -- $PMCB > $OUT/pmc_sq.json 2> $OUT/pmc_sq.err
+echo "[profile] SQ pass done"
+python3 bench.py --steps 20 --warmup 5 > $OUT/bench_default.json 2> $OUT/bench_default.err
+python3 tools/pmc_summary.py $R $OUT
+# drop the bulky per-dispatch traces, keep the summaries (gpurun merges <= 64 MiB back)
+find $OUT -name "*kernel_trace.csv" -size +20M -delete || true
+ls -la $OUT | head -30
