@@ -433,7 +433,14 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel_v8(GemmArgs g) {
 
         auto k_loop = [&](auto swap_c) {
             constexpr bool SWAP = decltype(swap_c)::value;
-            for (int kt = 0; kt < nk; ++kt) {
+            // K tile 0 apart (its waits may allow the epilogue's stores: run-time flag), then the steady loop with the flag a
+            // compile-time false: no branch between the MFMAs and the counted wait.  The merged q|k|v kernels hold both operand
+            // orders of this loop; a second call site each made hipcc spill, so they keep the flag inside one loop.
+            constexpr bool PEEL = !(EPI == EPI_QKV || EPI == EPI_QKV_LN);
+            if constexpr (PEEL)
+                v8_tile<T, SWAP, EXTRA>(acc, lds, lds + V8_STAGE, a_rd, b_rd, Ab + 128, Wb + 128, Ab + 256, Wb + 256, a_off, w_off, a_sub,
+                                        w_sub, a_dst, w_dst, after_epilogue);
+            for (int kt = PEEL ? 1 : 0; kt < nk; ++kt) {
                 char* cur = lds + (kt & 1) * V8_STAGE;
                 char* nxt = lds + ((kt + 1) & 1) * V8_STAGE;
                 const bool in1 = kt + 1 < nk, in2 = kt + 2 < nk;
@@ -442,7 +449,7 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel_v8(GemmArgs g) {
                 const char* a2 = in2 ? Ab + (int64_t)(kt + 2) * 128 : An + (int64_t)(kt + 2 - nk) * 128;
                 const char* w2 = in2 ? Wb + (int64_t)(kt + 2) * 128 : Wn + (int64_t)(kt + 2 - nk) * 128;
                 v8_tile<T, SWAP, EXTRA>(acc, cur, nxt, a_rd, b_rd, a1, w1, a2, w2, a_off, w_off, a_sub, w_sub, a_dst, w_dst,
-                                        kt == 0 && after_epilogue);
+                                        PEEL ? false : (kt == 0 && after_epilogue));
             }
         };
         const int mw = m0 + wr * 128, nw = n0 + wc * 64;
