@@ -19,6 +19,11 @@ class RadZeroConfig:
     pretrain_image_size: int = 224          # pos-embed grid = (224//14)^2 = 16x16 (dinov2-base-xray-224)
     vit_layers: int = 12
     vit_layer_norm_eps: float = 1e-6
+    # how the stored position grid is resized to another resolution (one-time host op, modeling.interpolate_pos_encoding):
+    # "size" = F.interpolate(size=(gh, gw)) — transformers >= 4.45 (and the 5.x the goldens were generated with);
+    # "scale_factor_0p1" = the pinned transformers 4.39.3 form, scale_factor=((gh + 0.1)/g0, (gw + 0.1)/g0): source coordinates differ by
+    # up to ~0.05 grid cells.  The reference pins 4.39.3 (requirements.txt:247); pick this to reproduce THAT environment.
+    pos_embed_interpolation: str = "size"
     # --- align transformer (radzero.yaml:29-34): Dinov2Encoder, no final LN ---
     align_layers: int = 2
     # --- text encoder: MPNet (text_encoders.py:13-14) ---

@@ -27,9 +27,15 @@ def _ptr(t: Optional[torch.Tensor]):
     return ctypes.c_void_p(t.data_ptr()) if t is not None else None
 
 
-def interpolate_pos_encoding(position_embeddings: torch.Tensor, grid_h: int, grid_w: int) -> torch.Tensor:
+def interpolate_pos_encoding(position_embeddings: torch.Tensor, grid_h: int, grid_w: int, mode: str = "size") -> torch.Tensor:
     """One-time host op per resolution: bicubic resize of the stored patch position grid, CLS kept
-    (TF:dinov2/modeling_dinov2.py:57-95).  Returns (1 + grid_h*grid_w, D) fp32 on the CPU."""
+    (TF:dinov2/modeling_dinov2.py:57-95).  Returns (1 + grid_h*grid_w, D) fp32 on the CPU.
+
+    mode "size": `F.interpolate(size=(gh, gw))`, what transformers >= 4.45 (incl. the 5.x installed here, which generated the
+    goldens) does.  mode "scale_factor_0p1": the form of the reference's PINNED transformers 4.39.3 (requirements.txt:247) —
+    `scale_factor=((gh + 0.1) / g0, (gw + 0.1) / g0)`, i.e. the same output size but source coordinates scaled by
+    g0 / (g + 0.1) instead of g0 / g (restated from the published 4.39 source; that version is not installed here, so this
+    branch is pinned only by its own properties in tests/test_checkpoint_cpu.py).  The kernels take the finished table either way."""
     pe = position_embeddings.detach().float().cpu()
     if pe.dim() == 3:
         pe = pe[0]
@@ -39,7 +45,14 @@ def interpolate_pos_encoding(position_embeddings: torch.Tensor, grid_h: int, gri
         return pe.contiguous()
     d = pe.shape[-1]
     grid = pe[1:].reshape(1, g0, g0, d).permute(0, 3, 1, 2)
-    grid = F.interpolate(grid, size=(grid_h, grid_w), mode="bicubic", align_corners=False)
+    if mode == "size":
+        grid = F.interpolate(grid, size=(grid_h, grid_w), mode="bicubic", align_corners=False)
+    elif mode == "scale_factor_0p1":
+        grid = F.interpolate(grid, scale_factor=((grid_h + 0.1) / g0, (grid_w + 0.1) / g0), mode="bicubic", align_corners=False)
+        if tuple(grid.shape[-2:]) != (grid_h, grid_w):
+            raise ValueError("Width or height does not match with the interpolated position embeddings")   # 4.39.3's own check
+    else:
+        raise ValueError(f"unknown pos_embed_interpolation {mode!r}")
     grid = grid.permute(0, 2, 3, 1).reshape(grid_h * grid_w, d)
     return torch.cat([pe[:1], grid], dim=0).contiguous()
 
@@ -212,7 +225,7 @@ class RadZeroModel:
         if (gh, gw) not in self._grids:
             if self._pos_embed is None:
                 raise _lib.RzError("weights not loaded")
-            table = interpolate_pos_encoding(self._pos_embed, gh, gw).numpy()
+            table = interpolate_pos_encoding(self._pos_embed, gh, gw, self.config.pos_embed_interpolation).numpy()
             torch.cuda.synchronize(self._device)
             _lib.check(self._lib.rz_set_position_table(self._h, gh, gw, table.ctypes.data_as(ctypes.c_void_p)),
                        "rz_set_position_table")
