@@ -322,7 +322,8 @@ def main():
             res["other_configs"] = [
                 short_run(sd, cfg, device, "bf16", 16, 1024, 64, "upsample", 8, 32),
                 short_run(sd, cfg, device, "f16", 1, 1536, 193, "none", 6, 16),
-                short_run(sd, cfg, device, "f32", 32, 1024, 14, "none", 6, 10, steps=2),
+                short_run(sd, cfg, device, "f16", 32, 1024, 14, "none", 6, 10),      # the <= 5e-3 16-bit mode on the headline shape
+                short_run(sd, cfg, device, "f32", 32, 1024, 14, "none", 6, 10, steps=2, warmup=1),      # the 1e-3 mode
             ]
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(cfg, sd, S, T, ids, mask)
