@@ -551,6 +551,9 @@ int rz_weights_ready(rz_handle_t m) {
         if ((rc = need(ok, "MPNetLayer " + std::to_string(i)))) return rc;
     }
     if ((rc = need(m->shared_ln_g.loaded && m->shared_ln_b.loaded && m->tau_loaded, "loss_fns.RadZeroLoss"))) return rc;
+    if (m->dt != RZ_F32)        // one-time packing of the fused-LayerNorm vectors (c1, c2): here, so that no forward call allocates
+        for (auto& b : m->blocks)
+            if ((rc = fold_block(m, b))) return rc;
     return 0;
 }
 
