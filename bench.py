@@ -182,6 +182,7 @@ def main():
     ap.add_argument("--min-len", type=int, default=6)
     ap.add_argument("--max-len", type=int, default=10)
     ap.add_argument("--force-dist", action="store_true", help="rehearsal: initialise the RCCL process group even with one rank")
+    ap.add_argument("--host-pixels", action="store_true", help="measurement only (never the headline): pixels start in pinned host memory and cross PCIe inside every step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true")
     ap.add_argument("--no-other-configs", action="store_true", help="skip the short runs of BASELINE configs[3], configs[4] per-GPU shape and the fp32 mode")
@@ -244,8 +245,11 @@ def main():
     torch.cuda.synchronize()
     text_ms = (time.time() - t0) * 1e3
 
+    host_pixels = pixels.cpu().pin_memory() if args.host_pixels else None
+
     def step():
-        out = model.compute_logits(pixels, [enc], text_features=text_features)
+        px = host_pixels.to(device, non_blocking=True) if host_pixels is not None else pixels
+        out = model.compute_logits(px, [enc], text_features=text_features)
         if args.maps == "upsample":      # (B, T, S, S) fp32 per-pixel maps (interpolate_similarity_scores semantics)
             out["similarity_maps"] = model.upsample_similarity(out["similarity_scores"], (S, S))
         elif args.maps == "points":      # fused upsample + argmax (get_grounding_point semantics), map never written
@@ -295,6 +299,8 @@ def main():
             "frac_of_mfma_peak_whole_path": round(ips * f_img / 1e12 / (PEAK_TFLOPS[args.dtype] * world), 4),
             "text_encode_once_ms": round(text_ms, 2),
         }
+        if args.host_pixels:
+            res["config"]["workload"] += "; PIXELS FROM PINNED HOST MEMORY EVERY STEP (PCIe-inclusive: not the headline number)"
         if prof is not None and prof["attn"]["launches"] > 0:
             # dominant kernel: flash attention (54 % of the algorithmic FLOPs at 1024^2).
             # algorithmic FLOPs per launch = B images x 4*N^2*D (QK^T + PV over all 12 heads), SURVEY.md §8(d)
