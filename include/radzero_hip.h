@@ -166,7 +166,7 @@ int rz_flash_attention(int dtype, const void* q_dev, const void* k_dev, const vo
  *   "gemm_v1_only"     1 = same as gemm_variant 1
  *   "gemm_debug_flags" bit 2 skip the epilogue, bit 3 per-wave fp32 LDS epilogue, bit 4 direct epilogue, bit 6 skip the K loop
  *   "attn_variant"     0/1 default (16x16x32 MFMA, 4 waves x 32 query rows, row sums on the matrix pipe) | 16 same with VALU
- *                      row sums | 8 eight waves | 64 / 264 / 464 64 query rows per wave | 2 / 3 32x32x16 MFMA kernel
+ *                      row sums | 8 eight waves | 64 / 264 / 464 64 query rows per wave
  *   "ln_fused"         1 (default) = the blocks' LayerNorms are fused into the GEMMs either side of them where the persistent
  *                      kernel applies (16-bit modes, >= 2 images of 1024^2); 0 = stand-alone LayerNorm kernels everywhere
  *   "vision_chunk"     images per internal pass of rz_vision_forward (0 = whole batch)

@@ -25,7 +25,6 @@ int fail(int code, const std::string& msg) {
 }
 // 0 = auto (= 1: measured fastest in bench.py, 1000 TFLOP/s); 1 = 16x16x32 kernel, 4 waves/128 q rows; 8 = same kernel, 8 waves/256 q rows;
 // 64 = 16x16x32 kernel, 4 waves x 64 q rows (4 q tiles per wave);
-// 2 = 32x32x16 kernel, 2-stage ring; 3 = 32x32x16 kernel, 3-stage ring; 4 = 32x32x16 software-pipelined (16-bit only)
 int g_vision_chunk = 0;   // images per pass of rz_vision_forward (0 = whole batch)
 int g_vision_streams = 1; // 2 = split the batch over two internal HIP streams
 int g_mlp_chunk = 0;      // images per fc1->fc2 pass (0 = whole batch = default, -1 = auto ~126 MiB of hidden rows): run_chunk in rz_vision_forward
@@ -34,7 +33,6 @@ int g_ln_fused = 1;       // 1 = fuse the blocks' LayerNorms into the GEMMs eith
 
 hipError_t flash_attn(int dt, const void* q, const void* k, const void* vt, void* ctx, int64_t bs, int B, int H, int nv, int np,
                       hipStream_t s) {
-    if (g_attn_variant == 2 || g_attn_variant == 3) return launch_flash_attn32(dt, q, k, vt, ctx, bs, B, H, nv, np, g_attn_variant, s);
     return launch_flash_attn(dt, q, k, vt, ctx, bs, B, H, nv, np, (g_attn_variant == 8 || g_attn_variant == 64 || g_attn_variant == 264 || g_attn_variant == 16 || g_attn_variant == 464) ? g_attn_variant : 4, s);
 }
 

@@ -373,6 +373,7 @@ hipError_t launch_flash_attn(int dtype, const void* q, const void* k, const void
     int qt = 2;
     // default shape (4 waves x 32 query rows): row sums on the matrix pipe; "16" = same shape with VALU row sums (A/B)
     const bool ls = (waves == 4 || waves == 416);
+    const bool force_ls = (waves == 416);
     if (waves == 416 || waves == 16) waves = 4;
     const bool ls4 = (waves == 464);                                     // "464": 4 waves x 64 query rows, row sums on the matrix pipe
     if (waves == 64 || waves == 464) { waves = 4; qt = 4; }              // "64": 4 waves x 64 query rows
@@ -386,7 +387,9 @@ hipError_t launch_flash_attn(int dtype, const void* q, const void* k, const void
 #define RZ_FA_LS(TT) hipLaunchKernelGGL((flash_attn_kernel<TT, 4, 2, true>), grid, block, 0, s, (const TT*)q, (const TT*)k, \
                                         (const TT*)vT, (TT*)ctx, qk_batch_stride, B, H, n_valid, n_pad)
     switch (dtype) {
-        case DT_F32: if (ls) RZ_FA_LS(float); else RZ_FA(float, 4, 2); break;
+        // fp32 operands: the ones-row sums cost 8 exact-f32 MFMAs per tile and push the kernel to one wave per SIMD; VALU sums measured
+        // 119-129 against 110 TFLOP/s (the 16-bit default stays on the matrix pipe)
+        case DT_F32: if (ls && force_ls) RZ_FA_LS(float); else RZ_FA(float, 4, 2); break;
         case DT_BF16: if (ls) RZ_FA_LS(bf16_t); else if (ls4 && qt == 4) hipLaunchKernelGGL((flash_attn_kernel<bf16_t, 4, 4, true>), grid, block, 0, s, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)vT, (bf16_t*)ctx, qk_batch_stride, B, H, n_valid, n_pad); else if (waves == 8) RZ_FA(bf16_t, 8, 2); else if (waves == 2) RZ_FA(bf16_t, 2, 4); else if (qt == 4) RZ_FA(bf16_t, 4, 4); else RZ_FA(bf16_t, 4, 2); break;
         case DT_F16: if (ls) RZ_FA_LS(f16_t); else if (waves == 8) RZ_FA(f16_t, 8, 2); else if (waves == 2) RZ_FA(f16_t, 2, 4); else if (qt == 4) RZ_FA(f16_t, 4, 4); else RZ_FA(f16_t, 4, 2); break;
         default: return hipErrorInvalidValue;

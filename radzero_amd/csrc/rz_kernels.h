@@ -65,10 +65,6 @@ hipError_t launch_gemm_v7(int variant, int dtype, int epi, const GemmArgs& g, hi
 hipError_t launch_flash_attn(int dtype, const void* q, const void* k, const void* vT, void* ctx,
                              int64_t qk_batch_stride, int B, int H, int n_valid, int n_pad, int waves, hipStream_t s);
 
-// Same contract, 32x32x16-MFMA formulation (attention32.hip) — the default; launch_flash_attn is kept for A/B.
-hipError_t launch_flash_attn32(int dtype, const void* q, const void* k, const void* vT, void* ctx,
-                               int64_t qk_batch_stride, int B, int H, int n_valid, int n_pad, int ring, hipStream_t s);
-
 // MPNet self-attention for short sequences: qkv [T*L][3*H*64] (q|k|v), additive relative-position bias expanded by the
 // host to rel_bias[H][L][L], key-padding mask [T][L]; ctx [T*L][H*64].
 hipError_t launch_text_attn(int dtype, const void* qkv, const float* rel_bias, const int64_t* attn_mask, void* ctx, int T, int L,

@@ -84,7 +84,7 @@ def _attn_ref(q, k, v):
     return torch.einsum("bhqk,bhkd->bhqd", torch.softmax(s, -1), v)
 
 
-@pytest.fixture(params=[1, 16, 8, 64, 264, 2, 3], ids=["mfma16", "mfma16valuRowSums", "mfma16x8waves", "mfma16x64rows", "mfma16x2wavesx64rows", "mfma32", "mfma32ring3"])
+@pytest.fixture(params=[1, 16, 8, 64, 264], ids=["mfma16", "mfma16valuRowSums", "mfma16x8waves", "mfma16x64rows", "mfma16x2wavesx64rows"])
 def attn_variant(request, lib):
     """Both flash-attention kernels (32x32x16 default, 16x16x32) must pass every attention test."""
     lib.rz_set_option(b"attn_variant", request.param)
