@@ -164,7 +164,6 @@ int rz_flash_attention(int dtype, const void* q_dev, const void* k_dev, const vo
  *                      | 8 the same K loop as a persistent kernel, one workgroup per CU (16-bit, gemm8.hip; default for big shapes)
  *                      | 9 = 7 with in-kernel s_memtime stamps (EPI_STORE only; stamps land in the `resid_dev` buffer)
  *   "gemm_v1_only"     1 = same as gemm_variant 1
- *   "gemm_debug_flags" bit 2 skip the epilogue, bit 3 per-wave fp32 LDS epilogue, bit 4 direct epilogue, bit 6 skip the K loop
  *   "attn_variant"     0/1 default (16x16x32 MFMA, 4 waves x 32 query rows, row sums on the matrix pipe) | 16 same with VALU
  *                      row sums | 8 eight waves | 64 / 264 / 464 64 query rows per wave
  *   "ln_fused"         1 (default) = the blocks' LayerNorms are fused into the GEMMs either side of them where the persistent

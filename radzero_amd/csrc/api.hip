@@ -373,7 +373,7 @@ int gemm_ln(rz_model* m, int epi, const void* hb, const Tensor& wf, const Tensor
     GemmArgs g;
     g.A = hb; g.lda = m->D; g.W = wf.p; g.ldw = m->D; g.M = M; g.N = N; g.K = m->D; g.bias = (const float*)c2.p; g.out = out; g.ldo = ldo;
     g.scale = (const float*)c1.p; g.resid = nullptr; g.ldr = 0; g.rows_per_image = np; g.heads_total = heads;
-    g.out2 = out2; g.heads_total2 = heads2; g.split_n = split_n; g.ln_stat = stat; g.debug_flags = 0;
+    g.out2 = out2; g.heads_total2 = heads2; g.split_n = split_n; g.ln_stat = stat;
     ProfScope ps(m, RZ_PROF_GEMM, s);
     RZ_HIP(launch_gemm(m->dt, epi, g, s));
     return 0;
@@ -386,7 +386,7 @@ int gemm_resid_ln(rz_model* m, const void* A, int64_t lda, const Tensor& W, cons
     GemmArgs g;
     g.A = A; g.lda = lda; g.W = W.p; g.ldw = K; g.M = M; g.N = m->D; g.K = K; g.bias = (const float*)bias.p; g.out = nullptr; g.ldo = 0;
     g.scale = (const float*)ls.p; g.resid = h; g.ldr = m->D; g.rows_per_image = np; g.heads_total = 0; g.ln_part = part; g.ln_hb = hb; g.ln_gamma = (const float*)next_gamma.p; g.ln_mu = mu;
-    g.debug_flags = 0;
+   
     {
         ProfScope ps(m, RZ_PROF_GEMM, s);
         RZ_HIP(launch_gemm(m->dt, EPI_RESID_SCALE_LN, g, s));
@@ -401,7 +401,7 @@ int gemm_qkv(rz_model* m, const void* xn, const DinoBlock& b, int M, int np, voi
     GemmArgs g;
     g.A = xn; g.lda = D; g.W = b.wqkv.p; g.ldw = D; g.M = M; g.N = 3 * D; g.K = D; g.bias = (const float*)b.bqkv.p;
     g.out = qk; g.ldo = 0; g.scale = nullptr; g.resid = nullptr; g.ldr = 0; g.rows_per_image = np; g.heads_total = 2 * H;
-    g.out2 = vt; g.heads_total2 = H; g.split_n = 2 * D; g.debug_flags = 0;
+    g.out2 = vt; g.heads_total2 = H; g.split_n = 2 * D;
     if (gemm_qkv_fused_ok(m->dt, g)) {
         ProfScope ps(m, RZ_PROF_GEMM, s);
         RZ_HIP(launch_gemm(m->dt, EPI_QKV, g, s));
@@ -903,7 +903,7 @@ int rz_gemm(int dtype, int epilogue, const void* a, const void* w, const float* 
     memset(&g, 0, sizeof g);
     g.A = a; g.lda = K; g.W = w; g.ldw = K; g.M = M; g.N = N; g.K = K; g.bias = bias; g.out = out; g.ldo = N;
     g.rows_per_image = M;
-    g.debug_flags = 0;
+   
     RZ_HIP(launch_gemm(dtype, epilogue, g, (hipStream_t)stream));
     return 0;
 }
@@ -934,7 +934,7 @@ int rz_gemm_qkv(int dtype, const void* x, const void* w, const float* bias, void
     GemmArgs g;
     g.A = x; g.lda = D; g.W = w; g.ldw = D; g.M = M; g.N = 3 * D; g.K = D; g.bias = bias; g.out = qk; g.ldo = 0;
     g.scale = nullptr; g.resid = nullptr; g.ldr = 0; g.rows_per_image = rows_per_image; g.heads_total = 2 * heads;
-    g.out2 = vt; g.heads_total2 = heads; g.split_n = 2 * D; g.debug_flags = 0;
+    g.out2 = vt; g.heads_total2 = heads; g.split_n = 2 * D;
     const bool fused = gemm_qkv_fused_ok(dtype, g);
     if (fused_out) *fused_out = fused ? 1 : 0;
     if (fused) {
@@ -975,7 +975,6 @@ int rz_set_option(const char* name, int value) {
     if (!name) return fail(RZ_ERR_INVALID, "rz_set_option: null name");
     if (!strcmp(name, "gemm_v1_only")) { gemm_force_v1(value != 0); return 0; }
     if (!strcmp(name, "gemm_variant")) { gemm_set_variant(value); return 0; }
-    if (!strcmp(name, "gemm_debug_flags")) { gemm_set_debug_flags(value); return 0; }
     if (!strcmp(name, "gemm_skew")) { gemm_set_skew(value); return 0; }
     if (!strcmp(name, "vision_chunk")) { g_vision_chunk = value; return 0; }
     if (!strcmp(name, "vision_streams")) { g_vision_streams = value; return 0; }

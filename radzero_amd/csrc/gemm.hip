@@ -143,7 +143,7 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel_v3(GemmArgs g) {
         for (int i = 0; i < 4; ++i) {
             const int row8 = (wave * 4 + i) * 8;
             glds_rows8(sa + row8 * 128, ga, lda_b, row8, lane);
-            if (!(g.debug_flags & 2)) glds_rows8(sb + row8 * 128, gb, ldw_b, row8, lane);
+            glds_rows8(sb + row8 * 128, gb, ldw_b, row8, lane);
         }
     };
 
@@ -162,7 +162,6 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel_v3(GemmArgs g) {
         if (kt + 1 < nk) stage(kt + 1, buf ^ 1);
         const char* sa = lds + buf * STAGE3_BYTES;
         const char* sb = sa + BM2 * 128;
-        if (!(g.debug_flags & 1))
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
             frag_t fa[8], fb[4];
@@ -181,14 +180,12 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel_v3(GemmArgs g) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
     }
-    if (g.debug_flags & 4) return;      // measurement only: no epilogue
     const f32x4 (&lo)[4][4] = *reinterpret_cast<const f32x4 (*)[4][4]>(&acc[0]);
     const f32x4 (&hi)[4][4] = *reinterpret_cast<const f32x4 (*)[4][4]>(&acc[4]);
-    // default: LDS-staged 16-byte stores for the 16-bit row-major / per-head / transposed outputs (+9..15 % on those GEMMs),
-    // direct epilogue for GELU (VALU-bound) and the fp32 residual read-modify-write (equal within noise).
-    // debug bit3 forces the LDS-staged epilogue everywhere, bit4 the direct one everywhere.
-    constexpr bool kLdsDefault = sizeof(T) == 2 && (EPI == EPI_STORE || EPI == EPI_HEADS || EPI == EPI_VT);
-    if ((g.debug_flags & 16) || (!kLdsDefault && !(g.debug_flags & 8))) {
+    // LDS-staged 16-byte stores for the 16-bit row-major / per-head / transposed outputs (+9..15 % on those GEMMs),
+    // direct epilogue for GELU (VALU-bound) and the fp32 outputs / residual read-modify-write (equal within noise).
+    constexpr bool kLds = sizeof(T) == 2 && (EPI == EPI_STORE || EPI == EPI_HEADS || EPI == EPI_VT);
+    if constexpr (!kLds) {
         gemm_epilogue<T, EPI>(g, lo, m0 + wm * 128, n0 + wn * 64, l15, lg);
         gemm_epilogue<T, EPI>(g, hi, m0 + wm * 128 + 64, n0 + wn * 64, l15, lg);
         return;
@@ -199,8 +196,6 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel_v3(GemmArgs g) {
     gemm_epilogue_lds<T, EPI>(g, hi, wlds, m0 + wm * 128 + 64, n0 + wn * 64, lane);
 }
 
-static int g_debug_flags = 0;
-void gemm_set_debug_flags(int f) { g_debug_flags = f; }
 static int g_skew = 0;
 void gemm_set_skew(int t) { g_skew = t; }
 static int g_variant = 0;      // 0 = auto, 1/2/3 = force that kernel where its shape constraints hold
@@ -281,7 +276,6 @@ static hipError_t launch_gemm_t(int epi, const GemmArgs& g, hipStream_t s) {
 
 hipError_t launch_gemm(int dtype, int epi, const GemmArgs& g_in, hipStream_t s) {
     GemmArgs g = g_in;
-    g.debug_flags = g_debug_flags;
     if (g_skew) g.skew_ticks = g_skew;
     if (g.M <= 0 || g.N <= 0 || g.K <= 0) return hipErrorInvalidValue;
     if (g.M % BM || g.N % BN) return hipErrorInvalidValue;

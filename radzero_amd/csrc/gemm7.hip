@@ -173,7 +173,7 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel_v7(GemmArgs g) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) acc[a][i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    if (!(g.debug_flags & 64)) {        // measurement only (bit 6): skip the K loop, epilogue of zeros
+    {
     // prologue: K tile 0 complete in buffer 0; U0, U1 of tile 1 on their way into buffer 1 (nk >= 2)
 #pragma unroll
     for (int e = 0; e < 2; ++e) {
@@ -230,27 +230,15 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel_v7(GemmArgs g) {
     }
     if (wr == 0) __builtin_amdgcn_s_barrier();
     }
-    if (g.debug_flags & 4) return;      // measurement only: no epilogue
-
     const int mw = m0 + wr * 128, nw = n0 + wc * 64;
-    // 16-bit row-major outputs: whole-tile staging (gemm_common.h); debug bit 3 = per-wave fp32 staging, bit 4 = direct
+    // 16-bit row-major outputs: whole-tile staging (gemm_common.h); everything else straight from the accumulators
     if constexpr (EPI == EPI_STORE || EPI == EPI_GELU || EPI == EPI_HEADS || EPI == EPI_VT) {
-        if (!(g.debug_flags & 24)) {
-            __syncthreads();            // every wave is past its last operand read: LDS is free
-            gemm_epilogue_tile16<T, EPI>(g, acc, lds, m0, n0, wr, wc, lane, tid);
-            return;
-        }
-    }
-    constexpr bool kLdsDefault = (EPI == EPI_STORE || EPI == EPI_HEADS || EPI == EPI_VT);
-    if ((g.debug_flags & 16) || (!kLdsDefault && !(g.debug_flags & 8))) {
+        __syncthreads();            // every wave is past its last operand read: LDS is free
+        gemm_epilogue_tile16<T, EPI>(g, acc, lds, m0, n0, wr, wc, lane, tid);
+    } else {
         gemm_epilogue<T, EPI>(g, acc[0], mw, nw, l15, lg);
         gemm_epilogue<T, EPI>(g, acc[1], mw + 64, nw, l15, lg);
-        return;
     }
-    __syncthreads();                    // every wave is past its last operand read: LDS is free
-    char* wlds = lds + wave * (64 * 256);
-    gemm_epilogue_lds<T, EPI>(g, acc[0], wlds, mw, nw, lane);
-    gemm_epilogue_lds<T, EPI>(g, acc[1], wlds, mw + 64, nw, lane);
 }
 
 template <typename T>

@@ -42,13 +42,10 @@ struct GemmArgs {
     const float* ln_gamma = nullptr; // EPI_RESID_SCALE_LN: gain of the LayerNorm that will consume ln_hb
     const float* ln_mu = nullptr;    // EPI_RESID_SCALE_LN: [M] centring constant of each row (its mean before this update): ln_hb = T((x - ln_mu[m]) * ln_gamma[n])
     int skew_ticks = 0;           // persistent kernel: start-up stagger period in 10 ns ticks (0 = none), see gemm8.hip
-    int debug_flags;              // measurement only: bit0 skip MFMA/ds_read body, bit1 skip W staging, bit2 skip epilogue,
-                                  // bit3 force the LDS-staged full-line epilogue, bit4 force the direct epilogue (256x256 kernels)
 };
 
 hipError_t launch_gemm(int dtype, int epi, const GemmArgs& g, hipStream_t s);
 void gemm_force_v1(bool on);   // A/B switch: use only the 128x128 two-stage kernel
-void gemm_set_debug_flags(int f);
 void gemm_v8_set_stamp_buffer(void* dev_u64);   // diagnostic: non-null => the stamped build of the persistent kernel writes 256 x 8 x 32 u64 there
 void gemm_set_skew(int ticks);  // experiment: start-up stagger of the persistent kernel (gemm8.hip), 10 ns ticks per full period
 void gemm_set_variant(int v);  // 0 auto, 1 = 128x128 two-stage, 3 = 256x256 two-stage, 7 = 256x256 staggered 8-phase (gemm7.hip), 8 = persistent (gemm8.hip), 9 = 7 + in-kernel stamps

@@ -158,14 +158,11 @@ if __name__ == "__main__":
     ap.add_argument("--v1", action="store_true")
     ap.add_argument("--variant", type=int, default=0)
     ap.add_argument("--attn-variant", type=int, default=0)
-    ap.add_argument("--gemm-debug", type=int, default=0)
     ap.add_argument("--zeros", action="store_true")
     ap.add_argument("--skew", type=int, default=0, help="persistent GEMM start-up stagger period, 10 ns ticks")
     a = ap.parse_args()
     if a.v1:
         lib.rz_set_option(b"gemm_v1_only", 1)
-    if a.gemm_debug:
-        lib.rz_set_option(b"gemm_debug_flags", a.gemm_debug)
     if a.attn_variant:
         lib.rz_set_option(b"attn_variant", a.attn_variant)
     if a.variant:
