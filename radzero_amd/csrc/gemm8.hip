@@ -149,17 +149,27 @@ __device__ __forceinline__ void v8_epilogue16(const GemmArgs& g, void* out, int 
     const int l15 = lane & 15, lg = lane >> 4;
     f32x4 b4[4], c4[4];      // per column block: bias (LNF: c2) and, LNF only, c1
     float bv[4], cv[4];
+    // LNF: the wave's 128 (mean, rstd) pairs and its 64 c1 / c2 values were put into the upper half of its LDS region by
+    // v8_prefetch_ln one tile ago (LDS-DMA, retired by the K loop's counted waits long before this point), so this epilogue
+    // issues no global load at all and never has to drain the operand units that are in flight for the next tile.
+    const float* lst = reinterpret_cast<const float*>(wl + 2048);          // [128][2]
+    const float* lc1 = reinterpret_cast<const float*>(wl + 3072);          // [64]
+    const float* lc2 = lc1 + 64;                                           // [64]
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         b4[j] = c4[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
         bv[j] = cv[j] = 0.f;
-        if (g.bias) {
+        if constexpr (LNF) {
+            if constexpr (SWAP) {
+                b4[j] = *reinterpret_cast<const f32x4*>(lc2 + j * 16 + 4 * lg);
+                c4[j] = *reinterpret_cast<const f32x4*>(lc1 + j * 16 + 4 * lg);
+            } else {
+                bv[j] = lc2[j * 16 + l15];
+                cv[j] = lc1[j * 16 + l15];
+            }
+        } else if (g.bias) {
             if constexpr (SWAP) b4[j] = *reinterpret_cast<const f32x4*>(g.bias + nw + j * 16 + 4 * lg);
             else bv[j] = g.bias[nw + j * 16 + l15];
-        }
-        if constexpr (LNF) {
-            if constexpr (SWAP) c4[j] = *reinterpret_cast<const f32x4*>(g.scale + nw + j * 16 + 4 * lg);
-            else cv[j] = g.scale[nw + j * 16 + l15];
         }
     }
     // LNF: (mean, rstd) of the operand rows this lane's accumulators belong to
@@ -171,10 +181,10 @@ __device__ __forceinline__ void v8_epilogue16(const GemmArgs& g, void* out, int 
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 if constexpr (SWAP) {
-                    st_row[a][i] = *reinterpret_cast<const f32x2*>(g.ln_stat + 2 * (int64_t)(mw + a * 64 + i * 16 + l15));
+                    st_row[a][i] = *reinterpret_cast<const f32x2*>(lst + 2 * (a * 64 + i * 16 + l15));
                 } else {
-                    const f32x4 p0 = *reinterpret_cast<const f32x4*>(g.ln_stat + 2 * (int64_t)(mw + a * 64 + i * 16 + 4 * lg));
-                    const f32x4 p1 = *reinterpret_cast<const f32x4*>(g.ln_stat + 2 * (int64_t)(mw + a * 64 + i * 16 + 4 * lg) + 4);
+                    const f32x4 p0 = *reinterpret_cast<const f32x4*>(lst + 2 * (a * 64 + i * 16 + 4 * lg));
+                    const f32x4 p1 = *reinterpret_cast<const f32x4*>(lst + 2 * (a * 64 + i * 16 + 4 * lg) + 4);
                     st_mu[a][i] = (f32x4){p0[0], p0[2], p1[0], p1[2]};
                     st_rs[a][i] = (f32x4){p0[1], p0[3], p1[1], p1[3]};
                 }
@@ -183,7 +193,7 @@ __device__ __forceinline__ void v8_epilogue16(const GemmArgs& g, void* out, int 
     const unsigned wr_off = (unsigned)(l15 * 128 + (lg & 1) * 8);
 #pragma unroll
     for (int grp = 0; grp < 8; ++grp) {
-        char* img = wl + (grp & 1) * 2048;
+        char* img = wl + (LNF ? 0 : (grp & 1) * 2048);        // LNF: one staging image, the other 2 KB hold the prefetched vectors
         const int a = SWAP ? (grp >> 2) : (grp & 1);
         const int x = SWAP ? (grp & 3) : (grp >> 1);          // SWAP: i (row block);  VT: j (feature block)
 #pragma unroll
@@ -302,6 +312,18 @@ __device__ __forceinline__ void v8_epilogue_resid_ln(const GemmArgs& g, const f3
     }
 }
 
+// Fused-LayerNorm consumers: what the epilogue of the tile at (mw, nw) will need besides the accumulators — the 128 (mean, rstd)
+// pairs of this wave's rows (1 KB, contiguous in ln_stat) and its 64 c1 and 64 c2 values — goes into the upper 2 KB of the
+// wave's LDS region by two LDS-DMA instructions, issued one tile ahead (workgroup prologue / end of the previous epilogue).
+__device__ __forceinline__ void v8_prefetch_ln(const GemmArgs& g, char* wl, int mw, int nw, int lane) {
+    const char* s0 = reinterpret_cast<const char*>(g.ln_stat + 2 * (int64_t)mw) + lane * 16;
+    // lanes 0-15: c1[nw ..], 16-31: c2[nw ..] (= g.scale / g.bias), lanes 32-63 repeat them into the 512 bytes behind
+    const float* vec = (lane & 16) ? g.bias : g.scale;
+    const char* s1 = reinterpret_cast<const char*>(vec + nw) + (lane & 15) * 16;
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)s0, (__attribute__((address_space(3))) void*)(wl + 2048), 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)s1, (__attribute__((address_space(3))) void*)(wl + 3072), 16, 0, 0);
+}
+
 template <int EPI> struct V8Epi {
     // 16-byte stores a wave issues LAST in this epilogue (nothing but stores after them), halved: see header
     static constexpr int kExtra = (EPI == EPI_RESID_SCALE || EPI == EPI_RESID_SCALE_LN || EPI == EPI_RESID_ADD || EPI == EPI_PATCH || EPI == EPI_STORE_F32) ? 16 : 8;
@@ -398,6 +420,8 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel_v8(GemmArgs g) {
     const char* Ab = reinterpret_cast<const char*>(g.A) + (int64_t)m0 * lda_b;
     const char* Wb = reinterpret_cast<const char*>(g.W) + (int64_t)n0 * ldw_b;
 
+    constexpr bool LN_CONSUMER = (EPI == EPI_QKV_LN || EPI == EPI_GELU_LN);
+    if constexpr (LN_CONSUMER) v8_prefetch_ln(g, wl, m0 + wr * 128, n0 + wc * 64, lane);      // oldest in the queue: retired by the prologue wait
     // prologue (once per workgroup): K tile 0 complete in buffer 0; U0, U1 of K tile 1 on their way into buffer 1
 #pragma unroll
     for (int e = 0; e < 2; ++e) {
@@ -485,6 +509,10 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel_v8(GemmArgs g) {
         }
         __builtin_amdgcn_sched_barrier(0);
         if (!has_next) break;
+        if constexpr (LN_CONSUMER) {       // the epilogue above has read its vectors: fetch the next tile's (youngest in the queue)
+            v8_prefetch_ln(g, wl, m1 + wr * 128, n1 + wc * 64, lane);
+            __builtin_amdgcn_sched_barrier(0);
+        }
 #pragma unroll
         for (int a = 0; a < 2; ++a)
 #pragma unroll
