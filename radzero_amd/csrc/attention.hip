@@ -71,7 +71,13 @@ __device__ __forceinline__ typename Traits<T>::frag lds_frag_row(const char* til
 // tile, every lane then holds l of its own query in all four registers) instead of 32 v_add_f32 per wave and tile — the
 // kernel is bound by VALU / MFMA ISSUE slots (VALU active 67 %, MFMA busy 45 %, issue-stalled 45 % of wave cycles,
 // profiles/r01/mfma_utilisation_pmc.json), and the matrix pipe has room.  l then sums the T-rounded P that also feeds PV.
-template <typename T, int NW, int QT, bool LS = false>
+// NOMAX = no running maximum in the hot loop (bf16 / f32 operands): softmax is scale free in floating point, so the reference point
+// fixed by tile 0 (its true row maximum) stays valid until some 2^(s - m) or a sum of them leaves the f32 / bf16 range, i.e. a later
+// score exceeds tile 0's maximum by > ~100 in log2 units.  That cannot be ruled out, so the kernel checks l and O for inf / nan when
+// the loop is done and, if any row of the workgroup overflowed, runs the whole loop again with the tracking path (16 v_max3 +
+// the vote per tile come out of the hot loop: the kernel is bound by vector ISSUE slots).  f16 operands keep the tracking path: P <= 65504 means the
+// second pass already triggers at s - m > 16, which random scores reach often enough to cost more than the maxima (927 against 997 TFLOP/s).
+template <typename T, int NW, int QT, bool LS = false, bool NOMAX = false>
 __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : (QT == 4 ? 2 : RZ_FA_WAVES)) void flash_attn_kernel(const T* __restrict__ q, const T* __restrict__ k,
                                                             const T* __restrict__ vT, T* __restrict__ ctx,
                                                             int64_t qk_batch_stride, int B, int H, int n_valid, int n_pad) {
@@ -81,8 +87,10 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : (QT == 4 ? 2 : RZ_FA_WAVES))
     constexpr int TILE = FaCfg<T>::TILE_BYTES;
     constexpr int ES = (int)sizeof(T);
     __shared__ __attribute__((aligned(1024))) char lds[4 * TILE];   // K0 K1 V0 V1
+    __shared__ int overflowed;                                      // NOMAX: some row of this workgroup left the float range
 
     const int tid = threadIdx.x, lane = tid & 63;
+    if (NOMAX && tid == 0) overflowed = 0;                          // ordered before its readers by the loop's barriers
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // provably uniform: LDS-DMA bases go to M0 by SALU only
     const int l15 = lane & 15, lg = lane >> 4;
 
@@ -174,8 +182,9 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : (QT == 4 ? 2 : RZ_FA_WAVES))
     for (int a = 0; a < QT; ++a) { mrow[a] = 0.f; lrow[a] = 0.f; cinit[a] = (f32x4){0.f, 0.f, 0.f, 0.f}; lacc[a] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
 
     // one KV tile.  FIRST: tile 0 (establishes the reference point).  MASK: ragged last tile (keys >= n_valid dead).
-    auto tile = [&](int t, auto first_c, auto mask_c) {
+    auto tile = [&](int t, auto first_c, auto mask_c, auto track_c) {
         constexpr bool FIRST = decltype(first_c)::value, MASK = decltype(mask_c)::value;
+        constexpr bool TRACK = FIRST || decltype(track_c)::value;    // running maximum + re-centring in this tile
         const int buf = t & 1;
         const char* sk = lds + buf * TILE;
         const char* sv = lds + (2 + buf) * TILE;
@@ -239,6 +248,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : (QT == 4 ? 2 : RZ_FA_WAVES))
         // "any row above the threshold", so the hot path carries no cross-lane step (the ds_bpermute pairs and their
         // lgkmcnt(0) waits used to sit between the score MFMAs and the exponentials of every tile).
         float mx[QT];
+        if constexpr (TRACK) {
 #pragma unroll
         for (int qt = 0; qt < QT; ++qt) {
             // plain fmaxf chains: hipcc fuses them into v_max3_f32 (this file is built with -fno-honor-nans, so no
@@ -252,6 +262,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : (QT == 4 ? 2 : RZ_FA_WAVES))
             m0 = fmaxf(fmaxf(m0, sacc[qt][2][3]), sacc[qt][3][0]);
             m0 = fmaxf(fmaxf(m0, sacc[qt][3][1]), sacc[qt][3][2]);
             mx[qt] = fmaxf(m0, sacc[qt][3][3]);
+        }
         }
         auto row_max = [&](float m0) {
             m0 = fmaxf(m0, __shfl_xor(m0, 16, 64));
@@ -267,7 +278,8 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : (QT == 4 ? 2 : RZ_FA_WAVES))
 #pragma unroll
                 for (int kt = 0; kt < 4; ++kt) sacc[qt][kt] -= mx[qt];
             }
-        } else if (__builtin_expect(__any((QT == 4 ? fmaxf(fmaxf(mx[0], mx[1]), fmaxf(mx[QT - 2], mx[QT - 1])) : fmaxf(mx[0], mx[1])) > FA_DEFER), 0)) {
+        } else if constexpr (TRACK) {
+        if (__builtin_expect(__any((QT == 4 ? fmaxf(fmaxf(mx[0], mx[1]), fmaxf(mx[QT - 2], mx[QT - 1])) : fmaxf(mx[0], mx[1])) > FA_DEFER), 0)) {
             asm volatile("" ::: "memory");   // keeps hipcc from if-converting the rare path into the hot one
 #pragma unroll
             for (int qt = 0; qt < QT; ++qt) {
@@ -282,6 +294,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : (QT == 4 ? 2 : RZ_FA_WAVES))
                 for (int dt = 0; dt < 4; ++dt) oacc[qt][dt] *= alpha;
             }
             asm volatile("" ::: "memory");
+        }
         }
         // ---- P = 2^S', row sums, pack P^T fragments ----
         frag_t pf[QT][2];
@@ -330,20 +343,49 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : (QT == 4 ? 2 : RZ_FA_WAVES))
     const int ntiles = (n_valid + FA_KEYS - 1) / FA_KEYS;
     const bool ragged = (n_valid % FA_KEYS) != 0;
     const int nplain = ragged ? ntiles - 1 : ntiles;     // tiles [0, nplain) need no masking
-    stage(0, 0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (ntiles > 1) stage(1, 1);
-    if (nplain >= 1) tile(0, TrueT{}, FalseT{}); else tile(0, TrueT{}, TrueT{});
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    for (int t = 1; t < nplain; ++t) {
-        if (t + 1 < ntiles) stage(t + 1, (t + 1) & 1);
-        tile(t, FalseT{}, FalseT{});
+    auto run = [&](auto track_c) {
+        stage(0, 0);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
+        if (ntiles > 1) stage(1, 1);
+        if (nplain >= 1) tile(0, TrueT{}, FalseT{}, track_c); else tile(0, TrueT{}, TrueT{}, track_c);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        for (int t = 1; t < nplain; ++t) {
+            if (t + 1 < ntiles) stage(t + 1, (t + 1) & 1);
+            tile(t, FalseT{}, FalseT{}, track_c);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+        }
+        if (ragged && ntiles > 1) tile(ntiles - 1, FalseT{}, TrueT{}, track_c);
+    };
+    if constexpr (NOMAX) {
+        run(FalseT{});
+        // inf / nan anywhere in l or O (bit test: this file is built with -fno-honor-nans)?
+        auto left_range = [](float x) { return (__float_as_uint(x) & 0x7f800000u) == 0x7f800000u; };
+        bool bad = false;
+#pragma unroll
+        for (int qt = 0; qt < QT; ++qt) {
+            bad |= left_range(LS ? lacc[qt][0] : lrow[qt]);
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) bad |= left_range(oacc[qt][dt][r]);
+        }
+        if (__any(bad) && lane == 0) overflowed = 1;
+        __syncthreads();                                 // also: every wave is done with the K / V buffers
+        if (__builtin_expect(overflowed != 0, 0)) {      // workgroup-uniform: the waves share the staging and its barriers
+#pragma unroll
+            for (int a = 0; a < QT; ++a) {
+                mrow[a] = 0.f; lrow[a] = 0.f; cinit[a] = (f32x4){0.f, 0.f, 0.f, 0.f}; lacc[a] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int c = 0; c < 4; ++c) oacc[a][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            }
+            run(TrueT{});
+        }
+    } else {
+        run(TrueT{});
     }
-    if (ragged && ntiles > 1) tile(ntiles - 1, FalseT{}, TrueT{});
 
     // ---- epilogue: O = O^T / l, ctx[(b*n_pad + q)][h*64 + d] ----
 #pragma unroll
@@ -372,9 +414,10 @@ hipError_t launch_flash_attn(int dtype, const void* q, const void* k, const void
     if (n_pad % FA_QROWS || n_valid <= 0 || n_valid > n_pad || B <= 0 || H <= 0) return hipErrorInvalidValue;
     int qt = 2;
     // default shape (4 waves x 32 query rows): row sums on the matrix pipe; "16" = same shape with VALU row sums (A/B)
-    const bool ls = (waves == 4 || waves == 416);
+    const bool ls = (waves == 4 || waves == 416 || waves == 417);
     const bool force_ls = (waves == 416);
-    if (waves == 416 || waves == 16) waves = 4;
+    const bool track = (waves == 417);                                   // "417": default shape WITH the running maximum in the hot loop (A/B)
+    if (waves == 416 || waves == 417 || waves == 16) waves = 4;
     const bool ls4 = (waves == 464);                                     // "464": 4 waves x 64 query rows, row sums on the matrix pipe
     if (waves == 64 || waves == 464) { waves = 4; qt = 4; }              // "64": 4 waves x 64 query rows
     if (waves == 264) { waves = 2; qt = 4; }                             // "264": 2 waves x 64 query rows (128-row q blocks)
@@ -390,7 +433,7 @@ hipError_t launch_flash_attn(int dtype, const void* q, const void* k, const void
         // fp32 operands: the ones-row sums cost 8 exact-f32 MFMAs per tile and push the kernel to one wave per SIMD; VALU sums measured
         // 119-129 against 110 TFLOP/s (the 16-bit default stays on the matrix pipe)
         case DT_F32: if (ls && force_ls) RZ_FA_LS(float); else RZ_FA(float, 4, 2); break;
-        case DT_BF16: if (ls) RZ_FA_LS(bf16_t); else if (ls4 && qt == 4) hipLaunchKernelGGL((flash_attn_kernel<bf16_t, 4, 4, true>), grid, block, 0, s, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)vT, (bf16_t*)ctx, qk_batch_stride, B, H, n_valid, n_pad); else if (waves == 8) RZ_FA(bf16_t, 8, 2); else if (waves == 2) RZ_FA(bf16_t, 2, 4); else if (qt == 4) RZ_FA(bf16_t, 4, 4); else RZ_FA(bf16_t, 4, 2); break;
+        case DT_BF16: if (ls && !track) hipLaunchKernelGGL((flash_attn_kernel<bf16_t, 4, 2, true, true>), grid, block, 0, s, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)vT, (bf16_t*)ctx, qk_batch_stride, B, H, n_valid, n_pad); else if (ls) RZ_FA_LS(bf16_t); else if (ls4 && qt == 4) hipLaunchKernelGGL((flash_attn_kernel<bf16_t, 4, 4, true>), grid, block, 0, s, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)vT, (bf16_t*)ctx, qk_batch_stride, B, H, n_valid, n_pad); else if (waves == 8) RZ_FA(bf16_t, 8, 2); else if (waves == 2) RZ_FA(bf16_t, 2, 4); else if (qt == 4) RZ_FA(bf16_t, 4, 4); else RZ_FA(bf16_t, 4, 2); break;
         case DT_F16: if (ls) RZ_FA_LS(f16_t); else if (waves == 8) RZ_FA(f16_t, 8, 2); else if (waves == 2) RZ_FA(f16_t, 2, 4); else if (qt == 4) RZ_FA(f16_t, 4, 4); else RZ_FA(f16_t, 4, 2); break;
         default: return hipErrorInvalidValue;
     }
