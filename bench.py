@@ -153,6 +153,20 @@ def short_run(sd, cfg, device, dtype, B, S, T, maps, min_len, max_len, steps=5, 
         model.profile(False)
         assert bool(torch.isfinite(out["logits"]).all())
         ips = B * steps / dt
+        graph_ips = None
+        if B == 1 and maps == "none":
+            # latency-bound shape: the same step replayed as ONE hipGraph (RadZeroModel.make_graphed), pixels copied into the
+            # graph's static input inside the timed region
+            run = model.make_graphed(px.shape, [enc])
+            for _ in range(warmup):
+                run(px)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                gout = run(px)
+            torch.cuda.synchronize()
+            graph_ips = B * steps / (time.perf_counter() - t0)
+            assert bool(torch.isfinite(gout["logits"]).all())
         f_img = flops_per_image(cfg, S, T)
         attn_ms = prof["attn"]["ms"] / max(1, prof["attn"]["launches"])
         attn_tf = B * attention_flops_per_image_layer(cfg, S) / (attn_ms * 1e-3) / 1e12 if attn_ms > 0 else None
@@ -161,6 +175,7 @@ def short_run(sd, cfg, device, dtype, B, S, T, maps, min_len, max_len, steps=5, 
                 "model_tflops_per_s": round(ips * f_img / 1e12, 2),
                 "frac_of_mfma_peak_whole_path": round(ips * f_img / 1e12 / PEAK_TFLOPS[dtype], 4),
                 "attention_tflops_per_s": None if attn_tf is None else round(attn_tf, 1),
+                **({} if graph_ips is None else {"images_per_s_hipgraph_replay": round(graph_ips, 3)}),
                 "kernel_family_ms_per_step": {k: round(v["ms"] / steps, 3) for k, v in prof.items()}}
     finally:
         model.close()
