@@ -33,7 +33,7 @@ int g_ln_fused = 1;       // 1 = fuse the blocks' LayerNorms into the GEMMs eith
 
 hipError_t flash_attn(int dt, const void* q, const void* k, const void* vt, void* ctx, int64_t bs, int B, int H, int nv, int np,
                       hipStream_t s) {
-    return launch_flash_attn(dt, q, k, vt, ctx, bs, B, H, nv, np, (g_attn_variant == 8 || g_attn_variant == 64 || g_attn_variant == 264 || g_attn_variant == 16 || g_attn_variant == 464 || g_attn_variant == 417) ? g_attn_variant : 4, s);
+    return launch_flash_attn(dt, q, k, vt, ctx, bs, B, H, nv, np, (g_attn_variant == 8 || g_attn_variant == 64 || g_attn_variant == 16 || g_attn_variant == 417) ? g_attn_variant : 4, s);
 }
 
 int hip_fail(hipError_t e, const char* what) {

@@ -78,11 +78,10 @@ __device__ __forceinline__ typename Traits<T>::frag lds_frag_row(const char* til
 // the vote per tile come out of the hot loop: the kernel is bound by vector ISSUE slots).  f16 operands keep the tracking path: P <= 65504 means the
 // second pass already triggers at s - m > 16, which random scores reach often enough to cost more than the maxima (927 against 997 TFLOP/s).
 template <typename T, int NW, int QT, bool LS = false, bool NOMAX = false>
-__global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : (QT == 4 ? 2 : RZ_FA_WAVES)) void flash_attn_kernel(const T* __restrict__ q, const T* __restrict__ k,
+__global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : ((QT == 4 || sizeof(T) == 4) ? 2 : RZ_FA_WAVES)) void flash_attn_kernel(const T* __restrict__ q, const T* __restrict__ k,
                                                             const T* __restrict__ vT, T* __restrict__ ctx,
                                                             int64_t qk_batch_stride, int B, int H, int n_valid, int n_pad) {
     typedef typename Traits<T>::frag frag_t;
-    typedef typename Traits<T>::vec4 v4_t;
     constexpr int NPAN = FaCfg<T>::NPAN;
     constexpr int TILE = FaCfg<T>::TILE_BYTES;
     constexpr int ES = (int)sizeof(T);
@@ -412,33 +411,37 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : (QT == 4 ? 2 : RZ_FA_WAVES))
 hipError_t launch_flash_attn(int dtype, const void* q, const void* k, const void* vT, void* ctx,
                              int64_t qk_batch_stride, int B, int H, int n_valid, int n_pad, int waves, hipStream_t s) {
     if (n_pad % FA_QROWS || n_valid <= 0 || n_valid > n_pad || B <= 0 || H <= 0) return hipErrorInvalidValue;
+    // `waves` selects the kernel shape (option attn_variant; every shape passes the same tests):
+    //   4   default: 4 waves x 32 query rows, row sums on the matrix pipe; bf16 without the running maximum (NOMAX)
+    //   417 the default shape with the running maximum tracked in every tile (what f16 always runs; the bf16 second pass)
+    //   16  the default shape with VALU row sums (fp32 operands always: the ones-row sums cost 8 exact-f32 MFMAs per tile and push
+    //       the kernel to one wave per SIMD — 119-129 against 110 TFLOP/s)
+    //   8   8 waves x 32 rows (256-row query blocks), 64: 4 waves x 64 rows — 16-bit operands, n_pad % 256 == 0
     int qt = 2;
-    // default shape (4 waves x 32 query rows): row sums on the matrix pipe; "16" = same shape with VALU row sums (A/B)
-    const bool ls = (waves == 4 || waves == 416 || waves == 417);
-    const bool force_ls = (waves == 416);
-    const bool track = (waves == 417);                                   // "417": default shape WITH the running maximum in the hot loop (A/B)
-    if (waves == 416 || waves == 417 || waves == 16) waves = 4;
-    const bool ls4 = (waves == 464);                                     // "464": 4 waves x 64 query rows, row sums on the matrix pipe
-    if (waves == 64 || waves == 464) { waves = 4; qt = 4; }              // "64": 4 waves x 64 query rows
-    if (waves == 264) { waves = 2; qt = 4; }                             // "264": 2 waves x 64 query rows (128-row q blocks)
-    if ((waves == 8 || qt == 4) && ((n_pad % 256 && waves != 2) || dtype == DT_F32)) { waves = 4; qt = 2; }   // 16-bit operands only
+    const bool ls = (waves == 4 || waves == 417) && dtype != DT_F32;
+    const bool track = (waves == 417) || dtype == DT_F16;
+    if (waves == 417 || waves == 16) waves = 4;
+    if (waves == 64) { waves = 4; qt = 4; }
+    if ((waves == 8 || qt == 4) && (n_pad % 256 || dtype == DT_F32)) { waves = 4; qt = 2; }
+    if (waves != 4 && waves != 8) return hipErrorInvalidValue;
     const int nq = n_pad / (16 * qt * waves);
     const int pairs = B * H;
     dim3 grid(((pairs * nq + 7) / 8) * 8), block(64 * waves);
-#define RZ_FA(TT, NWV, QTV) hipLaunchKernelGGL((flash_attn_kernel<TT, NWV, QTV>), grid, block, 0, s, (const TT*)q, (const TT*)k, \
-                                               (const TT*)vT, (TT*)ctx, qk_batch_stride, B, H, n_valid, n_pad)
-#define RZ_FA_LS(TT) hipLaunchKernelGGL((flash_attn_kernel<TT, 4, 2, true>), grid, block, 0, s, (const TT*)q, (const TT*)k, \
-                                        (const TT*)vT, (TT*)ctx, qk_batch_stride, B, H, n_valid, n_pad)
+#define RZ_FA(TT, NWV, QTV, LSV, NOMAXV) hipLaunchKernelGGL((flash_attn_kernel<TT, NWV, QTV, LSV, NOMAXV>), grid, block, 0, s, (const TT*)q, \
+                                                            (const TT*)k, (const TT*)vT, (TT*)ctx, qk_batch_stride, B, H, n_valid, n_pad)
+#define RZ_FA16(TT)                                                   \
+    if (ls) RZ_FA(TT, 4, 2, true, false);                             \
+    else if (waves == 8) RZ_FA(TT, 8, 2, false, false);               \
+    else if (qt == 4) RZ_FA(TT, 4, 4, false, false);                  \
+    else RZ_FA(TT, 4, 2, false, false)
     switch (dtype) {
-        // fp32 operands: the ones-row sums cost 8 exact-f32 MFMAs per tile and push the kernel to one wave per SIMD; VALU sums measured
-        // 119-129 against 110 TFLOP/s (the 16-bit default stays on the matrix pipe)
-        case DT_F32: if (ls && force_ls) RZ_FA_LS(float); else RZ_FA(float, 4, 2); break;
-        case DT_BF16: if (ls && !track) hipLaunchKernelGGL((flash_attn_kernel<bf16_t, 4, 2, true, true>), grid, block, 0, s, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)vT, (bf16_t*)ctx, qk_batch_stride, B, H, n_valid, n_pad); else if (ls) RZ_FA_LS(bf16_t); else if (ls4 && qt == 4) hipLaunchKernelGGL((flash_attn_kernel<bf16_t, 4, 4, true>), grid, block, 0, s, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)vT, (bf16_t*)ctx, qk_batch_stride, B, H, n_valid, n_pad); else if (waves == 8) RZ_FA(bf16_t, 8, 2); else if (waves == 2) RZ_FA(bf16_t, 2, 4); else if (qt == 4) RZ_FA(bf16_t, 4, 4); else RZ_FA(bf16_t, 4, 2); break;
-        case DT_F16: if (ls) RZ_FA_LS(f16_t); else if (waves == 8) RZ_FA(f16_t, 8, 2); else if (waves == 2) RZ_FA(f16_t, 2, 4); else if (qt == 4) RZ_FA(f16_t, 4, 4); else RZ_FA(f16_t, 4, 2); break;
+        case DT_F32: RZ_FA(float, 4, 2, false, false); break;
+        case DT_BF16: if (ls && !track) RZ_FA(bf16_t, 4, 2, true, true); else { RZ_FA16(bf16_t); } break;
+        case DT_F16: RZ_FA16(f16_t); break;
         default: return hipErrorInvalidValue;
     }
+#undef RZ_FA16
 #undef RZ_FA
-#undef RZ_FA_LS
     return hipGetLastError();
 }
 
