@@ -159,6 +159,7 @@ if __name__ == "__main__":
     ap.add_argument("--variant", type=int, default=0)
     ap.add_argument("--attn-variant", type=int, default=0)
     ap.add_argument("--zeros", action="store_true")
+    ap.add_argument("--tokens", type=int, default=5330, help="tokens per image for the attention bench (5330 = 1024^2, 11882 = 1536^2)")
     ap.add_argument("--skew", type=int, default=0, help="persistent GEMM start-up stagger period, 10 ns ticks")
     a = ap.parse_args()
     if a.v1:
@@ -170,7 +171,7 @@ if __name__ == "__main__":
     if a.skew:
         lib.rz_set_option(b"gemm_skew", a.skew)
     if a.what in ("attn", "all"):
-        bench_attn(a.images, dt=a.dtype, zeros=a.zeros)
+        bench_attn(a.images, n=a.tokens, dt=a.dtype, zeros=a.zeros)
     if a.what in ("gemm", "all"):
         bench_gemm(a.images, dt=a.dtype)
     if a.what == "gemmab":
