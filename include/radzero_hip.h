@@ -158,14 +158,21 @@ int rz_layernorm(int dtype, const float* in_dev, const float* gamma_dev, const f
  * log2 units: ctx = softmax2(q k^T) v with softmax2(x) = 2^x / sum 2^x  (the model folds log2(e)/sqrt(64) into q). */
 int rz_flash_attention(int dtype, const void* q_dev, const void* k_dev, const void* v_t_dev, void* ctx_dev, int batch,
                        int heads, int n_valid, int n_pad, void* stream);
+/* the same contraction for fp32 tensors on the f16 matrix pipe: every operand carried as hi + lo f16 planes (22 mantissa bits),
+ * every product as three MFMAs with fp32 accumulation (what the fp32 mode's attention runs by default, option "attn_f32_split").
+ * workspace_dev: rz_flash_attention_split_workspace(batch, heads, n_pad) bytes, caller owned. */
+size_t rz_flash_attention_split_workspace(int batch, int heads, int n_pad);
+int rz_flash_attention_f32_split(const float* q_dev, const float* k_dev, const float* v_t_dev, float* ctx_dev, void* workspace_dev,
+                                 int batch, int heads, int n_valid, int n_pad, void* stream);
 
 /* process-wide tuning / A-B switches (measurement only; defaults are the measured-fastest choices, 0 restores them):
  *   "gemm_variant"     0 auto | 1 128x128 two-stage | 3 256x256 two-stage | 7 256x256 staggered 8-phase (16-bit, gemm7.hip)
  *                      | 8 the same K loop as a persistent kernel, one workgroup per CU (16-bit, gemm8.hip; default for big shapes)
  *                      | 9 = 7 with in-kernel s_memtime stamps (EPI_STORE only; stamps land in the `resid_dev` buffer)
  *   "gemm_v1_only"     1 = same as gemm_variant 1
- *   "attn_variant"     0/1 default (16x16x32 MFMA, 4 waves x 32 query rows, row sums on the matrix pipe) | 16 same with VALU
- *                      row sums | 8 eight waves | 64 / 264 / 464 64 query rows per wave
+ *   "attn_variant"     0/1 default (16x16x32 MFMA, 4 waves x 32 query rows, row sums on the matrix pipe; bf16 without the running
+ *                      maximum in the hot loop) | 417 the same with it | 16 VALU row sums | 8 eight waves | 64 sixty-four query rows per wave
+ *   "attn_f32_split"   1 (default) = fp32 mode runs attention as hi/lo-split f16 MFMAs; 0 = exact-fp32 MFMAs (16x16x4_f32)
  *   "ln_fused"         1 (default) = the blocks' LayerNorms are fused into the GEMMs either side of them where the persistent
  *                      kernel applies (16-bit modes, >= 2 images of 1024^2); 0 = stand-alone LayerNorm kernels everywhere
  *   "vision_chunk"     images per internal pass of rz_vision_forward (0 = whole batch)

@@ -125,6 +125,8 @@ SYMBOLS = {
     "rz_gemm_qkv": (_I, [_I, _P, _P, _P, _P, _P, _I, _I, _I, _P, _P]),
     "rz_layernorm": (_I, [_I, _P, _P, _P, _F, _P, _P, _L, _I, _P]),
     "rz_flash_attention": (_I, [_I, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "rz_flash_attention_split_workspace": (ctypes.c_size_t, [_I, _I, _I]),
+    "rz_flash_attention_f32_split": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "rz_set_option": (_I, [ctypes.c_char_p, _I]),
     "rz_debug_buffer": (_I, [ctypes.c_char_p, _P]),
     "rz_profile_enable": (_I, [_P, _I]),

@@ -29,6 +29,7 @@ int g_vision_chunk = 0;   // images per pass of rz_vision_forward (0 = whole bat
 int g_vision_streams = 1; // 2 = split the batch over two internal HIP streams
 int g_mlp_chunk = 0;      // images per fc1->fc2 pass (0 = whole batch = default, -1 = auto ~126 MiB of hidden rows): run_chunk in rz_vision_forward
 int g_attn_variant = 0;
+int g_attn_f32_split = 1; // fp32 mode: attention on the f16 matrix pipe with hi/lo-split operands (0 = exact-fp32 MFMAs)
 int g_ln_fused = 1;       // 1 = fuse the blocks' LayerNorms into the GEMMs either side where the persistent kernel applies (16-bit modes)
 
 hipError_t flash_attn(int dt, const void* q, const void* k, const void* vt, void* ctx, int64_t bs, int B, int H, int nv, int np,
@@ -707,7 +708,11 @@ int rz_vision_forward(rz_handle_t m, const float* px, int B, int C, int Himg, in
                 // q heads are heads [0,H) and k heads [H,2H) of the [B][2H][np][64] tensor
                 const char* qb = (const char*)qkb;
                 const char* kb = qb + (size_t)H * np * 64 * es;
-                RZ_HIP(flash_attn(m->dt, qb, kb, vtb, ctxb, (int64_t)2 * H * np * 64, Bc, H, nv, np, s));
+                if (m->dt == RZ_F32 && g_attn_f32_split)      // hi/lo f16 planes of q, k, V^T live in `mid` (free between the QKV and fc1 GEMMs: 3/4 of it)
+                    RZ_HIP(launch_flash_attn_f32_split((const float*)qb, (const float*)kb, (const float*)vtb, (float*)ctxb, mid, (int64_t)2 * H * np * 64,
+                                                       Bc, H, nv, np, s));
+                else
+                    RZ_HIP(flash_attn(m->dt, qb, kb, vtb, ctxb, (int64_t)2 * H * np * 64, Bc, H, nv, np, s));
             }
             if (!fused) {
                 if ((rc = gemm(m, EPI_RESID_SCALE, ctxb, D, b.wo.p, D, M, D, D, (const float*)b.bo.p, nullptr, 0, (const float*)b.ls1.p, h, D, np, 0, s))) return rc;
@@ -965,6 +970,16 @@ int rz_flash_attention(int dtype, const void* q, const void* k, const void* vt, 
     return 0;
 }
 
+size_t rz_flash_attention_split_workspace(int B, int H, int n_pad) { return flash_attn_split_workspace_bytes(B, H, n_pad); }
+
+int rz_flash_attention_f32_split(const float* q, const float* k, const float* vt, float* ctx, void* ws, int B, int H, int n_valid, int n_pad,
+                                 void* stream) {
+    if (!q || !k || !vt || !ctx || !ws) return fail(RZ_ERR_INVALID, "rz_flash_attention_f32_split: null argument");
+    if (n_pad % 128 || n_valid <= 0 || n_valid > n_pad) return fail(RZ_ERR_INVALID, "rz_flash_attention_f32_split: n_pad must be a multiple of 128 >= n_valid > 0");
+    RZ_HIP(launch_flash_attn_f32_split(q, k, vt, ctx, ws, (int64_t)H * n_pad * 64, B, H, n_valid, n_pad, (hipStream_t)stream));
+    return 0;
+}
+
 int rz_debug_buffer(const char* what, void* dev_ptr) {
     if (!what) return fail(RZ_ERR_INVALID, "rz_debug_buffer: null name");
     if (!strcmp(what, "gemm_v8_stamps")) { gemm_v8_set_stamp_buffer(dev_ptr); return 0; }
@@ -981,6 +996,7 @@ int rz_set_option(const char* name, int value) {
     if (!strcmp(name, "mlp_chunk")) { g_mlp_chunk = value; return 0; }
     if (!strcmp(name, "attn_variant")) { g_attn_variant = value; return 0; }
     if (!strcmp(name, "ln_fused")) { g_ln_fused = value; return 0; }
+    if (!strcmp(name, "attn_f32_split")) { g_attn_f32_split = value; return 0; }
     return fail(RZ_ERR_INVALID, std::string("rz_set_option: unknown option ") + name);
 }
 

@@ -408,6 +408,291 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : ((QT == 4 || sizeof(T) == 4)
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// flash_attn_split_kernel: the fp32 mode's attention on the f16 matrix pipe.  Every fp32 operand x is carried as two f16 planes,
+// hi = f16(x) and lo = f16(x - hi) (x - hi is exact in fp32, so hi + lo holds 22 mantissa bits), and every product as three MFMAs with
+// fp32 accumulation:  a.b = ah.bh + ah.bl + al.bh  (the dropped al.bl term is 2^-22 relative).  S = K Q^T, P = 2^(S - m) in fp32,
+// P split the same way, O = V^T P^T; row sums are plain fp32 adds of P.  96 f16 MFMAs per wave and 64-key tile instead of 256
+// exact-fp32 ones (16x16x4_f32 runs at 1/16 of the f16 rate): 2.5 PFLOP/s / 3 against 157 TFLOP/s of matrix peak.
+// Same tiles, fragment maps and XCD mapping as flash_attn_workgroup<f16, 4, 2>; LDS holds both planes of K and V^T, double buffered
+// (64 KB, two workgroups per CU); the running maximum is tracked (P <= 2^8 fits f16).  Output: fp32 ctx.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256, 2) void flash_attn_split_kernel(const f16_t* __restrict__ q, const f16_t* __restrict__ k,
+                                                                  const f16_t* __restrict__ vT, float* __restrict__ ctx,
+                                                                  int64_t qk_batch_stride, int64_t qk_lo_off, int64_t v_lo_off,
+                                                                  int B, int H, int n_valid, int n_pad) {
+    typedef f16x8 frag_t;
+    constexpr int TILE = 64 * 128;                   // one plane of one 64-key tile
+    constexpr int ES = 2;
+    __shared__ __attribute__((aligned(1024))) char lds[8 * TILE];   // K: [buf][plane], then V^T: [buf][plane]
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l15 = lane & 15, lg = lane >> 4;
+
+    const int nq = n_pad / FA_QROWS;
+    const int pairs = B * H;
+    const int items = pairs * nq;
+    const int per_xcd = (items + 7) >> 3;
+    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+    const int item = xcd * per_xcd + j;
+    if (j >= per_xcd || item >= items) return;
+    const int pair = item / nq;
+    const int qb = item - pair * nq;
+    const int b = pair / H, h = pair % H;
+
+    const f16_t* qbase = q + (int64_t)b * qk_batch_stride + ((int64_t)h * n_pad) * 64;
+    const char* kbase = reinterpret_cast<const char*>(k + (int64_t)b * qk_batch_stride + ((int64_t)h * n_pad) * 64);
+    const char* vbase = reinterpret_cast<const char*>(vT + ((int64_t)pair * 64) * n_pad);
+    const int64_t k_ld = 64 * (int64_t)ES, v_ld = (int64_t)n_pad * ES;
+    const int64_t k_lo_b = qk_lo_off * ES, v_lo_b = v_lo_off * ES;
+
+    const int q0 = qb * FA_QROWS + wave * 32;
+    frag_t qh[2][2], ql[2][2];
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const f16_t* src = qbase + (int64_t)(q0 + qt * 16 + l15) * 64 + ks * 32 + lg * 8;
+            qh[qt][ks] = *reinterpret_cast<const frag_t*>(src);
+            ql[qt][ks] = *reinterpret_cast<const frag_t*>(src + qk_lo_off);
+        }
+
+    const int krow = 8 * (l15 >> 2) + (l15 & 3);
+    const int ksw = swz_k(krow);
+    int koff[2], voff[2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) koff[ks] = krow * 128 + (((ks * 4 + lg) ^ ksw) << 4);
+    const int sw = (l15 >> 1) & 7;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) voff[kk] = l15 * 128 + (((kk * 4 + lg) ^ sw) << 4);
+
+    auto stage = [&](int t, int buf) {
+        char* sk = lds + buf * 2 * TILE;
+        char* sv = lds + 4 * TILE + buf * 2 * TILE;
+        const int key0 = t * FA_KEYS;
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int row8 = (wave * 2 + i) * 8;
+                glds_rows8<1>(sk + pl * TILE + row8 * 128, kbase + pl * k_lo_b + (int64_t)key0 * k_ld, k_ld, row8, lane);
+                glds_rows8(sv + pl * TILE + row8 * 128, vbase + pl * v_lo_b + (int64_t)key0 * ES, v_ld, row8, lane);
+            }
+    };
+
+    f32x4 oacc[2][4], cinit[2];
+    float mrow[2], lrow[2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+        mrow[a] = 0.f; lrow[a] = 0.f;
+        cinit[a] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int c = 0; c < 4; ++c) oacc[a][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+
+    auto tile = [&](int t, auto first_c, auto mask_c) {
+        constexpr bool FIRST = decltype(first_c)::value, MASK = decltype(mask_c)::value;
+        const int buf = t & 1;
+        const char* sk = lds + buf * 2 * TILE;
+        const char* sv = lds + 4 * TILE + buf * 2 * TILE;
+        auto load_k = [&](int pl, int ks, int kt) -> frag_t {
+            return *reinterpret_cast<const frag_t*>(sk + pl * TILE + koff[ks] + (32 * (kt >> 1) + 4 * (kt & 1)) * 128);
+        };
+        auto load_v = [&](int pl, int kk, int dt) -> frag_t {
+            return *reinterpret_cast<const frag_t*>(sv + pl * TILE + voff[kk] + dt * 2048);
+        };
+        // ---- S' = K Q^T - mrow:  kh.qh + kh.ql + kl.qh ----
+        f32x4 sacc[2][4];
+        {
+            frag_t kf[2][4];
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int kt = 0; kt < 4; ++kt) kf[ks][kt] = load_k(0, ks, kt);
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                for (int a = 0; a < 2; ++a) sacc[a][kt] = mma(kf[0][kt], qh[a][0], cinit[a]);
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                for (int a = 0; a < 2; ++a) sacc[a][kt] = mma(kf[1][kt], qh[a][1], sacc[a][kt]);
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                    for (int a = 0; a < 2; ++a) sacc[a][kt] = mma(kf[ks][kt], ql[a][ks], sacc[a][kt]);
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int kt = 0; kt < 4; ++kt) kf[ks][kt] = load_k(1, ks, kt);
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                    for (int a = 0; a < 2; ++a) sacc[a][kt] = mma(kf[ks][kt], qh[a][ks], sacc[a][kt]);
+        }
+        if constexpr (MASK) {
+            const int key0 = t * FA_KEYS;
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const bool dead = key0 + 32 * (kt >> 1) + 8 * lg + 4 * (kt & 1) + r >= n_valid;
+                    if (dead) { sacc[0][kt][r] = -INFINITY; sacc[1][kt][r] = -INFINITY; }
+                }
+        }
+        float mx[2];
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt) {
+            float m0 = fmaxf(fmaxf(sacc[qt][0][0], sacc[qt][0][1]), fmaxf(sacc[qt][0][2], sacc[qt][0][3]));
+#pragma unroll
+            for (int kt = 1; kt < 4; ++kt)
+                m0 = fmaxf(m0, fmaxf(fmaxf(sacc[qt][kt][0], sacc[qt][kt][1]), fmaxf(sacc[qt][kt][2], sacc[qt][kt][3])));
+            mx[qt] = m0;
+        }
+        auto row_max = [&](float m0) {
+            m0 = fmaxf(m0, __shfl_xor(m0, 16, 64));
+            return fmaxf(m0, __shfl_xor(m0, 32, 64));
+        };
+        if constexpr (FIRST) {
+#pragma unroll
+            for (int qt = 0; qt < 2; ++qt) {
+                mx[qt] = row_max(mx[qt]);
+                mrow[qt] = mx[qt];
+                cinit[qt] = (f32x4){-mx[qt], -mx[qt], -mx[qt], -mx[qt]};
+#pragma unroll
+                for (int kt = 0; kt < 4; ++kt) sacc[qt][kt] -= mx[qt];
+            }
+        } else if (__builtin_expect(__any(fmaxf(mx[0], mx[1]) > FA_DEFER), 0)) {
+            asm volatile("" ::: "memory");
+#pragma unroll
+            for (int qt = 0; qt < 2; ++qt) {
+                const float delta = fmaxf(row_max(mx[qt]), 0.f);
+                const float alpha = __builtin_amdgcn_exp2f(-delta);
+                mrow[qt] += delta;
+                cinit[qt] -= delta;
+                lrow[qt] *= alpha;
+#pragma unroll
+                for (int kt = 0; kt < 4; ++kt) sacc[qt][kt] -= delta;
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) oacc[qt][dt] *= alpha;
+            }
+            asm volatile("" ::: "memory");
+        }
+        // ---- P = 2^S' (fp32), row sums, split into f16 planes ----
+        frag_t ph[2][2], pl[2][2];
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt) {
+            float psum = 0.f;
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                float pv[8], pr[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    pv[i] = __builtin_amdgcn_exp2f(sacc[qt][2 * kk + (i >> 2)][i & 3]);
+                    psum += pv[i];
+                }
+                ph[qt][kk] = pack8<f16_t>(pv[0], pv[1], pv[2], pv[3], pv[4], pv[5], pv[6], pv[7]);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) pr[i] = pv[i] - (float)ph[qt][kk][i];
+                pl[qt][kk] = pack8<f16_t>(pr[0], pr[1], pr[2], pr[3], pr[4], pr[5], pr[6], pr[7]);
+            }
+            lrow[qt] += psum;
+        }
+        // ---- O^T += V^T P^T:  vh.ph + vh.pl + vl.ph ----
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            frag_t vf[4];
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) vf[dt] = load_v(0, kk, dt);
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+                for (int a = 0; a < 2; ++a) {
+                    oacc[a][dt] = mma(vf[dt], pl[a][kk], oacc[a][dt]);
+                    oacc[a][dt] = mma(vf[dt], ph[a][kk], oacc[a][dt]);
+                }
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) vf[dt] = load_v(1, kk, dt);
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+                for (int a = 0; a < 2; ++a) oacc[a][dt] = mma(vf[dt], ph[a][kk], oacc[a][dt]);
+        }
+    };
+    using TrueT = std::integral_constant<bool, true>;
+    using FalseT = std::integral_constant<bool, false>;
+
+    const int ntiles = (n_valid + FA_KEYS - 1) / FA_KEYS;
+    const bool ragged = (n_valid % FA_KEYS) != 0;
+    const int nplain = ragged ? ntiles - 1 : ntiles;
+    stage(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (ntiles > 1) stage(1, 1);
+    if (nplain >= 1) tile(0, TrueT{}, FalseT{}); else tile(0, TrueT{}, TrueT{});
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (int t = 1; t < nplain; ++t) {
+        if (t + 1 < ntiles) stage(t + 1, (t + 1) & 1);
+        tile(t, FalseT{}, FalseT{});
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+    if (ragged && ntiles > 1) tile(ntiles - 1, FalseT{}, TrueT{});
+
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt) {
+        float l = lrow[qt];
+        l += __shfl_xor(l, 16, 64);
+        l += __shfl_xor(l, 32, 64);
+        const float inv = 1.0f / l;
+        const int qrow = q0 + qt * 16 + l15;
+        float* o = ctx + ((int64_t)b * n_pad + qrow) * (H * 64) + h * 64 + lg * 4;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) *reinterpret_cast<f32x4*>(o + dt * 16) = oacc[qt][dt] * inv;
+    }
+}
+
+// x (fp32, B slabs of `per` contiguous elements `src_stride` apart) -> compact planes hi = f16(x), lo = f16(x - hi)   (per % 4 == 0)
+__global__ __launch_bounds__(256) void split_f16_kernel(const float* __restrict__ x, int64_t src_stride, f16_t* __restrict__ hi,
+                                                        f16_t* __restrict__ lo, int64_t per4) {
+    const float* src = x + (int64_t)blockIdx.y * src_stride;
+    const int64_t dst0 = (int64_t)blockIdx.y * per4 * 4;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < per4; i += (int64_t)gridDim.x * 256) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(src + 4 * i);
+        const f16x4 h = pack4<f16_t>(v[0], v[1], v[2], v[3]);
+        const f16x4 l = pack4<f16_t>(v[0] - (float)h[0], v[1] - (float)h[1], v[2] - (float)h[2], v[3] - (float)h[3]);
+        *reinterpret_cast<f16x4*>(hi + dst0 + 4 * i) = h;
+        *reinterpret_cast<f16x4*>(lo + dst0 + 4 * i) = l;
+    }
+}
+
+size_t flash_attn_split_workspace_bytes(int B, int H, int n_pad) { return (size_t)3 * B * H * n_pad * 64 * 4; }
+
+// fp32 q, k ([B][H][n_pad][64] each, batch stride qk_batch_stride) and V^T ([B][H][64][n_pad]) -> fp32 ctx through the split kernel.
+// split_ws (flash_attn_split_workspace_bytes): planes q_hi q_lo k_hi k_lo v_hi v_lo, each B*H*n_pad*64 f16.
+hipError_t launch_flash_attn_f32_split(const float* q, const float* k, const float* vT, float* ctx, void* split_ws, int64_t qk_batch_stride,
+                                       int B, int H, int n_valid, int n_pad, hipStream_t s) {
+    if (n_pad % FA_QROWS || n_valid <= 0 || n_valid > n_pad || B <= 0 || H <= 0 || !split_ws) return hipErrorInvalidValue;
+    const int64_t per = (int64_t)H * n_pad * 64, n = (int64_t)B * per;
+    f16_t* q_hi = reinterpret_cast<f16_t*>(split_ws);
+    f16_t* k_hi = q_hi + 2 * n;
+    f16_t* v_hi = q_hi + 4 * n;
+    const dim3 sgrid(256, B);
+    hipLaunchKernelGGL(split_f16_kernel, sgrid, dim3(256), 0, s, q, qk_batch_stride, q_hi, q_hi + n, per / 4);
+    hipLaunchKernelGGL(split_f16_kernel, sgrid, dim3(256), 0, s, k, qk_batch_stride, k_hi, k_hi + n, per / 4);
+    hipLaunchKernelGGL(split_f16_kernel, sgrid, dim3(256), 0, s, vT, per, v_hi, v_hi + n, per / 4);
+    const int nq = n_pad / FA_QROWS;
+    dim3 grid(((B * H * nq + 7) / 8) * 8), block(256);
+    hipLaunchKernelGGL(flash_attn_split_kernel, grid, block, 0, s, q_hi, k_hi, v_hi, ctx, per, n, n, B, H, n_valid, n_pad);
+    return hipGetLastError();
+}
+
 hipError_t launch_flash_attn(int dtype, const void* q, const void* k, const void* vT, void* ctx,
                              int64_t qk_batch_stride, int B, int H, int n_valid, int n_pad, int waves, hipStream_t s) {
     if (n_pad % FA_QROWS || n_valid <= 0 || n_valid > n_pad || B <= 0 || H <= 0) return hipErrorInvalidValue;

@@ -59,6 +59,9 @@ hipError_t launch_gemm_v7(int variant, int dtype, int epi, const GemmArgs& g, hi
 // Flash attention over per-head tensors: q,k [B][H][Npad][64], vT [B][H][64][Npad] -> ctx [B*Npad][H*64].
 // Scores are NOT rescaled inside (1/sqrt(dh) is folded into the packed q weights).
 // q/k of image b start at q + b*qk_batch_stride (elements), heads contiguous ([H][Npad][64]).
+size_t flash_attn_split_workspace_bytes(int B, int H, int n_pad);
+hipError_t launch_flash_attn_f32_split(const float* q, const float* k, const float* vT, float* ctx, void* split_ws, int64_t qk_batch_stride,
+                                       int B, int H, int n_valid, int n_pad, hipStream_t s);
 hipError_t launch_flash_attn(int dtype, const void* q, const void* k, const void* vT, void* ctx,
                              int64_t qk_batch_stride, int B, int H, int n_valid, int n_pad, int waves, hipStream_t s);
 

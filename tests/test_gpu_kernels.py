@@ -150,6 +150,36 @@ def test_flash_attention_rescale_branch(lib, attn_variant, dt):
     assert (got - ref).abs().max().item() <= {"f32": 5e-5, "bf16": 2.5e-2, "f16": 3e-3}[dt]
 
 
+@pytest.mark.parametrize("case", [(1, 2, 257, 1.0), (2, 12, 362, 1.0), (1, 1, 1, 1.0), (1, 2, 1370, 1.0), (1, 1, 128, 1.0), (1, 3, 700, 0.02), (1, 2, 320, 30.0)])
+def test_flash_attention_f32_split(lib, case):
+    """The fp32 mode's attention: fp32 tensors through hi/lo-split f16 MFMAs (attention.hip, flash_attn_split_kernel) against an
+    fp64 softmax.  Bar: 2e-5 of the value scale, i.e. the gate of the exact-fp32 MFMA kernel — also with operands 50 x smaller (every
+    lo plane then lies in f16's subnormal range).  With k and v 30 x larger (scores of +-150: one-hot softmax, re-centring on every
+    tile) fp32 rounding of the scores themselves dominates: there the bar is the exact-fp32 kernel's own error on the same data."""
+    B, H, n, scale = case
+    npad = (n + 127) // 128 * 128
+    g = torch.Generator(device="cpu").manual_seed(n + H)
+    q = torch.zeros(B, H, npad, 64); k = torch.zeros(B, H, npad, 64); v = torch.zeros(B, H, npad, 64)
+    q[:, :, :n] = torch.randn(B, H, n, 64, generator=g) * 0.65 * (scale if scale < 1 else 1.0)
+    k[:, :, :n] = torch.randn(B, H, n, 64, generator=g) * (scale if scale > 1 else 1.0)
+    v[:, :, :n] = torch.randn(B, H, n, 64, generator=g) * scale
+    k[:, :, n:] = 37.0
+    v[:, :, n:] = -91.0
+    qd, kd = q.cuda(), k.cuda()
+    vtd = v.transpose(2, 3).contiguous().cuda()
+    ctx = torch.empty(B * npad, H * 64, device="cuda")
+    ws = torch.empty(lib.rz_flash_attention_split_workspace(B, H, npad), dtype=torch.uint8, device="cuda")
+    check(lib, lib.rz_flash_attention_f32_split(P(qd), P(kd), P(vtd), P(ctx), P(ws), B, H, n, npad, stream()))
+    exact = torch.empty_like(ctx)
+    check(lib, lib.rz_flash_attention(0, P(qd), P(kd), P(vtd), P(exact), B, H, n, npad, stream()))
+    torch.cuda.synchronize()
+    ref = _attn_ref(q[:, :, :n].double(), k[:, :, :n].double(), v[:, :, :n].double())
+    got = ctx.double().cpu().view(B, npad, H, 64).permute(0, 2, 1, 3)[:, :, :n]
+    ex = exact.double().cpu().view(B, npad, H, 64).permute(0, 2, 1, 3)[:, :, :n]
+    err, err_exact = (got - ref).abs().max().item(), (ex - ref).abs().max().item()
+    assert err <= max(2e-5 * scale, 1.25 * err_exact if scale > 1 else 0.0), (case, err, err_exact)
+
+
 @pytest.mark.parametrize("g,size", [(16, (224, 224)), (37, (512, 640)), (73, (1024, 1024)), (19, (300, 200))])
 def test_upsample(lib, g, size):
     gen = torch.Generator(device="cpu").manual_seed(g)
