@@ -29,6 +29,7 @@ int g_vision_chunk = 0;   // images per pass of rz_vision_forward (0 = whole bat
 int g_vision_streams = 1; // 2 = split the batch over two internal HIP streams
 int g_mlp_chunk = 0;      // images per fc1->fc2 pass (0 = whole batch = default, -1 = auto ~126 MiB of hidden rows): run_chunk in rz_vision_forward
 int g_attn_variant = 0;
+int g_gemm_f32_split = 1; // fp32 mode: the vision encoder's GEMMs on the f16 matrix pipe with hi/lo-split operands (0 = exact-fp32 MFMAs)
 int g_attn_f32_split = 1; // fp32 mode: attention on the f16 matrix pipe with hi/lo-split operands (0 = exact-fp32 MFMAs)
 int g_ln_fused = 1;       // 1 = fuse the blocks' LayerNorms into the GEMMs either side where the persistent kernel applies (16-bit modes)
 
@@ -87,6 +88,7 @@ struct DevBuf {
 
 struct Tensor {          // one packed checkpoint tensor on the device
     void* p = nullptr;
+    void* p3 = nullptr;  // fp32 mode, matrices: [N][3K] f16 planes [hi | hi | lo] for the hi/lo-split GEMMs (rz_weights_ready)
     bool loaded = false;
 };
 
@@ -123,6 +125,10 @@ struct rz_model {
     int cap_batch = 0, cap_npad = 0, cap_trows = 0, cap_prompts = 0;
     DevBuf h, xn, qk, vt, ctx, mid, vws, qhat, lnpart, lnstat, lnmu;      // xn doubles as the residual's T copy on the fused-LayerNorm path
     DevBuf th, txn, tqkv, tctx, tmid, tsum;
+    DevBuf asplit;                       // fp32 mode: [hi | lo | hi] f16 planes of the A operand of the GEMM in flight (3 x max K per token row)
+    struct SplitW { const char* p; size_t bytes; const char* p3; };
+    std::vector<SplitW> split_w;         // fp32 weight matrix -> its split copy
+    bool split_dirty = true;             // a weight was (re)loaded since the split copies were built
     // state of the last vision forward
     int last_batch = 0, last_nvalid = 0, last_npad = 0;
     // profiling
@@ -318,12 +324,53 @@ int load_text_layer(rz_model* m, TextLayer& l, const char* rest, const float* da
     return fail(RZ_ERR_INVALID, std::string("unknown MPNetLayer tensor: ") + rest);
 }
 
+// fp32 mode, vision encoder: the GEMM runs on the f16 matrix pipe over hi/lo-split operands (gemm.hip, launch_gemm_split_f32out) when
+// the weight has a split copy and A lies in one of the vision workspaces (its token row picks the slice of the split scratch).
+// reuse_split: A was split by the previous call (q|k and v projections share their input).
+int gemm_f32_split(rz_model* m, int epi, GemmArgs g, bool reuse_split, hipStream_t s, bool* done) {
+    *done = false;
+    if (!(epi == EPI_HEADS || epi == EPI_VT || epi == EPI_GELU || epi == EPI_RESID_SCALE || epi == EPI_PATCH)) return 0;
+    if (g.M % 128 || g.lda != g.K || g.ldw != g.K || !m->asplit.p) return 0;
+    const char* w3 = nullptr;
+    for (const auto& e : m->split_w) {
+        const char* w = (const char*)g.W;
+        if (w >= e.p && w < e.p + e.bytes) {
+            const size_t row = (size_t)(w - e.p) / ((size_t)g.K * 4);
+            if (e.p + row * g.K * 4 != w) return 0;
+            w3 = e.p3 + row * 3 * g.K * 2;
+            break;
+        }
+    }
+    if (!w3) return 0;
+    const size_t maxk = std::max((size_t)m->F, (size_t)m->KPAD);
+    const char* a = (const char*)g.A;
+    auto row_in = [&](const DevBuf& b, size_t row_bytes, size_t* row) {
+        if (!b.p || a < (const char*)b.p || a >= (const char*)b.p + b.bytes) return false;
+        *row = (size_t)(a - (const char*)b.p) / row_bytes;
+        return true;
+    };
+    size_t row = 0;
+    if (!(row_in(m->xn, (size_t)m->D * 4, &row) || row_in(m->ctx, (size_t)m->D * 4, &row) || row_in(m->mid, maxk * 4, &row))) return 0;
+    char* a3 = (char*)m->asplit.p + row * 3 * maxk * 2;
+    if (a3 + (size_t)g.M * 3 * g.K * 2 > (char*)m->asplit.p + m->asplit.bytes) return 0;
+    if (!reuse_split) RZ_HIP(launch_split3((const float*)g.A, g.lda, a3, g.M, g.K, 0, s));
+    g.A = a3; g.W = w3; g.lda = g.ldw = 3 * (int64_t)g.K; g.K = 3 * g.K;
+    RZ_HIP(launch_gemm_split_f32out(epi, g, s));
+    *done = true;
+    return 0;
+}
+
 int gemm(rz_model* m, int epi, const void* A, int64_t lda, const void* W, int64_t ldw, int M, int N, int K, const float* bias,
-         void* out, int64_t ldo, const float* scale, float* resid, int64_t ldr, int rpi, int heads, hipStream_t s) {
+         void* out, int64_t ldo, const float* scale, float* resid, int64_t ldr, int rpi, int heads, hipStream_t s, bool reuse_split = false) {
     GemmArgs g;
     g.A = A; g.lda = lda; g.W = W; g.ldw = ldw; g.M = M; g.N = N; g.K = K; g.bias = bias; g.out = out; g.ldo = ldo;
     g.scale = scale; g.resid = resid; g.ldr = ldr; g.rows_per_image = rpi; g.heads_total = heads;
     ProfScope ps(m, RZ_PROF_GEMM, s);
+    if (m->dt == RZ_F32 && g_gemm_f32_split) {
+        bool done = false;
+        int rc = gemm_f32_split(m, epi, g, reuse_split, s, &done);
+        if (rc || done) return rc;
+    }
     RZ_HIP(launch_gemm(m->dt, epi, g, s));
     return 0;
 }
@@ -411,7 +458,7 @@ int gemm_qkv(rz_model* m, const void* xn, const DinoBlock& b, int M, int np, voi
     const char* wv = (const char*)b.wqkv.p + (size_t)2 * D * D * dsize(m->dt);
     int rc;
     if ((rc = gemm(m, EPI_HEADS, xn, D, b.wqkv.p, D, M, 2 * D, D, (const float*)b.bqkv.p, qk, 0, nullptr, nullptr, 0, np, 2 * H, s))) return rc;
-    return gemm(m, EPI_VT, xn, D, wv, D, M, D, D, (const float*)b.bqkv.p + 2 * D, vt, 0, nullptr, nullptr, 0, np, H, s);
+    return gemm(m, EPI_VT, xn, D, wv, D, M, D, D, (const float*)b.bqkv.p + 2 * D, vt, 0, nullptr, nullptr, 0, np, H, s, true);
 }
 
 }  // namespace
@@ -466,6 +513,7 @@ int rz_destroy(rz_handle_t m) {
 
 int rz_load_weight(rz_handle_t m, const char* name, const float* data, int64_t numel) {
     if (!m || !name || !data || numel <= 0) return fail(RZ_ERR_INVALID, "rz_load_weight: bad argument");
+    m->split_dirty = true;
     const size_t D = m->D;
     int idx;
     const char* rest;
@@ -553,6 +601,25 @@ int rz_weights_ready(rz_handle_t m) {
     if (m->dt != RZ_F32)        // one-time packing of the fused-LayerNorm vectors (c1, c2): here, so that no forward call allocates
         for (auto& b : m->blocks)
             if ((rc = fold_block(m, b))) return rc;
+    if (m->dt == RZ_F32 && m->split_dirty) {     // f16 [hi | hi | lo] copies of the vision encoder's matrices for the hi/lo-split GEMMs
+        m->split_w.clear();
+        auto split = [&](Tensor& t, size_t N, size_t K) -> int {
+            if (!t.p3) {
+                RZ_HIP(hipMalloc(&t.p3, N * 3 * K * 2));
+                m->allocs.push_back(t.p3);
+            }
+            RZ_HIP(launch_split3((const float*)t.p, (int64_t)K, t.p3, (int64_t)N, (int)K, 1, nullptr));
+            m->split_w.push_back({(const char*)t.p, N * K * 4, (const char*)t.p3});
+            return 0;
+        };
+        const size_t D = m->D, F = m->F;
+        if ((rc = split(m->patch_w, D, m->KPAD))) return rc;
+        for (auto& b : m->blocks) {
+            if ((rc = split(b.wqkv, 3 * D, D)) || (rc = split(b.wo, D, D)) || (rc = split(b.w1, F, D)) || (rc = split(b.w2, D, F))) return rc;
+        }
+        RZ_HIP(hipDeviceSynchronize());
+        m->split_dirty = false;
+    }
     return 0;
 }
 
@@ -587,6 +654,7 @@ int rz_reserve(rz_handle_t m, int max_batch, int max_tokens, int max_prompts, in
         RZ_HIP(m->vt.ensure(rows * D * es, true));
         RZ_HIP(m->ctx.ensure(rows * D * es, true));
         RZ_HIP(m->mid.ensure(rows * std::max(F, (size_t)m->KPAD) * es, true));
+        if (m->dt == RZ_F32) RZ_HIP(m->asplit.ensure(rows * 3 * std::max(F, (size_t)m->KPAD) * 2, false));
         if (m->dt != RZ_F32) {
             RZ_HIP(m->lnpart.ensure(rows * 24 * 4, true));
             RZ_HIP(m->lnstat.ensure(rows * 2 * 4, true));
@@ -997,6 +1065,7 @@ int rz_set_option(const char* name, int value) {
     if (!strcmp(name, "attn_variant")) { g_attn_variant = value; return 0; }
     if (!strcmp(name, "ln_fused")) { g_ln_fused = value; return 0; }
     if (!strcmp(name, "attn_f32_split")) { g_attn_f32_split = value; return 0; }
+    if (!strcmp(name, "gemm_f32_split")) { g_gemm_f32_split = value; return 0; }
     return fail(RZ_ERR_INVALID, std::string("rz_set_option: unknown option ") + name);
 }
 

@@ -13,12 +13,16 @@
 // N a multiple of 128, K*sizeof(T) a multiple of 128.
 #include <cstring>
 
+#include <algorithm>
+
 #include "gemm_common.h"
 
 namespace rz {
 
 
-template <typename T, int EPI>
+// OT = type of the outputs the epilogue writes (default: the operand type).  <f16_t, EPI, float> = 16-bit operands, fp32 outputs: the
+// fp32 mode's hi/lo-split GEMMs (launch_gemm_split_f32out below).
+template <typename T, int EPI, typename OT = T>
 __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs g) {
     __shared__ __attribute__((aligned(1024))) char lds[4 * PANEL_BYTES];  // A0 A1 B0 B1
     constexpr bool SWAP = (EPI != EPI_VT && EPI != EPI_VT_LN);
@@ -98,7 +102,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs g) {
         __syncthreads();
     }
 
-    gemm_epilogue<T, EPI>(g, acc, m0 + wm * 64, n0 + wn * 64, l15, lg);
+    gemm_epilogue<OT, EPI>(g, acc, m0 + wm * 64, n0 + wn * 64, l15, lg);
 }
 
 constexpr int BM2 = 256;
@@ -112,7 +116,7 @@ constexpr int BM2 = 256;
 constexpr int BN3 = 256;
 constexpr int STAGE3_BYTES = (BM2 + BN3) * 128;   // 64 KB
 
-template <typename T, int EPI>
+template <typename T, int EPI, typename OT = T>
 __global__ __launch_bounds__(512, 2) void gemm_kernel_v3(GemmArgs g) {
     __shared__ __attribute__((aligned(1024))) char lds[2 * STAGE3_BYTES];
     constexpr bool SWAP = (EPI != EPI_VT);
@@ -184,16 +188,17 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel_v3(GemmArgs g) {
     const f32x4 (&hi)[4][4] = *reinterpret_cast<const f32x4 (*)[4][4]>(&acc[4]);
     // LDS-staged 16-byte stores for the 16-bit row-major / per-head / transposed outputs (+9..15 % on those GEMMs),
     // direct epilogue for GELU (VALU-bound) and the fp32 outputs / residual read-modify-write (equal within noise).
-    constexpr bool kLds = sizeof(T) == 2 && (EPI == EPI_STORE || EPI == EPI_HEADS || EPI == EPI_VT);
+    constexpr bool kLds = sizeof(OT) == 2 && (EPI == EPI_STORE || EPI == EPI_HEADS || EPI == EPI_VT);
     if constexpr (!kLds) {
-        gemm_epilogue<T, EPI>(g, lo, m0 + wm * 128, n0 + wn * 64, l15, lg);
-        gemm_epilogue<T, EPI>(g, hi, m0 + wm * 128 + 64, n0 + wn * 64, l15, lg);
+        gemm_epilogue<OT, EPI>(g, lo, m0 + wm * 128, n0 + wn * 64, l15, lg);
+        gemm_epilogue<OT, EPI>(g, hi, m0 + wm * 128 + 64, n0 + wn * 64, l15, lg);
         return;
+    } else {
+        __syncthreads();                    // every wave is done reading operand stages: LDS is free
+        char* wlds = lds + wave * (64 * 256);
+        gemm_epilogue_lds<OT, EPI>(g, lo, wlds, m0 + wm * 128, n0 + wn * 64, lane);
+        gemm_epilogue_lds<OT, EPI>(g, hi, wlds, m0 + wm * 128 + 64, n0 + wn * 64, lane);
     }
-    __syncthreads();                    // every wave is done reading operand stages: LDS is free
-    char* wlds = lds + wave * (64 * 256);
-    gemm_epilogue_lds<T, EPI>(g, lo, wlds, m0 + wm * 128, n0 + wn * 64, lane);
-    gemm_epilogue_lds<T, EPI>(g, hi, wlds, m0 + wm * 128 + 64, n0 + wn * 64, lane);
 }
 
 static int g_skew = 0;
@@ -271,6 +276,57 @@ static hipError_t launch_gemm_t(int epi, const GemmArgs& g, hipStream_t s) {
     }
 #undef RZ_CASE
 #undef RZ_CASE1
+    return hipGetLastError();
+}
+
+// fp32 mode on the f16 matrix pipe.  The caller has split both operands into f16 planes laid side by side along K:
+//   A' = [A_hi | A_lo | A_hi]  (M x 3K),   W' = [W_hi | W_hi | W_lo]  (N x 3K)    =>   A' W'^T = A_hi W_hi + A_lo W_hi + A_hi W_lo,
+// i.e. the product of the two 22-bit operands less the 2^-22 lo.lo term, accumulated in fp32 by the ordinary f16 kernels run over
+// K' = 3K.  Epilogues that write fp32 anyway (residual read-modify-write, patch table) go to launch_gemm's 16-bit dispatch unchanged;
+// the others run here with fp32 outputs (OT = float: exact-erf GELU, fp32 per-head / transposed / row-major stores).
+hipError_t launch_gemm_split_f32out(int epi, const GemmArgs& g, hipStream_t s) {
+    if (epi == EPI_RESID_SCALE || epi == EPI_RESID_ADD || epi == EPI_PATCH || epi == EPI_STORE_F32) return launch_gemm(DT_F16, epi, g, s);
+    if (g.M <= 0 || g.N <= 0 || g.K <= 0 || g.M % BM || g.N % BN || (g.K * 2) % 128 || (g.lda * 2) % 16 || (g.ldw * 2) % 16) return hipErrorInvalidValue;
+    const bool v3 = big_tiles_pay(g);
+    const int ntiles = v3 ? (g.M / BM2) * (g.N / BN3) : (g.M / BM) * (g.N / BN);
+    dim3 grid(ntiles), block(v3 ? 512 : 256);
+#define RZ_CASE(E) \
+    case E: if (v3) hipLaunchKernelGGL((gemm_kernel_v3<f16_t, E, float>), grid, block, 0, s, g); \
+            else hipLaunchKernelGGL((gemm_kernel<f16_t, E, float>), grid, block, 0, s, g); break;
+    switch (epi) {
+        RZ_CASE(EPI_STORE)
+        RZ_CASE(EPI_GELU)
+        RZ_CASE(EPI_HEADS)
+        RZ_CASE(EPI_VT)
+        default: return hipErrorInvalidValue;
+    }
+#undef RZ_CASE
+    return hipGetLastError();
+}
+
+// src fp32 [rows][K] (row stride ld) -> dst f16 [rows][3K]: [hi | lo | hi] (activations) or, w_layout, [hi | hi | lo] (weights)
+__global__ __launch_bounds__(256) void split3_rows_kernel(const float* __restrict__ src, int64_t ld, f16_t* __restrict__ dst, int64_t rows,
+                                                          int K, int w_layout) {
+    const int k4 = K / 4;
+    const int64_t total = rows * k4;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t r = i / k4;
+        const int c = (int)(i - r * k4) * 4;
+        const f32x4 v = *reinterpret_cast<const f32x4*>(src + r * ld + c);
+        const f16x4 h = pack4<f16_t>(v[0], v[1], v[2], v[3]);
+        const f16x4 l = pack4<f16_t>(v[0] - (float)h[0], v[1] - (float)h[1], v[2] - (float)h[2], v[3] - (float)h[3]);
+        f16_t* o = dst + r * 3 * K + c;
+        *reinterpret_cast<f16x4*>(o) = h;
+        *reinterpret_cast<f16x4*>(o + K) = w_layout ? h : l;
+        *reinterpret_cast<f16x4*>(o + 2 * K) = w_layout ? l : h;
+    }
+}
+
+hipError_t launch_split3(const float* src, int64_t ld, void* dst, int64_t rows, int K, int w_layout, hipStream_t s) {
+    if (rows <= 0 || K <= 0 || K % 4 || ld % 4) return hipErrorInvalidValue;
+    const int64_t total = rows * (K / 4);
+    const int blocks = (int)std::min<int64_t>((total + 255) / 256, 8192);
+    hipLaunchKernelGGL(split3_rows_kernel, dim3(blocks), dim3(256), 0, s, src, ld, (f16_t*)dst, rows, K, w_layout);
     return hipGetLastError();
 }
 

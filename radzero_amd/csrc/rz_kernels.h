@@ -53,6 +53,9 @@ bool gemm_v7_ok(int dtype, const GemmArgs& g);
 bool gemm_v8_ok(int dtype, int epi, const GemmArgs& g);
 bool gemm_qkv_fused_ok(int dtype, const GemmArgs& g);
 bool gemm_ln_fused_ok(int dtype, int M, int D, int F);   // may a Dinov2 block of M token rows use the fused-LayerNorm epilogues   // may EPI_QKV be launched for this shape (else: EPI_HEADS + EPI_VT)
+// fp32 mode on the f16 matrix pipe: operands split into f16 planes along K (gemm.hip)
+hipError_t launch_gemm_split_f32out(int epi, const GemmArgs& g, hipStream_t s);
+hipError_t launch_split3(const float* src, int64_t ld, void* dst, int64_t rows, int K, int w_layout, hipStream_t s);
 hipError_t launch_gemm_v8(int dtype, int epi, const GemmArgs& g, hipStream_t s);   // persistent 256x256 kernel (gemm8.hip)
 hipError_t launch_gemm_v7(int variant, int dtype, int epi, const GemmArgs& g, hipStream_t s);
 
