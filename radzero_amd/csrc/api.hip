@@ -327,10 +327,12 @@ int load_text_layer(rz_model* m, TextLayer& l, const char* rest, const float* da
 // fp32 mode, vision encoder: the GEMM runs on the f16 matrix pipe over hi/lo-split operands (gemm.hip, launch_gemm_split_f32out) when
 // the weight has a split copy and A lies in one of the vision workspaces (its token row picks the slice of the split scratch).
 // reuse_split: A was split by the previous call (q|k and v projections share their input).
-int gemm_f32_split(rz_model* m, int epi, GemmArgs g, bool reuse_split, hipStream_t s, bool* done) {
+enum { A_F32 = 0, A_SPLIT = 1, A_REUSE = 2 };   // the A operand: fp32 (split here), already [M][3K] hi|lo|hi planes, or split by the previous call
+
+int gemm_f32_split(rz_model* m, int epi, GemmArgs g, int a_mode, bool out_split, hipStream_t s, bool* done) {
     *done = false;
     if (!(epi == EPI_HEADS || epi == EPI_VT || epi == EPI_GELU || epi == EPI_RESID_SCALE || epi == EPI_PATCH)) return 0;
-    if (g.M % 128 || g.lda != g.K || g.ldw != g.K || !m->asplit.p) return 0;
+    if (g.M % 128 || g.lda != g.K || g.ldw != g.K) return 0;
     const char* w3 = nullptr;
     for (const auto& e : m->split_w) {
         const char* w = (const char*)g.W;
@@ -342,35 +344,42 @@ int gemm_f32_split(rz_model* m, int epi, GemmArgs g, bool reuse_split, hipStream
         }
     }
     if (!w3) return 0;
-    const size_t maxk = std::max((size_t)m->F, (size_t)m->KPAD);
-    const char* a = (const char*)g.A;
-    auto row_in = [&](const DevBuf& b, size_t row_bytes, size_t* row) {
-        if (!b.p || a < (const char*)b.p || a >= (const char*)b.p + b.bytes) return false;
-        *row = (size_t)(a - (const char*)b.p) / row_bytes;
-        return true;
-    };
-    size_t row = 0;
-    if (!(row_in(m->xn, (size_t)m->D * 4, &row) || row_in(m->ctx, (size_t)m->D * 4, &row) || row_in(m->mid, maxk * 4, &row))) return 0;
-    char* a3 = (char*)m->asplit.p + row * 3 * maxk * 2;
-    if (a3 + (size_t)g.M * 3 * g.K * 2 > (char*)m->asplit.p + m->asplit.bytes) return 0;
-    if (!reuse_split) RZ_HIP(launch_split3((const float*)g.A, g.lda, a3, g.M, g.K, 0, s));
-    g.A = a3; g.W = w3; g.lda = g.ldw = 3 * (int64_t)g.K; g.K = 3 * g.K;
-    RZ_HIP(launch_gemm_split_f32out(epi, g, s));
+    if (a_mode != A_SPLIT) {
+        if (!m->asplit.p) return 0;
+        const size_t maxk = std::max((size_t)m->F, (size_t)m->KPAD);
+        const char* a = (const char*)g.A;
+        auto row_in = [&](const DevBuf& b, size_t row_bytes, size_t* row) {
+            if (!b.p || a < (const char*)b.p || a >= (const char*)b.p + b.bytes) return false;
+            *row = (size_t)(a - (const char*)b.p) / row_bytes;
+            return true;
+        };
+        size_t row = 0;
+        if (!(row_in(m->xn, (size_t)m->D * 6, &row) || row_in(m->ctx, (size_t)m->D * 6, &row) || row_in(m->mid, maxk * 6, &row))) return 0;
+        char* a3 = (char*)m->asplit.p + row * 3 * maxk * 2;
+        if (a3 + (size_t)g.M * 3 * g.K * 2 > (char*)m->asplit.p + m->asplit.bytes) return 0;
+        if (a_mode == A_F32) RZ_HIP(launch_split3((const float*)g.A, g.lda, a3, g.M, g.K, 0, s));
+        g.A = a3;
+    }
+    g.W = w3; g.lda = g.ldw = 3 * (int64_t)g.K; g.K = 3 * g.K;
+    RZ_HIP(launch_gemm_split_f32out(epi, g, s, out_split));
     *done = true;
     return 0;
 }
 
+// a_mode / out_split / plane_off: fp32 mode's hi/lo-split path only (see gemm_f32_split); with A_SPLIT or out_split the call MUST take it
 int gemm(rz_model* m, int epi, const void* A, int64_t lda, const void* W, int64_t ldw, int M, int N, int K, const float* bias,
-         void* out, int64_t ldo, const float* scale, float* resid, int64_t ldr, int rpi, int heads, hipStream_t s, bool reuse_split = false) {
+         void* out, int64_t ldo, const float* scale, float* resid, int64_t ldr, int rpi, int heads, hipStream_t s, int a_mode = A_F32,
+         bool out_split = false, int64_t plane_off = 0) {
     GemmArgs g;
     g.A = A; g.lda = lda; g.W = W; g.ldw = ldw; g.M = M; g.N = N; g.K = K; g.bias = bias; g.out = out; g.ldo = ldo;
-    g.scale = scale; g.resid = resid; g.ldr = ldr; g.rows_per_image = rpi; g.heads_total = heads;
+    g.scale = scale; g.resid = resid; g.ldr = ldr; g.rows_per_image = rpi; g.heads_total = heads; g.plane_off = plane_off;
     ProfScope ps(m, RZ_PROF_GEMM, s);
     if (m->dt == RZ_F32 && g_gemm_f32_split) {
         bool done = false;
-        int rc = gemm_f32_split(m, epi, g, reuse_split, s, &done);
+        int rc = gemm_f32_split(m, epi, g, a_mode, out_split, s, &done);
         if (rc || done) return rc;
     }
+    if (a_mode == A_SPLIT || out_split) return fail(RZ_ERR_STATE, "split GEMM requested but not applicable");
     RZ_HIP(launch_gemm(m->dt, epi, g, s));
     return 0;
 }
@@ -458,7 +467,7 @@ int gemm_qkv(rz_model* m, const void* xn, const DinoBlock& b, int M, int np, voi
     const char* wv = (const char*)b.wqkv.p + (size_t)2 * D * D * dsize(m->dt);
     int rc;
     if ((rc = gemm(m, EPI_HEADS, xn, D, b.wqkv.p, D, M, 2 * D, D, (const float*)b.bqkv.p, qk, 0, nullptr, nullptr, 0, np, 2 * H, s))) return rc;
-    return gemm(m, EPI_VT, xn, D, wv, D, M, D, D, (const float*)b.bqkv.p + 2 * D, vt, 0, nullptr, nullptr, 0, np, H, s, true);
+    return gemm(m, EPI_VT, xn, D, wv, D, M, D, D, (const float*)b.bqkv.p + 2 * D, vt, 0, nullptr, nullptr, 0, np, H, s, A_REUSE);
 }
 
 }  // namespace
@@ -649,11 +658,12 @@ int rz_reserve(rz_handle_t m, int max_batch, int max_tokens, int max_prompts, in
         const int B = std::max(max_batch, m->cap_batch), NP = std::max(npad, m->cap_npad);
         const size_t rows = (size_t)B * NP;
         RZ_HIP(m->h.ensure(rows * D * 4, true));
-        RZ_HIP(m->xn.ensure(rows * D * es, true));
+        const size_t ex = m->dt == RZ_F32 ? 6 : es;      // fp32 mode: room for the [hi | lo | hi] f16 planes of the hi/lo-split path
+        RZ_HIP(m->xn.ensure(rows * D * ex, true));
         RZ_HIP(m->qk.ensure(rows * 2 * D * es, true));
         RZ_HIP(m->vt.ensure(rows * D * es, true));
-        RZ_HIP(m->ctx.ensure(rows * D * es, true));
-        RZ_HIP(m->mid.ensure(rows * std::max(F, (size_t)m->KPAD) * es, true));
+        RZ_HIP(m->ctx.ensure(rows * D * ex, true));
+        RZ_HIP(m->mid.ensure(rows * std::max(F, (size_t)m->KPAD) * ex, true));
         if (m->dt == RZ_F32) RZ_HIP(m->asplit.ensure(rows * 3 * std::max(F, (size_t)m->KPAD) * 2, false));
         if (m->dt != RZ_F32) {
             RZ_HIP(m->lnpart.ensure(rows * 24 * 4, true));
@@ -710,11 +720,15 @@ int rz_vision_forward(rz_handle_t m, const float* px, int B, int C, int Himg, in
         const size_t row0 = (size_t)c0 * np;                                   // first token row of this chunk
         float* h = (float*)m->h.p + row0 * D;
         const float* pxc = px + (size_t)c0 * C * Himg * Wimg;
-        char* xn = (char*)m->xn.p + row0 * D * es;
+        // fp32 mode on the f16 matrix pipe: activations between the kernels travel as hi/lo f16 planes (6 bytes per element where they feed
+        // a GEMM: [hi | lo | hi] along K; 4 where they feed the attention: hi plane, lo plane)
+        const bool sp = m->dt == RZ_F32 && g_gemm_f32_split && g_attn_f32_split && !m->split_w.empty();
+        const size_t ex = m->dt == RZ_F32 ? 6 : es;
+        char* xn = (char*)m->xn.p + row0 * D * ex;
         char* qkb = (char*)m->qk.p + row0 * 2 * D * es;
         char* vtb = (char*)m->vt.p + row0 * D * es;
-        char* ctxb = (char*)m->ctx.p + row0 * D * es;
-        char* mid = (char*)m->mid.p + row0 * std::max((size_t)F, (size_t)m->KPAD) * es;
+        char* ctxb = (char*)m->ctx.p + row0 * D * ex;
+        char* mid = (char*)m->mid.p + row0 * std::max((size_t)F, (size_t)m->KPAD) * ex;
         // auto: ~126 MiB of hidden activations per pass (4 images of 5376 rows at 16 bits), whole images only
         const size_t hid_row_bytes = (size_t)F * es;
         const int mlp_auto = (int)std::max<size_t>(1, ((size_t)132 << 20) / (hid_row_bytes * np));
@@ -749,7 +763,17 @@ int rz_vision_forward(rz_handle_t m, const float* px, int B, int C, int Himg, in
         for (int li = 0; li < nblocks; ++li) {
             const DinoBlock& b = m->blocks[li];
             const bool last_vit = (li == m->cfg.vit_layers - 1), last = (li == nblocks - 1);
-            if (!fused) {
+            if (sp) {
+                {
+                    ProfScope ps(m, RZ_PROF_ROWOPS, s);
+                    RZ_HIP(launch_layernorm_split3(h, (const float*)b.ln1_g.p, (const float*)b.ln1_b.p, eps, xn, M, D, s));
+                }
+                // q | k -> hi / lo planes of [Bc][2H][np][64]; V^T -> hi / lo planes of [Bc][H][64][np]
+                const char* wv = (const char*)b.wqkv.p + (size_t)2 * D * D * 4;
+                if ((rc = gemm(m, EPI_HEADS, xn, D, b.wqkv.p, D, M, 2 * D, D, (const float*)b.bqkv.p, qkb, 0, nullptr, nullptr, 0, np, 2 * H, s, A_SPLIT, true,
+                               (int64_t)M * 2 * D))) return rc;
+                if ((rc = gemm(m, EPI_VT, xn, D, wv, D, M, D, D, (const float*)b.bqkv.p + 2 * D, vtb, 0, nullptr, nullptr, 0, np, H, s, A_SPLIT, true, (int64_t)M * D))) return rc;
+            } else if (!fused) {
                 {
                     ProfScope ps(m, RZ_PROF_ROWOPS, s);
                     RZ_HIP(launch_layernorm(m->dt, h, (const float*)b.ln1_g.p, (const float*)b.ln1_b.p, eps, xn, nullptr, M, D, s));
@@ -776,13 +800,22 @@ int rz_vision_forward(rz_handle_t m, const float* px, int B, int C, int Himg, in
                 // q heads are heads [0,H) and k heads [H,2H) of the [B][2H][np][64] tensor
                 const char* qb = (const char*)qkb;
                 const char* kb = qb + (size_t)H * np * 64 * es;
-                if (m->dt == RZ_F32 && g_attn_f32_split)      // hi/lo f16 planes of q, k, V^T live in `mid` (free between the QKV and fc1 GEMMs: 3/4 of it)
+                if (sp)                                         // planes in (f16: k heads start H*np*64 ELEMENTS behind q), [hi | lo | hi] ctx out
+                    RZ_HIP(launch_flash_attn_split_planes(qb, qb + (size_t)H * np * 64 * 2, vtb, ctxb, (int64_t)2 * H * np * 64, (int64_t)M * 2 * D, (int64_t)M * D,
+                                                          Bc, H, nv, np, s));
+                else if (m->dt == RZ_F32 && g_attn_f32_split)      // hi/lo f16 planes of q, k, V^T live in `mid` (free between the QKV and fc1 GEMMs: 3/4 of it)
                     RZ_HIP(launch_flash_attn_f32_split((const float*)qb, (const float*)kb, (const float*)vtb, (float*)ctxb, mid, (int64_t)2 * H * np * 64,
                                                        Bc, H, nv, np, s));
                 else
                     RZ_HIP(flash_attn(m->dt, qb, kb, vtb, ctxb, (int64_t)2 * H * np * 64, Bc, H, nv, np, s));
             }
-            if (!fused) {
+            if (sp) {
+                if ((rc = gemm(m, EPI_RESID_SCALE, ctxb, D, b.wo.p, D, M, D, D, (const float*)b.bo.p, nullptr, 0, (const float*)b.ls1.p, h, D, np, 0, s, A_SPLIT))) return rc;
+                {
+                    ProfScope ps(m, RZ_PROF_ROWOPS, s);
+                    RZ_HIP(launch_layernorm_split3(h, (const float*)b.ln2_g.p, (const float*)b.ln2_b.p, eps, xn, M, D, s));
+                }
+            } else if (!fused) {
                 if ((rc = gemm(m, EPI_RESID_SCALE, ctxb, D, b.wo.p, D, M, D, D, (const float*)b.bo.p, nullptr, 0, (const float*)b.ls1.p, h, D, np, 0, s))) return rc;
                 {
                     ProfScope ps(m, RZ_PROF_ROWOPS, s);
@@ -803,6 +836,9 @@ int rz_vision_forward(rz_handle_t m, const float* px, int B, int C, int Himg, in
                 } else {
                     if ((rc = gemm_resid_ln(m, mid, F, b.w2, b.b2, b.ls2, M, F, h, np, m->blocks[li + 1].ln1_g, xn, part, lnmu, stat, eps, s))) return rc;
                 }
+            } else if (sp) {        // fc1 writes [hi | lo | hi] of GELU(.) straight into fc2's A operand
+                if ((rc = gemm(m, EPI_GELU, xn, D, b.w1.p, D, M, F, D, (const float*)b.b1.p, mid, F, nullptr, nullptr, 0, np, 0, s, A_SPLIT, true))) return rc;
+                if ((rc = gemm(m, EPI_RESID_SCALE, mid, F, b.w2.p, F, M, D, F, (const float*)b.b2.p, nullptr, 0, (const float*)b.ls2.p, h, D, np, 0, s, A_SPLIT))) return rc;
             } else {
                 for (int i0 = 0; i0 < Bc; i0 += mlp_images) {
                     const int Mi = std::min(mlp_images, Bc - i0) * np;

@@ -417,8 +417,10 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : ((QT == 4 || sizeof(T) == 4)
 // Same tiles, fragment maps and XCD mapping as flash_attn_workgroup<f16, 4, 2>; LDS holds both planes of K and V^T, double buffered
 // (64 KB, two workgroups per CU); the running maximum is tracked (P <= 2^8 fits f16).  Output: fp32 ctx.
 // ---------------------------------------------------------------------------------------------
+// OUT_SPLIT: ctx leaves as the out-projection's split A operand [rows][3 * H * 64] f16 = [hi | lo | hi] instead of fp32.
+template <bool OUT_SPLIT>
 __global__ __launch_bounds__(256, 2) void flash_attn_split_kernel(const f16_t* __restrict__ q, const f16_t* __restrict__ k,
-                                                                  const f16_t* __restrict__ vT, float* __restrict__ ctx,
+                                                                  const f16_t* __restrict__ vT, void* __restrict__ ctx_out,
                                                                   int64_t qk_batch_stride, int64_t qk_lo_off, int64_t v_lo_off,
                                                                   int B, int H, int n_valid, int n_pad) {
     typedef f16x8 frag_t;
@@ -652,9 +654,22 @@ __global__ __launch_bounds__(256, 2) void flash_attn_split_kernel(const f16_t* _
         l += __shfl_xor(l, 32, 64);
         const float inv = 1.0f / l;
         const int qrow = q0 + qt * 16 + l15;
-        float* o = ctx + ((int64_t)b * n_pad + qrow) * (H * 64) + h * 64 + lg * 4;
+        const int D = H * 64;
+        if constexpr (OUT_SPLIT) {
+            f16_t* o = reinterpret_cast<f16_t*>(ctx_out) + ((int64_t)b * n_pad + qrow) * (3 * D) + h * 64 + lg * 4;
 #pragma unroll
-        for (int dt = 0; dt < 4; ++dt) *reinterpret_cast<f32x4*>(o + dt * 16) = oacc[qt][dt] * inv;
+            for (int dt = 0; dt < 4; ++dt) {
+                f16x4 hi, lo;
+                split4(oacc[qt][dt] * inv, hi, lo);
+                *reinterpret_cast<f16x4*>(o + dt * 16) = hi;
+                *reinterpret_cast<f16x4*>(o + D + dt * 16) = lo;
+                *reinterpret_cast<f16x4*>(o + 2 * D + dt * 16) = hi;
+            }
+        } else {
+            float* o = reinterpret_cast<float*>(ctx_out) + ((int64_t)b * n_pad + qrow) * D + h * 64 + lg * 4;
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) *reinterpret_cast<f32x4*>(o + dt * 16) = oacc[qt][dt] * inv;
+        }
     }
 }
 
@@ -689,7 +704,19 @@ hipError_t launch_flash_attn_f32_split(const float* q, const float* k, const flo
     hipLaunchKernelGGL(split_f16_kernel, sgrid, dim3(256), 0, s, vT, per, v_hi, v_hi + n, per / 4);
     const int nq = n_pad / FA_QROWS;
     dim3 grid(((B * H * nq + 7) / 8) * 8), block(256);
-    hipLaunchKernelGGL(flash_attn_split_kernel, grid, block, 0, s, q_hi, k_hi, v_hi, ctx, per, n, n, B, H, n_valid, n_pad);
+    hipLaunchKernelGGL(flash_attn_split_kernel<false>, grid, block, 0, s, q_hi, k_hi, v_hi, (void*)ctx, per, n, n, B, H, n_valid, n_pad);
+    return hipGetLastError();
+}
+
+// The same kernel on operands that are ALREADY hi/lo planes (written by the split q|k / V^T epilogues, gemm_common.h): q_hi, k_hi
+// with batch stride qk_batch_stride, lo planes qk_lo_off / v_lo_off elements behind the hi planes; ctx3 = [rows][3 * H * 64] f16.
+hipError_t launch_flash_attn_split_planes(const void* q_hi, const void* k_hi, const void* v_hi, void* ctx3, int64_t qk_batch_stride,
+                                          int64_t qk_lo_off, int64_t v_lo_off, int B, int H, int n_valid, int n_pad, hipStream_t s) {
+    if (n_pad % FA_QROWS || n_valid <= 0 || n_valid > n_pad || B <= 0 || H <= 0) return hipErrorInvalidValue;
+    const int nq = n_pad / FA_QROWS;
+    dim3 grid(((B * H * nq + 7) / 8) * 8), block(256);
+    hipLaunchKernelGGL(flash_attn_split_kernel<true>, grid, block, 0, s, (const f16_t*)q_hi, (const f16_t*)k_hi, (const f16_t*)v_hi, ctx3,
+                       qk_batch_stride, qk_lo_off, v_lo_off, B, H, n_valid, n_pad);
     return hipGetLastError();
 }
 

@@ -284,20 +284,29 @@ static hipError_t launch_gemm_t(int epi, const GemmArgs& g, hipStream_t s) {
 // i.e. the product of the two 22-bit operands less the 2^-22 lo.lo term, accumulated in fp32 by the ordinary f16 kernels run over
 // K' = 3K.  Epilogues that write fp32 anyway (residual read-modify-write, patch table) go to launch_gemm's 16-bit dispatch unchanged;
 // the others run here with fp32 outputs (OT = float: exact-erf GELU, fp32 per-head / transposed / row-major stores).
-hipError_t launch_gemm_split_f32out(int epi, const GemmArgs& g, hipStream_t s) {
+hipError_t launch_gemm_split_f32out(int epi, const GemmArgs& g, hipStream_t s, bool split_out) {
     if (epi == EPI_RESID_SCALE || epi == EPI_RESID_ADD || epi == EPI_PATCH || epi == EPI_STORE_F32) return launch_gemm(DT_F16, epi, g, s);
     if (g.M <= 0 || g.N <= 0 || g.K <= 0 || g.M % BM || g.N % BN || (g.K * 2) % 128 || (g.lda * 2) % 16 || (g.ldw * 2) % 16) return hipErrorInvalidValue;
     const bool v3 = big_tiles_pay(g);
     const int ntiles = v3 ? (g.M / BM2) * (g.N / BN3) : (g.M / BM) * (g.N / BN);
     dim3 grid(ntiles), block(v3 ? 512 : 256);
-#define RZ_CASE(E) \
-    case E: if (v3) hipLaunchKernelGGL((gemm_kernel_v3<f16_t, E, float>), grid, block, 0, s, g); \
-            else hipLaunchKernelGGL((gemm_kernel<f16_t, E, float>), grid, block, 0, s, g); break;
+#define RZ_CASE(E, OT) \
+    case E: if (v3) hipLaunchKernelGGL((gemm_kernel_v3<f16_t, E, OT>), grid, block, 0, s, g); \
+            else hipLaunchKernelGGL((gemm_kernel<f16_t, E, OT>), grid, block, 0, s, g); break;
+    if (split_out) {          // outputs leave as hi/lo f16 planes (the next split GEMM's A operand, the split attention's q / k / V^T)
+        switch (epi) {
+            RZ_CASE(EPI_GELU, split_f16)
+            RZ_CASE(EPI_HEADS, split_f16)
+            RZ_CASE(EPI_VT, split_f16)
+            default: return hipErrorInvalidValue;
+        }
+        return hipGetLastError();
+    }
     switch (epi) {
-        RZ_CASE(EPI_STORE)
-        RZ_CASE(EPI_GELU)
-        RZ_CASE(EPI_HEADS)
-        RZ_CASE(EPI_VT)
+        RZ_CASE(EPI_STORE, float)
+        RZ_CASE(EPI_GELU, float)
+        RZ_CASE(EPI_HEADS, float)
+        RZ_CASE(EPI_VT, float)
         default: return hipErrorInvalidValue;
     }
 #undef RZ_CASE

@@ -1,6 +1,7 @@
 // radzero_hip — pieces shared by the GEMM translation units (gemm.hip, gemm7.hip): tile rasterisation and the fused
 // epilogues (reference call sites: see gemm.hip).
 #pragma once
+#include <type_traits>
 #include "rz_common.h"
 #include "rz_kernels.h"
 
@@ -200,7 +201,26 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, const f32x4 (&a
                     const f32x4 b = *reinterpret_cast<const f32x4*>(g.bias + n);
                     v += b;
                 }
-                if constexpr (EPI == EPI_STORE) {
+                if constexpr (std::is_same<T, split_f16>::value) {
+                    // fp32 mode, hi/lo-split outputs (rz_common.h split4): EPI_GELU -> the next GEMM's A operand [M][3N] = [hi | lo | hi]
+                    // (exact-erf GELU as in every fp32 epilogue); EPI_HEADS -> two planes `plane_off` elements apart
+                    f16x4 hi, lo;
+                    if constexpr (EPI == EPI_GELU) {
+                        split4((f32x4){gelu_erf(v[0]), gelu_erf(v[1]), gelu_erf(v[2]), gelu_erf(v[3])}, hi, lo);
+                        f16_t* o = reinterpret_cast<f16_t*>(g.out) + (int64_t)m * 3 * g.ldo + n;
+                        *reinterpret_cast<f16x4*>(o) = hi;
+                        *reinterpret_cast<f16x4*>(o + g.ldo) = lo;
+                        *reinterpret_cast<f16x4*>(o + 2 * g.ldo) = hi;
+                    } else {
+                        static_assert(EPI == EPI_HEADS, "split outputs: EPI_GELU, EPI_HEADS, EPI_VT");
+                        split4(v, hi, lo);
+                        const int b = m / g.rows_per_image, tok = m - b * g.rows_per_image;
+                        f16_t* o = reinterpret_cast<f16_t*>(g.out) +
+                                   (((int64_t)b * g.heads_total + (n >> 6)) * g.rows_per_image + tok) * 64 + (n & 63);
+                        *reinterpret_cast<f16x4*>(o) = hi;
+                        *reinterpret_cast<f16x4*>(o + g.plane_off) = lo;
+                    }
+                } else if constexpr (EPI == EPI_STORE) {
                     T* o = reinterpret_cast<T*>(g.out) + (int64_t)m * g.ldo + n;
                     *reinterpret_cast<typename Traits<T>::vec4*>(o) = pack4<T>(v[0], v[1], v[2], v[3]);
                 } else if constexpr (EPI == EPI_GELU) {
@@ -239,9 +259,17 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, const f32x4 (&a
                 const float bv = g.bias ? g.bias[n] : 0.f;
                 const int b = m / g.rows_per_image, tok = m - b * g.rows_per_image;
                 // vT[b][head][d][tok]
-                T* o = reinterpret_cast<T*>(g.out) +
-                       (((int64_t)b * g.heads_total + (n >> 6)) * 64 + (n & 63)) * g.rows_per_image + tok;
-                *reinterpret_cast<typename Traits<T>::vec4*>(o) = pack4<T>(a[0] + bv, a[1] + bv, a[2] + bv, a[3] + bv);
+                const int64_t idx = (((int64_t)b * g.heads_total + (n >> 6)) * 64 + (n & 63)) * g.rows_per_image + tok;
+                if constexpr (std::is_same<T, split_f16>::value) {
+                    f16x4 hi, lo;
+                    split4((f32x4){a[0] + bv, a[1] + bv, a[2] + bv, a[3] + bv}, hi, lo);
+                    f16_t* o = reinterpret_cast<f16_t*>(g.out) + idx;
+                    *reinterpret_cast<f16x4*>(o) = hi;
+                    *reinterpret_cast<f16x4*>(o + g.plane_off) = lo;
+                } else {
+                    T* o = reinterpret_cast<T*>(g.out) + idx;
+                    *reinterpret_cast<typename Traits<T>::vec4*>(o) = pack4<T>(a[0] + bv, a[1] + bv, a[2] + bv, a[3] + bv);
+                }
             }
         }
     }

@@ -78,6 +78,13 @@ template <typename T> __device__ __forceinline__ typename Traits<T>::vec4 pack4(
     return v;
 }
 
+// Output "type" of the fp32 mode's hi/lo-split path: a value x leaves an epilogue as f16 planes hi = f16(x), lo = f16(x - hi).
+struct split_f16 {};
+__device__ __forceinline__ void split4(const f32x4& v, f16x4& hi, f16x4& lo) {
+    hi = pack4<f16_t>(v[0], v[1], v[2], v[3]);
+    lo = pack4<f16_t>(v[0] - (float)hi[0], v[1] - (float)hi[1], v[2] - (float)hi[2], v[3] - (float)hi[3]);
+}
+
 // 8 floats -> one operand fragment (pairwise packed converts: v_cvt_pk_bf16_f32 / v_cvt_f16 + pack)
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));

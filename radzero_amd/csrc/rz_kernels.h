@@ -41,6 +41,7 @@ struct GemmArgs {
     void* ln_hb = nullptr;           // EPI_RESID_SCALE_LN: [M][N] copy of the new residual TIMES ln_gamma[n], in the compute dtype
     const float* ln_gamma = nullptr; // EPI_RESID_SCALE_LN: gain of the LayerNorm that will consume ln_hb
     const float* ln_mu = nullptr;    // EPI_RESID_SCALE_LN: [M] centring constant of each row (its mean before this update): ln_hb = T((x - ln_mu[m]) * ln_gamma[n])
+    int64_t plane_off = 0;        // hi/lo-split outputs (fp32 mode, EPI_HEADS / EPI_VT): elements from the hi plane to the lo plane
     int skew_ticks = 0;           // persistent kernel: start-up stagger period in 10 ns ticks (0 = none), see gemm8.hip
 };
 
@@ -54,7 +55,7 @@ bool gemm_v8_ok(int dtype, int epi, const GemmArgs& g);
 bool gemm_qkv_fused_ok(int dtype, const GemmArgs& g);
 bool gemm_ln_fused_ok(int dtype, int M, int D, int F);   // may a Dinov2 block of M token rows use the fused-LayerNorm epilogues   // may EPI_QKV be launched for this shape (else: EPI_HEADS + EPI_VT)
 // fp32 mode on the f16 matrix pipe: operands split into f16 planes along K (gemm.hip)
-hipError_t launch_gemm_split_f32out(int epi, const GemmArgs& g, hipStream_t s);
+hipError_t launch_gemm_split_f32out(int epi, const GemmArgs& g, hipStream_t s, bool split_out = false);
 hipError_t launch_split3(const float* src, int64_t ld, void* dst, int64_t rows, int K, int w_layout, hipStream_t s);
 hipError_t launch_gemm_v8(int dtype, int epi, const GemmArgs& g, hipStream_t s);   // persistent 256x256 kernel (gemm8.hip)
 hipError_t launch_gemm_v7(int variant, int dtype, int epi, const GemmArgs& g, hipStream_t s);
@@ -65,6 +66,8 @@ hipError_t launch_gemm_v7(int variant, int dtype, int epi, const GemmArgs& g, hi
 size_t flash_attn_split_workspace_bytes(int B, int H, int n_pad);
 hipError_t launch_flash_attn_f32_split(const float* q, const float* k, const float* vT, float* ctx, void* split_ws, int64_t qk_batch_stride,
                                        int B, int H, int n_valid, int n_pad, hipStream_t s);
+hipError_t launch_flash_attn_split_planes(const void* q_hi, const void* k_hi, const void* v_hi, void* ctx3, int64_t qk_batch_stride,
+                                          int64_t qk_lo_off, int64_t v_lo_off, int B, int H, int n_valid, int n_pad, hipStream_t s);
 hipError_t launch_flash_attn(int dtype, const void* q, const void* k, const void* vT, void* ctx,
                              int64_t qk_batch_stride, int B, int H, int n_valid, int n_pad, int waves, hipStream_t s);
 
@@ -85,6 +88,7 @@ hipError_t launch_ln_prepare(int dtype, const float* in, const float* gamma, con
 
 // LayerNorm over rows of 768: fp32 in; writes T-typed normalized copy (out_t, may be null) and/or
 // fp32 (out_f32, may alias in).
+hipError_t launch_layernorm_split3(const float* in, const float* gamma, const float* beta, float eps, void* out3, int64_t rows, int D, hipStream_t s);
 hipError_t launch_layernorm(int dtype, const float* in, const float* gamma, const float* beta, float eps,
                             void* out_t, float* out_f32, int64_t rows, int D, hipStream_t s);
 
