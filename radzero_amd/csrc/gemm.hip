@@ -288,6 +288,7 @@ hipError_t launch_gemm_split_f32out(int epi, const GemmArgs& g, hipStream_t s, b
     if (epi == EPI_RESID_SCALE || epi == EPI_RESID_ADD || epi == EPI_PATCH || epi == EPI_STORE_F32) return launch_gemm(DT_F16, epi, g, s);
     if (g.M <= 0 || g.N <= 0 || g.K <= 0 || g.M % BM || g.N % BN || (g.K * 2) % 128 || (g.lda * 2) % 16 || (g.ldw * 2) % 16) return hipErrorInvalidValue;
     const bool v3 = big_tiles_pay(g);
+    if (v3 && (g_variant == 0 || g_variant == 7) && gemm_v7_ok(DT_F16, g)) return launch_gemm_v7_f16_out(epi, g, split_out, s);   // the deeper-pipelined K loop
     const int ntiles = v3 ? (g.M / BM2) * (g.N / BN3) : (g.M / BM) * (g.N / BN);
     dim3 grid(ntiles), block(v3 ? 512 : 256);
 #define RZ_CASE(E, OT) \

@@ -128,7 +128,8 @@ __device__ __forceinline__ void v7_tile(f32x4 (&acc)[2][4][4], char* cur, char* 
     }
 }
 
-template <typename T, int EPI, int MODE>
+// OT = type of the outputs (default: the operand type); float / split_f16 = the fp32 mode's hi/lo-split GEMMs (gemm.hip)
+template <typename T, int EPI, int MODE, typename OT = T>
 __global__ __launch_bounds__(512, 2) void gemm_kernel_v7(GemmArgs g) {
     static_assert(sizeof(T) == 2, "v7 is for 16-bit operands");
     __shared__ __attribute__((aligned(1024))) char lds[2 * V7_STAGE];
@@ -232,12 +233,12 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel_v7(GemmArgs g) {
     }
     const int mw = m0 + wr * 128, nw = n0 + wc * 64;
     // 16-bit row-major outputs: whole-tile staging (gemm_common.h); everything else straight from the accumulators
-    if constexpr (EPI == EPI_STORE || EPI == EPI_GELU || EPI == EPI_HEADS || EPI == EPI_VT) {
+    if constexpr (sizeof(OT) == 2 && (EPI == EPI_STORE || EPI == EPI_GELU || EPI == EPI_HEADS || EPI == EPI_VT)) {
         __syncthreads();            // every wave is past its last operand read: LDS is free
-        gemm_epilogue_tile16<T, EPI>(g, acc, lds, m0, n0, wr, wc, lane, tid);
+        gemm_epilogue_tile16<OT, EPI>(g, acc, lds, m0, n0, wr, wc, lane, tid);
     } else {
-        gemm_epilogue<T, EPI>(g, acc[0], mw, nw, l15, lg);
-        gemm_epilogue<T, EPI>(g, acc[1], mw + 64, nw, l15, lg);
+        gemm_epilogue<OT, EPI>(g, acc[0], mw, nw, l15, lg);
+        gemm_epilogue<OT, EPI>(g, acc[1], mw + 64, nw, l15, lg);
     }
 }
 
@@ -258,6 +259,31 @@ static hipError_t launch_v7_t(int variant, int epi, const GemmArgs& g, hipStream
         default: return hipErrorInvalidValue;
     }
 #undef RZ_CASE7
+    return hipGetLastError();
+}
+
+// f16 operands (planes side by side along K), fp32 or hi/lo-split outputs: launch_gemm_split_f32out's large shapes
+hipError_t launch_gemm_v7_f16_out(int epi, const GemmArgs& g, bool split_out, hipStream_t s) {
+    if (!gemm_v7_ok(DT_F16, g)) return hipErrorInvalidValue;
+    dim3 grid((g.M / V7_BM) * (g.N / V7_BN)), block(512);
+#define RZ_CASE7O(E, OT) case E: hipLaunchKernelGGL((gemm_kernel_v7<f16_t, E, 0, OT>), grid, block, 0, s, g); break;
+    if (split_out) {
+        switch (epi) {
+            RZ_CASE7O(EPI_GELU, split_f16)
+            RZ_CASE7O(EPI_HEADS, split_f16)
+            RZ_CASE7O(EPI_VT, split_f16)
+            default: return hipErrorInvalidValue;
+        }
+    } else {
+        switch (epi) {
+            RZ_CASE7O(EPI_STORE, float)
+            RZ_CASE7O(EPI_GELU, float)
+            RZ_CASE7O(EPI_HEADS, float)
+            RZ_CASE7O(EPI_VT, float)
+            default: return hipErrorInvalidValue;
+        }
+    }
+#undef RZ_CASE7O
     return hipGetLastError();
 }
 

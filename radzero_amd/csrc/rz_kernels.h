@@ -59,6 +59,7 @@ hipError_t launch_gemm_split_f32out(int epi, const GemmArgs& g, hipStream_t s, b
 hipError_t launch_split3(const float* src, int64_t ld, void* dst, int64_t rows, int K, int w_layout, hipStream_t s);
 hipError_t launch_gemm_v8(int dtype, int epi, const GemmArgs& g, hipStream_t s);   // persistent 256x256 kernel (gemm8.hip)
 hipError_t launch_gemm_v7(int variant, int dtype, int epi, const GemmArgs& g, hipStream_t s);
+hipError_t launch_gemm_v7_f16_out(int epi, const GemmArgs& g, bool split_out, hipStream_t s);   // f16 operands, fp32 / hi-lo-split outputs
 
 // Flash attention over per-head tensors: q,k [B][H][Npad][64], vT [B][H][64][Npad] -> ctx [B*Npad][H*64].
 // Scores are NOT rescaled inside (1/sqrt(dh) is folded into the packed q weights).
