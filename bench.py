@@ -26,7 +26,9 @@ from radzero_amd.config import RadZeroConfig, attention_flops_per_image_layer, f
 from radzero_amd.synthetic import synthetic_prompts  # noqa: E402
 from radzero_amd.weights import make_state_dict  # noqa: E402
 
-PEAK_TFLOPS = {"bf16": 2500.0, "f16": 2500.0, "f32": 157.3}   # dense MFMA peaks, MI355X_MICROARCH.md
+# dense MFMA peaks, MI355X_MICROARCH.md.  fp32 mode computes every product as THREE f16 MFMAs over hi/lo-split operands, so
+# an algorithmic FLOP is priced against the f16 pipe / 3 (the exact-fp32 MFMA peak, 157.3 TFLOP/s, applies with both split switches off)
+PEAK_TFLOPS = {"bf16": 2500.0, "f16": 2500.0, "f32": 2500.0 / 3}
 DTYPES = {"bf16": torch.bfloat16, "f16": torch.float16, "f32": torch.float32}
 
 
@@ -325,7 +327,7 @@ def main():
             flops_launch = args.steps * cfg.num_blocks * B * attention_flops_per_image_layer(cfg, S) / launches
             achieved = flops_launch / (avg_ms * 1e-3) / 1e12
             traffic, traffic_rnd = pmc_traffic("flash_attn_kernel", B, S, args.dtype)
-            res["roofline"] = {"kernel": "flash_attn_kernel", "bound": "mfma", "achieved": round(achieved, 2),
+            res["roofline"] = {"kernel": "flash_attn_split_kernel" if args.dtype == "f32" else "flash_attn_kernel", "bound": "mfma", "achieved": round(achieved, 2),
                                "peak": PEAK_TFLOPS[args.dtype], "unit": "TFLOP/s",
                                "frac": round(achieved / PEAK_TFLOPS[args.dtype], 4),
                                "traffic": traffic,
