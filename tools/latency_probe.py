@@ -1,3 +1,5 @@
+"""Single-image latency of compute_logits, eager and replayed as one hipGraph, bf16 and fp32, 224 / 518 / 1024 px (GPU box):
+  python tools/latency_probe.py"""
 import time, torch, numpy as np, sys
 sys.path.insert(0, ".")
 from radzero_amd.config import RadZeroConfig
