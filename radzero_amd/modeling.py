@@ -410,6 +410,14 @@ class RadZeroModel:
         run.graph = graph
         return run
 
+    # ---- library switches ------------------------------------------------------------------------
+    @staticmethod
+    def set_option(name: str, value: int) -> None:
+        """Process-wide switch of the HIP library (include/radzero_hip.h, rz_set_option), e.g. set_option("gemm_f32_split", 0) and
+        set_option("attn_f32_split", 0): fp32 mode on the exact-fp32 MFMA kernels instead of the hi/lo-split f16 ones."""
+        lib = _lib.load()
+        _lib.check(lib.rz_set_option(name.encode(), int(value)), "rz_set_option")
+
     # ---- measurement -----------------------------------------------------------------------------
     def profile(self, enable: bool):
         _lib.check(self._lib.rz_profile_enable(self._h, int(enable)), "rz_profile_enable")

@@ -76,3 +76,15 @@ def test_host_tables_match_oracle():
         tbl = relative_position_bucket_table(L)
         assert torch.equal(bias, w[tbl].permute(2, 0, 1))
         assert np.all(np.isfinite(bias.numpy()))
+
+
+def test_set_option_known_and_unknown_names():
+    """RadZeroModel.set_option -> rz_set_option: every documented switch is accepted (and restored), an unknown name raises ValueError.
+    No compute call: runs without a GPU."""
+    from radzero_amd.modeling import RadZeroModel
+    defaults = {"gemm_variant": 0, "attn_variant": 0, "ln_fused": 1, "attn_f32_split": 1, "gemm_f32_split": 1, "vision_chunk": 0,
+                "vision_streams": 1, "mlp_chunk": 0, "gemm_skew": 0}
+    for name, value in defaults.items():
+        RadZeroModel.set_option(name, value)
+    with pytest.raises(ValueError):
+        RadZeroModel.set_option("no_such_option", 1)
