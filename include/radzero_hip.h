@@ -185,6 +185,7 @@ int rz_debug_buffer(const char* what, void* dev_ptr);
 
 /* ---- measurement: HIP-event timing of kernel families on the launch stream ---- */
 enum rz_prof_family { RZ_PROF_ATTN = 0, RZ_PROF_GEMM = 1, RZ_PROF_ROWOPS = 2, RZ_PROF_VLCABS = 3, RZ_PROF_NFAM = 4 };
+/* enable: 0 off | 1 every family | 1 + (mask << 1): only the families whose bit (1 << rz_prof_family) is set in mask */
 int rz_profile_enable(rz_handle_t h, int enable);
 /* after a stream synchronize: total milliseconds and launch count per family since enable; resets them */
 int rz_profile_read(rz_handle_t h, float* ms_per_family, int64_t* launches_per_family);

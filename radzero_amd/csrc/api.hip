@@ -133,6 +133,7 @@ struct rz_model {
     int last_batch = 0, last_nvalid = 0, last_npad = 0;
     // profiling
     bool prof = false;
+    unsigned prof_mask = 0xF;   // kernel families that record events (bit = rz_prof_family)
     struct Ev { hipEvent_t a, b; int fam; };
     std::vector<Ev> ev_pool;
     size_t ev_used = 0;
@@ -168,7 +169,7 @@ struct ProfScope {
     hipStream_t s;
     int idx = -1;
     ProfScope(rz_model* m_, int fam, hipStream_t s_) : m(m_), s(s_) {
-        if (!m->prof || m->ev_used >= (1u << 20)) return;      // bounded: profiling left on without reads stops recording
+        if (!m->prof || !((m->prof_mask >> fam) & 1u) || m->ev_used >= (1u << 20)) return;      // bounded: profiling left on without reads stops recording
         if (m->ev_used == m->ev_pool.size()) {
             rz_model::Ev e;
             if (hipEventCreate(&e.a) != hipSuccess || hipEventCreate(&e.b) != hipSuccess) return;
@@ -1108,6 +1109,7 @@ int rz_set_option(const char* name, int value) {
 int rz_profile_enable(rz_handle_t m, int enable) {
     if (!m) return fail(RZ_ERR_INVALID, "null handle");
     m->prof = enable != 0;
+    m->prof_mask = enable > 1 ? ((unsigned)enable >> 1) & 0xFu : 0xFu;      // enable = 1: every family; 1 | mask << 1: only the families in mask
     m->ev_used = 0;
     for (int i = 0; i < RZ_PROF_NFAM; ++i) { m->prof_ms[i] = 0.f; m->prof_n[i] = 0; }
     return 0;

@@ -419,8 +419,12 @@ class RadZeroModel:
         _lib.check(lib.rz_set_option(name.encode(), int(value)), "rz_set_option")
 
     # ---- measurement -----------------------------------------------------------------------------
-    def profile(self, enable: bool):
-        _lib.check(self._lib.rz_profile_enable(self._h, int(enable)), "rz_profile_enable")
+    def profile(self, enable: bool, families=None):
+        """HIP-event timing of kernel families on the launch stream; `families` (e.g. ("attn",)) restricts the recording to those."""
+        code = int(bool(enable))
+        if enable and families is not None:
+            code = 1 + (sum(1 << _lib.PROF_FAMILIES.index(f) for f in families) << 1)
+        _lib.check(self._lib.rz_profile_enable(self._h, code), "rz_profile_enable")
 
     def profile_read(self):
         ms = (ctypes.c_float * 4)()
