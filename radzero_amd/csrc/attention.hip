@@ -3,6 +3,7 @@
 // flash_attn_kernel: softmax(Q K^T) V for the 14 Dinov2 blocks without ever materialising the
 //   (B,12,N,N) score tensor (1.36 GB fp32 per image at 1024^2).  Replaces
 //   TF:dinov2/modeling_dinov2.py:153-178 (eager_attention_forward) as called from :182-234.
+// flash_attn_split_kernel: the same contraction for the fp32 mode — operands as hi / lo f16 planes, three f16 MFMAs per product.
 // text_attn_kernel: MPNet self-attention with additive relative-position bias and key-padding mask,
 //   TF:mpnet/modeling_mpnet.py:131-171 (bias computed once per forward, :312-348).
 //
@@ -12,7 +13,8 @@
 //                   (q = lane&15, g = lane>>4), which receives rows 4g..4g+3 of every tile, owns the 8 CONTIGUOUS
 //                   keys 32kk + 8g .. +7 of each 32-key step kk (tiles 2kk and 2kk+1).
 //   softmax       : per-lane max guard and exponentials only; no cross-lane step and no LDS round trip in the hot path
-//                   (the cross-lane row maximum is needed only inside the rare re-centring branch).
+//                   (the cross-lane row maximum is needed only inside the rare re-centring branch).  bf16: no maximum at all
+//                   after tile 0 (template flag NOMAX: overflow check + tracking second pass).
 //   l^T += 1 P^T  : row sums accumulate on the matrix pipe (all-ones A fragment; template flag LS, default).
 //   O^T += V^T P^T: A = V^T fragment (row = d, 8 contiguous keys 32kk + 8g..+7: one ds_read_b128),
 //                   B = P^T packed in registers straight from the S^T accumulators (no transpose, no LDS);

@@ -11,6 +11,7 @@
 // 128 bytes per step (64 x 16-bit or 32 x f32), two LDS stages filled by global_load_lds_dwordx4 with
 // the panel XOR swizzle of rz_common.h.  M must be a multiple of 128 (callers pad rows per image),
 // N a multiple of 128, K*sizeof(T) a multiple of 128.
+// fp32 mode: launch_gemm_split_f32out — the f16 kernels over hi/lo-split operands laid side by side along K (three MFMAs per product).
 #include <cstring>
 
 #include <algorithm>
