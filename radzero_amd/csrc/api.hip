@@ -185,6 +185,12 @@ struct ProfScope {
 };
 
 int round_up(int x, int m) { return (x + m - 1) / m * m; }
+// padded token rows per image: a multiple of 128 (every GEMM M-tile and attention query block is full); of 256 when that costs less than
+// 2 % more rows, so that the 256x256 GEMM kernels apply at any batch size (one 1536^2 image: 11882 -> 12032 instead of 11904 = 46.5 x 256)
+int pad_tokens(int nv) {
+    const int p128 = round_up(nv, 128), p256 = round_up(nv, 256);
+    return (p256 - nv) * 50 <= nv ? p256 : p128;
+}
 
 bool parse_layer(const char* name, const char* prefix, int* idx, const char** rest) {
     size_t n = strlen(prefix);
@@ -636,7 +642,7 @@ int rz_weights_ready(rz_handle_t m) {
 int rz_set_position_table(rz_handle_t m, int gh, int gw, const float* pos_host) {
     if (!m || !pos_host || gh <= 0 || gw <= 0) return fail(RZ_ERR_INVALID, "rz_set_position_table: bad argument");
     if (!m->cls_loaded || !m->patch_bias_loaded) return fail(RZ_ERR_STATE, "rz_set_position_table: load cls_token and patch bias first");
-    const int D = m->D, nv = 1 + gh * gw, np = round_up(nv, 128);
+    const int D = m->D, nv = 1 + gh * gw, np = pad_tokens(nv);
     std::vector<float> tbl((size_t)np * D, 0.f);
     for (int d = 0; d < D; ++d) tbl[d] = pos_host[d] + m->cls_host[d];
     for (int t = 1; t < nv; ++t)
@@ -653,7 +659,7 @@ int rz_set_position_table(rz_handle_t m, int gh, int gw, const float* pos_host) 
 int rz_reserve(rz_handle_t m, int max_batch, int max_tokens, int max_prompts, int max_len) {
     if (!m || max_batch < 0 || max_tokens < 0 || max_prompts < 0 || max_len < 0) return fail(RZ_ERR_INVALID, "rz_reserve: bad argument");
     const size_t es = dsize(m->dt), D = m->D, F = m->F;
-    const int npad = round_up(max_tokens, 128);
+    const int npad = pad_tokens(max_tokens);
     RZ_HIP(hipDeviceSynchronize());      // buffers may be re-allocated below: wait for any forward still using the old ones
     if (max_batch > 0 && max_tokens > 0) {
         const int B = std::max(max_batch, m->cap_batch), NP = std::max(npad, m->cap_npad);

@@ -173,7 +173,7 @@ if __name__ == "__main__":
     if a.what in ("attn", "all"):
         bench_attn(a.images, n=a.tokens, dt=a.dtype, zeros=a.zeros)
     if a.what in ("gemm", "all"):
-        bench_gemm(a.images, dt=a.dtype)
+        bench_gemm(a.images, n=a.tokens, dt=a.dtype)
     if a.what == "gemmab":
         bench_gemm_ab(a.images, dt=a.dtype)
     if a.what == "library":
