@@ -165,22 +165,33 @@ size_t rz_flash_attention_split_workspace(int batch, int heads, int n_pad);
 int rz_flash_attention_f32_split(const float* q_dev, const float* k_dev, const float* v_t_dev, float* ctx_dev, void* workspace_dev,
                                  int batch, int heads, int n_valid, int n_pad, void* stream);
 
-/* process-wide tuning / A-B switches (measurement only; defaults are the measured-fastest choices, 0 restores them):
+/* Tuning / A-B switches.  rz_set_option sets the PROCESS-WIDE value (what the measurement tools flip); rz_set_model_option sets one
+ * handle's own value, which then overrides the process-wide one for that handle only (INT32_MIN = follow the process-wide value again):
+ * two handles of one process can differ.  Defaults are the measured-fastest choices.
  *   "gemm_variant"     0 auto | 1 128x128 two-stage | 3 256x256 two-stage | 7 256x256 staggered 8-phase (16-bit, gemm7.hip)
  *                      | 8 the same K loop as a persistent kernel, one workgroup per CU (16-bit, gemm8.hip; default for big shapes)
- *                      | 9 = 7 with in-kernel s_memtime stamps (EPI_STORE only; stamps land in the `resid_dev` buffer)
- *   "gemm_v1_only"     1 = same as gemm_variant 1
- *   "attn_variant"     0/1 default (16x16x32 MFMA, 4 waves x 32 query rows, row sums on the matrix pipe; bf16 without the running
- *                      maximum in the hot loop) | 417 the same with it | 16 VALU row sums | 8 eight waves | 64 sixty-four query rows per wave
+ *   "gemm_v1_only"     (process-wide only) 1 = same as gemm_variant 1
+ *   "attn_variant"     0 default (16x16x32 MFMA, 4 waves x 32 query rows, row sums on the matrix pipe; bf16 without the running
+ *                      maximum in the hot loop) | 417 the same with it (what f16 always runs)
  *   "attn_f32_split"   1 (default) = fp32 mode runs attention as hi/lo-split f16 MFMAs; 0 = exact-fp32 MFMAs (16x16x4_f32)
- *   "ln_fused"         1 (default) = the blocks' LayerNorms are fused into the GEMMs either side of them where the persistent
- *                      kernel applies (16-bit modes, >= 2 images of 1024^2); 0 = stand-alone LayerNorm kernels everywhere
+ *   "gemm_f32_split"   1 (default) = fp32 mode runs the vision encoder's GEMMs as hi/lo-split f16 MFMAs; 0 = exact-fp32 MFMAs
+ *   "f32_split_guard"  1 (default) = fp32 mode: a forward in which a value left the f16 range of the hi/lo planes (|x| > 65504) is
+ *                      repeated on the exact-fp32 kernels before rz_vision_forward returns (one stream synchronisation per forward;
+ *                      not under stream capture); rz_get_model_option(h, "f32_split_guard_reruns") counts the repeats
+ *   "ln_fused"         1 (default) = the blocks' LayerNorms are fused into the GEMMs either side of them (16-bit modes);
+ *                      0 = stand-alone LayerNorm kernels everywhere
+ *   "pad_rows"         token rows per image are padded to: 0 (default) a multiple of 128, of 256 where that costs < 2 % more rows
+ *                      | 128 | 256 always that multiple.  Setting it on a handle drops its position tables and workspace sizes
+ *                      (call rz_set_position_table / rz_reserve again).
  *   "vision_chunk"     images per internal pass of rz_vision_forward (0 = whole batch)
  *   "vision_streams"   2 = two halves of the batch on two internal streams
  *   "mlp_chunk"        images per fc1->fc2 pass (0 = whole batch, -1 = ~126 MiB of hidden activations) */
 int rz_set_option(const char* name, int value);
-/* diagnostic builds only (tools/kstamp8.py): "gemm_v8_stamps" = device buffer of 256 x 8 x 32 uint64 that the stamped build of
- * the persistent GEMM fills with per-wave K-loop / epilogue times (100 MHz ticks); NULL switches the stamped build off again */
+int rz_set_model_option(rz_handle_t h, const char* name, int value);
+/* the value in force for this handle (its own, else the process-wide one); also "f32_split_guard_reruns" */
+int rz_get_model_option(rz_handle_t h, const char* name, int* value_out);
+/* diagnostic library builds only (-DRZ_EXPERIMENTS, tools/kstamp8.py): "gemm_v8_stamps" = device buffer of 256 x 8 x 32 uint64 that the
+ * stamped build of the persistent GEMM fills with per-wave K-loop / epilogue times; the production library knows no buffer */
 int rz_debug_buffer(const char* what, void* dev_ptr);
 
 /* ---- measurement: HIP-event timing of kernel families on the launch stream ---- */

@@ -128,6 +128,8 @@ SYMBOLS = {
     "rz_flash_attention_split_workspace": (ctypes.c_size_t, [_I, _I, _I]),
     "rz_flash_attention_f32_split": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "rz_set_option": (_I, [ctypes.c_char_p, _I]),
+    "rz_set_model_option": (_I, [_P, ctypes.c_char_p, _I]),
+    "rz_get_model_option": (_I, [_P, ctypes.c_char_p, ctypes.POINTER(_I)]),
     "rz_debug_buffer": (_I, [ctypes.c_char_p, _P]),
     "rz_profile_enable": (_I, [_P, _I]),
     "rz_profile_read": (_I, [_P, _P, _P]),

@@ -88,20 +88,36 @@ def _shape_facts(state_dict) -> dict:
         return facts
     def depth(prefix):
         idx = {int(k[len(prefix):].split(".", 1)[0]) for k in state_dict if k.startswith(prefix)}
-        return (max(idx) + 1) if idx else 0
+        return (max(idx) + 1) if idx else None
     shape = lambda k: tuple(np.shape(state_dict[k])) if k in state_dict else None
-    facts["vit_layers"] = depth("vision_model.encoder.layer.")
-    facts["align_layers"] = depth("align_transformer.transformer_layers.layer.")
-    facts["text_layers"] = depth("text_model.encoder.layer.")
+    # a layer count is a fact only when the checkpoint has at least one key of that stack: a vision-only or partial state dict
+    # says nothing about the others (config.json / the defaults keep speaking for them)
+    for field, prefix in (("vit_layers", "vision_model.encoder.layer."), ("align_layers", "align_transformer.transformer_layers.layer."),
+                          ("text_layers", "text_model.encoder.layer.")):
+        n = depth(prefix)
+        if n is not None:
+            facts[field] = n
     we = shape("text_model.embeddings.word_embeddings.weight")
     pe = shape("text_model.embeddings.position_embeddings.weight")
     rb = shape("text_model.encoder.relative_attention_bias.weight")
     inter = shape("text_model.encoder.layer.0.intermediate.dense.weight")
     vpos = shape("vision_model.embeddings.position_embeddings")
+    cls = shape("vision_model.embeddings.cls_token")
     pw = shape("vision_model.embeddings.patch_embeddings.projection.weight")
-    if we: facts["vocab_size"], facts["hidden_size"] = we
+    fc1 = shape("vision_model.encoder.layer.0.mlp.fc1.weight")
+    # the shared width and the head count are VISION-side fields of RadZeroConfig: they come from vision tensors.  The text side has
+    # to agree (one `hidden_size` / `num_attention_heads` serves both encoders and the VL-CABS head): a mismatch is an error, not
+    # something to overwrite silently.
+    vis_hidden = (pw[0] if pw else None) or (cls[-1] if cls else None)
+    if vis_hidden: facts["hidden_size"] = vis_hidden
+    if fc1 and vis_hidden and fc1[1] == vis_hidden and fc1[0] % vis_hidden == 0: facts["mlp_ratio"] = fc1[0] // vis_hidden
+    if we:
+        facts["vocab_size"] = we[0]
+        if vis_hidden and we[1] != vis_hidden:
+            raise ValueError(f"text embedding width {we[1]} differs from the vision width {vis_hidden}: not a CxrAlignModel checkpoint this path supports")
+        if not vis_hidden: facts["hidden_size"] = we[1]
     if pe: facts["max_position_embeddings"] = pe[0]
-    if rb: facts["relative_attention_num_buckets"], facts["num_attention_heads"] = rb
+    if rb: facts["relative_attention_num_buckets"], facts["text_num_attention_heads"] = rb
     if inter: facts["text_intermediate_size"] = inter[0]
     if pw: facts["num_channels"], facts["patch_size"] = pw[1], pw[2]
     if vpos and pw:
@@ -144,7 +160,11 @@ def config_from_hf(path_or_dict, state_dict=None) -> RadZeroConfig:
         loss_temperature=loss.get("loss_temperature", base.loss_temperature),
         sim_op=loss.get("sim_op", base.sim_op),
     )
-    fields.update(_shape_facts(state_dict))
+    facts = _shape_facts(state_dict)
+    text_heads = facts.pop("text_num_attention_heads", None)          # MPNet's head count (relative_attention_bias columns)
+    fields.update(facts)
+    if text_heads is not None and text_heads != fields["num_attention_heads"]:
+        raise ValueError(f"MPNet has {text_heads} attention heads, the vision encoder {fields['num_attention_heads']}: the kernels share one head count")
     cfg = RadZeroConfig(**fields)
     if a.get("use_layer_norm"):
         raise NotImplementedError("align_transformer_config.use_layer_norm=True is not part of the released model")

@@ -23,19 +23,43 @@ int fail(int code, const std::string& msg) {
     g_err = msg;
     return code;
 }
-// 0 = auto (= 1: measured fastest in bench.py, 1000 TFLOP/s); 1 = 16x16x32 kernel, 4 waves/128 q rows; 8 = same kernel, 8 waves/256 q rows;
-// 64 = 16x16x32 kernel, 4 waves x 64 q rows (4 q tiles per wave);
-int g_vision_chunk = 0;   // images per pass of rz_vision_forward (0 = whole batch)
-int g_vision_streams = 1; // 2 = split the batch over two internal HIP streams
-int g_mlp_chunk = 0;      // images per fc1->fc2 pass (0 = whole batch = default, -1 = auto ~126 MiB of hidden rows): run_chunk in rz_vision_forward
-int g_attn_variant = 0;
-int g_gemm_f32_split = 1; // fp32 mode: the vision encoder's GEMMs on the f16 matrix pipe with hi/lo-split operands (0 = exact-fp32 MFMAs)
-int g_attn_f32_split = 1; // fp32 mode: attention on the f16 matrix pipe with hi/lo-split operands (0 = exact-fp32 MFMAs)
-int g_ln_fused = 1;       // 1 = fuse the blocks' LayerNorms into the GEMMs either side where the persistent kernel applies (16-bit modes)
+// Tuning / A-B switches.  Every handle owns a set (rz_set_model_option); a field left at RZ_OPT_INHERIT follows the process-wide value
+// (rz_set_option: what the measurement tools flip), so two handles of one process can differ and a test that sets a handle's option
+// cannot leak into another handle.
+constexpr int RZ_OPT_INHERIT = INT32_MIN;
+struct Options {
+    int vision_chunk;     // images per pass of rz_vision_forward (0 = whole batch)
+    int vision_streams;   // 2 = split the batch over two internal HIP streams
+    int mlp_chunk;        // images per fc1->fc2 pass (0 = whole batch = default, -1 = auto ~126 MiB of hidden rows): run_chunk in rz_vision_forward
+    int attn_variant;     // 0 = default; see include/radzero_hip.h
+    int gemm_variant;     // 0 = auto; see include/radzero_hip.h
+    int gemm_f32_split;   // fp32 mode: the vision encoder's GEMMs on the f16 matrix pipe with hi/lo-split operands (0 = exact-fp32 MFMAs)
+    int attn_f32_split;   // fp32 mode: attention on the f16 matrix pipe with hi/lo-split operands (0 = exact-fp32 MFMAs)
+    int ln_fused;         // 1 = fuse the blocks' LayerNorms into the GEMMs either side where the persistent kernel applies (16-bit modes)
+    int pad_rows;         // token rows per image: 0 = multiple of 128, of 256 when that costs < 2 % more rows | 128 | 256 = always that multiple
+    int f32_split_guard;  // fp32 mode: 1 = a forward whose f16 planes overflowed is repeated on the exact-fp32 kernels (default)
+};
+Options g_opt = {0, 1, 0, 0, 0, 1, 1, 1, 0, 1};
+const Options kInherit = {RZ_OPT_INHERIT, RZ_OPT_INHERIT, RZ_OPT_INHERIT, RZ_OPT_INHERIT, RZ_OPT_INHERIT, RZ_OPT_INHERIT, RZ_OPT_INHERIT,
+                          RZ_OPT_INHERIT, RZ_OPT_INHERIT, RZ_OPT_INHERIT};
+int* option_field(Options& o, const char* name) {
+    if (!strcmp(name, "vision_chunk")) return &o.vision_chunk;
+    if (!strcmp(name, "vision_streams")) return &o.vision_streams;
+    if (!strcmp(name, "mlp_chunk")) return &o.mlp_chunk;
+    if (!strcmp(name, "attn_variant")) return &o.attn_variant;
+    if (!strcmp(name, "gemm_variant")) return &o.gemm_variant;
+    if (!strcmp(name, "gemm_f32_split")) return &o.gemm_f32_split;
+    if (!strcmp(name, "attn_f32_split")) return &o.attn_f32_split;
+    if (!strcmp(name, "ln_fused")) return &o.ln_fused;
+    if (!strcmp(name, "pad_rows")) return &o.pad_rows;
+    if (!strcmp(name, "f32_split_guard")) return &o.f32_split_guard;
+    return nullptr;
+}
+inline int pick(int own, int process_wide) { return own == RZ_OPT_INHERIT ? process_wide : own; }
 
-hipError_t flash_attn(int dt, const void* q, const void* k, const void* vt, void* ctx, int64_t bs, int B, int H, int nv, int np,
+hipError_t flash_attn(int variant, int dt, const void* q, const void* k, const void* vt, void* ctx, int64_t bs, int B, int H, int nv, int np,
                       hipStream_t s) {
-    return launch_flash_attn(dt, q, k, vt, ctx, bs, B, H, nv, np, (g_attn_variant == 8 || g_attn_variant == 64 || g_attn_variant == 16 || g_attn_variant == 417) ? g_attn_variant : 4, s);
+    return launch_flash_attn(dt, q, k, vt, ctx, bs, B, H, nv, np, (variant == 16 || variant == 417) ? variant : 4, s);
 }
 
 int hip_fail(hipError_t e, const char* what) {
@@ -68,6 +92,10 @@ uint16_t f32_to_f16(float f) {
 struct DevBuf {
     void* p = nullptr;
     size_t bytes = 0;
+    DevBuf() = default;
+    DevBuf(const DevBuf&) = delete;
+    DevBuf& operator=(const DevBuf&) = delete;
+    ~DevBuf() { release(); }            // a buffer added to rz_model can no longer be forgotten in rz_destroy
     hipError_t ensure(size_t n, bool zero) {
         if (n <= bytes) return hipSuccess;
         if (p) (void)hipFree(p);
@@ -110,6 +138,26 @@ struct TextLayer {       // TF:mpnet/modeling_mpnet.py:234-261
 
 struct rz_model {
     rz_config cfg;
+    Options opt = kInherit;
+    int o_vision_chunk() const { return pick(opt.vision_chunk, g_opt.vision_chunk); }
+    int o_vision_streams() const { return pick(opt.vision_streams, g_opt.vision_streams); }
+    int o_mlp_chunk() const { return pick(opt.mlp_chunk, g_opt.mlp_chunk); }
+    int o_attn_variant() const { return pick(opt.attn_variant, g_opt.attn_variant); }
+    int o_gemm_variant() const { return pick(opt.gemm_variant, g_opt.gemm_variant); }
+    bool o_gemm_f32_split() const { return pick(opt.gemm_f32_split, g_opt.gemm_f32_split) != 0 && !force_exact; }
+    bool o_attn_f32_split() const { return pick(opt.attn_f32_split, g_opt.attn_f32_split) != 0 && !force_exact; }
+    bool o_ln_fused() const { return pick(opt.ln_fused, g_opt.ln_fused) != 0; }
+    int o_pad_rows() const { return pick(opt.pad_rows, g_opt.pad_rows); }
+    bool o_guard() const { return pick(opt.f32_split_guard, g_opt.f32_split_guard) != 0; }
+    bool force_exact = false;            // set while a forward is repeated on the exact-fp32 kernels (overflow guard)
+    // padded token rows per image: a multiple of 128 (every GEMM M-tile and attention query block is full); of 256 when that costs less
+    // than 2 % more rows, so that the 256x256 GEMM kernels apply at any batch size (one 1536^2 image: 11882 -> 12032 instead of 11904)
+    int pad_tokens(int nv) const {
+        const int p128 = (nv + 127) / 128 * 128, p256 = (nv + 255) / 256 * 256, rule = o_pad_rows();
+        if (rule == 128) return p128;
+        if (rule == 256) return p256;
+        return (p256 - nv) * 50 <= nv ? p256 : p128;
+    }
     int dt;               // compute dtype
     int D, H, F, KP, KPAD;
     std::vector<DinoBlock> blocks;
@@ -126,6 +174,9 @@ struct rz_model {
     DevBuf h, xn, qk, vt, ctx, mid, vws, qhat, lnpart, lnstat, lnmu;      // xn doubles as the residual's T copy on the fused-LayerNorm path
     DevBuf th, txn, tqkv, tctx, tmid, tsum;
     DevBuf asplit;                       // fp32 mode: [hi | lo | hi] f16 planes of the A operand of the GEMM in flight (3 x max K per token row)
+    DevBuf ovf;                          // fp32 mode: one word the hi/lo-split producers OR into when a value leaves the f16 range
+    unsigned* ovf_host = nullptr;        // pinned mirror of it
+    int64_t guard_reruns = 0;            // forwards repeated on the exact-fp32 kernels since rz_create
     struct SplitW { const char* p; size_t bytes; const char* p3; };
     std::vector<SplitW> split_w;         // fp32 weight matrix -> its split copy
     bool split_dirty = true;             // a weight was (re)loaded since the split copies were built
@@ -185,12 +236,6 @@ struct ProfScope {
 };
 
 int round_up(int x, int m) { return (x + m - 1) / m * m; }
-// padded token rows per image: a multiple of 128 (every GEMM M-tile and attention query block is full); of 256 when that costs less than
-// 2 % more rows, so that the 256x256 GEMM kernels apply at any batch size (one 1536^2 image: 11882 -> 12032 instead of 11904 = 46.5 x 256)
-int pad_tokens(int nv) {
-    const int p128 = round_up(nv, 128), p256 = round_up(nv, 256);
-    return (p256 - nv) * 50 <= nv ? p256 : p128;
-}
 
 bool parse_layer(const char* name, const char* prefix, int* idx, const char** rest) {
     size_t n = strlen(prefix);
@@ -238,18 +283,20 @@ int load_dino_block(rz_model* m, DinoBlock& b, const char* rest, const float* da
         t.loaded = true;
         return 0;
     };
-    const bool keep = m->dt != RZ_F32;       // host copies for the fused-LayerNorm packing (fold_block)
-    b.folded = false;
-    if (!strcmp(rest, "norm1.weight")) { if (keep) b.h_g1.assign(data, data + numel); return vec(b.ln1_g, D); }
-    if (!strcmp(rest, "norm1.bias")) { if (keep) b.h_be1.assign(data, data + numel); return vec(b.ln1_b, D); }
-    if (!strcmp(rest, "norm2.weight")) { if (keep) b.h_g2.assign(data, data + numel); return vec(b.ln2_g, D); }
-    if (!strcmp(rest, "norm2.bias")) { if (keep) b.h_be2.assign(data, data + numel); return vec(b.ln2_b, D); }
+    // host copies for the fused-LayerNorm packing (fold_block): kept for the life of the handle (16.5 MB per block), so that a
+    // partial reload (load_state_dict(strict=False), one rz_load_weight) re-folds from complete data; only the tensors that enter
+    // c1 / c2 (norm1 / norm2, q|k|v, fc1) invalidate the fold
+    const bool keep = m->dt != RZ_F32;
+    if (!strcmp(rest, "norm1.weight")) { if (keep) { b.h_g1.assign(data, data + numel); b.folded = false; } return vec(b.ln1_g, D); }
+    if (!strcmp(rest, "norm1.bias")) { if (keep) { b.h_be1.assign(data, data + numel); b.folded = false; } return vec(b.ln1_b, D); }
+    if (!strcmp(rest, "norm2.weight")) { if (keep) { b.h_g2.assign(data, data + numel); b.folded = false; } return vec(b.ln2_g, D); }
+    if (!strcmp(rest, "norm2.bias")) { if (keep) { b.h_be2.assign(data, data + numel); b.folded = false; } return vec(b.ln2_b, D); }
     if (!strcmp(rest, "layer_scale1.lambda1")) return vec(b.ls1, D);
     if (!strcmp(rest, "layer_scale2.lambda1")) return vec(b.ls2, D);
     if (!strcmp(rest, "attention.output.dense.weight")) return mat(b.wo, D, D);
     if (!strcmp(rest, "attention.output.dense.bias")) return vec(b.bo, D);
-    if (!strcmp(rest, "mlp.fc1.weight")) { if (keep) b.h_w1.assign(data, data + numel); return mat(b.w1, F, D); }
-    if (!strcmp(rest, "mlp.fc1.bias")) { if (keep) b.h_b1.assign(data, data + numel); return vec(b.b1, F); }
+    if (!strcmp(rest, "mlp.fc1.weight")) { if (keep) { b.h_w1.assign(data, data + numel); b.folded = false; } return mat(b.w1, F, D); }
+    if (!strcmp(rest, "mlp.fc1.bias")) { if (keep) { b.h_b1.assign(data, data + numel); b.folded = false; } return vec(b.b1, F); }
     if (!strcmp(rest, "mlp.fc2.weight")) return mat(b.w2, D, F);
     if (!strcmp(rest, "mlp.fc2.bias")) return vec(b.b2, D);
     const char* names[3] = {"query", "key", "value"};
@@ -264,6 +311,7 @@ int load_dino_block(rz_model* m, DinoBlock& b, const char* rest, const float* da
             if (keep) {
                 b.h_wqkv.resize(3 * D * D);
                 for (size_t e = 0; e < D * D; ++e) b.h_wqkv[i * D * D + e] = data[e] * (i == 0 ? qscale : 1.f);
+                b.folded = false;
             }
             b.qkv_parts |= (1 << i);
             return 0;
@@ -275,6 +323,7 @@ int load_dino_block(rz_model* m, DinoBlock& b, const char* rest, const float* da
             if (keep) {
                 b.h_bqkv.resize(3 * D);
                 for (size_t e = 0; e < D; ++e) b.h_bqkv[i * D + e] = data[e] * (i == 0 ? qscale : 1.f);
+                b.folded = false;
             }
             b.qkv_parts |= (8 << i);
             return 0;
@@ -364,7 +413,7 @@ int gemm_f32_split(rz_model* m, int epi, GemmArgs g, int a_mode, bool out_split,
         if (!(row_in(m->xn, (size_t)m->D * 6, &row) || row_in(m->ctx, (size_t)m->D * 6, &row) || row_in(m->mid, maxk * 6, &row))) return 0;
         char* a3 = (char*)m->asplit.p + row * 3 * maxk * 2;
         if (a3 + (size_t)g.M * 3 * g.K * 2 > (char*)m->asplit.p + m->asplit.bytes) return 0;
-        if (a_mode == A_F32) RZ_HIP(launch_split3((const float*)g.A, g.lda, a3, g.M, g.K, 0, s));
+        if (a_mode == A_F32) RZ_HIP(launch_split3((const float*)g.A, g.lda, a3, g.M, g.K, 0, g.ovf_flag, s));
         g.A = a3;
     }
     g.W = w3; g.lda = g.ldw = 3 * (int64_t)g.K; g.K = 3 * g.K;
@@ -380,8 +429,9 @@ int gemm(rz_model* m, int epi, const void* A, int64_t lda, const void* W, int64_
     GemmArgs g;
     g.A = A; g.lda = lda; g.W = W; g.ldw = ldw; g.M = M; g.N = N; g.K = K; g.bias = bias; g.out = out; g.ldo = ldo;
     g.scale = scale; g.resid = resid; g.ldr = ldr; g.rows_per_image = rpi; g.heads_total = heads; g.plane_off = plane_off;
+    g.variant = m->o_gemm_variant(); g.ovf_flag = (unsigned*)m->ovf.p;
     ProfScope ps(m, RZ_PROF_GEMM, s);
-    if (m->dt == RZ_F32 && g_gemm_f32_split) {
+    if (m->dt == RZ_F32 && m->o_gemm_f32_split()) {
         bool done = false;
         int rc = gemm_f32_split(m, epi, g, a_mode, out_split, s, &done);
         if (rc || done) return rc;
@@ -422,11 +472,11 @@ int fold_matrix(rz_model* m, const std::vector<float>& W, const std::vector<floa
 
 int fold_block(rz_model* m, DinoBlock& b) {
     if (b.folded) return 0;
+    if (b.qkv_parts != 63) return fail(RZ_ERR_STATE, "fused LayerNorm packing: q|k|v pieces of the block are incomplete");
     const size_t D = m->D, F = m->F;
     int rc;
     if ((rc = fold_matrix(m, b.h_wqkv, b.h_bqkv, b.h_g1, b.h_be1, 3 * D, D, b.c1qkv, b.c2qkv))) return rc;
     if ((rc = fold_matrix(m, b.h_w1, b.h_b1, b.h_g2, b.h_be2, F, D, b.c1_1, b.c2_1))) return rc;
-    for (auto* v : {&b.h_wqkv, &b.h_bqkv, &b.h_w1, &b.h_b1, &b.h_g1, &b.h_be1, &b.h_g2, &b.h_be2}) std::vector<float>().swap(*v);
     b.folded = true;
     return 0;
 }
@@ -437,7 +487,7 @@ int gemm_ln(rz_model* m, int epi, const void* hb, const Tensor& wf, const Tensor
     GemmArgs g;
     g.A = hb; g.lda = m->D; g.W = wf.p; g.ldw = m->D; g.M = M; g.N = N; g.K = m->D; g.bias = (const float*)c2.p; g.out = out; g.ldo = ldo;
     g.scale = (const float*)c1.p; g.resid = nullptr; g.ldr = 0; g.rows_per_image = np; g.heads_total = heads;
-    g.out2 = out2; g.heads_total2 = heads2; g.split_n = split_n; g.ln_stat = stat;
+    g.out2 = out2; g.heads_total2 = heads2; g.split_n = split_n; g.ln_stat = stat; g.variant = m->o_gemm_variant();
     ProfScope ps(m, RZ_PROF_GEMM, s);
     RZ_HIP(launch_gemm(m->dt, epi, g, s));
     return 0;
@@ -450,7 +500,7 @@ int gemm_resid_ln(rz_model* m, const void* A, int64_t lda, const Tensor& W, cons
     GemmArgs g;
     g.A = A; g.lda = lda; g.W = W.p; g.ldw = K; g.M = M; g.N = m->D; g.K = K; g.bias = (const float*)bias.p; g.out = nullptr; g.ldo = 0;
     g.scale = (const float*)ls.p; g.resid = h; g.ldr = m->D; g.rows_per_image = np; g.heads_total = 0; g.ln_part = part; g.ln_hb = hb; g.ln_gamma = (const float*)next_gamma.p; g.ln_mu = mu;
-   
+    g.variant = m->o_gemm_variant();
     {
         ProfScope ps(m, RZ_PROF_GEMM, s);
         RZ_HIP(launch_gemm(m->dt, EPI_RESID_SCALE_LN, g, s));
@@ -465,7 +515,7 @@ int gemm_qkv(rz_model* m, const void* xn, const DinoBlock& b, int M, int np, voi
     GemmArgs g;
     g.A = xn; g.lda = D; g.W = b.wqkv.p; g.ldw = D; g.M = M; g.N = 3 * D; g.K = D; g.bias = (const float*)b.bqkv.p;
     g.out = qk; g.ldo = 0; g.scale = nullptr; g.resid = nullptr; g.ldr = 0; g.rows_per_image = np; g.heads_total = 2 * H;
-    g.out2 = vt; g.heads_total2 = H; g.split_n = 2 * D;
+    g.out2 = vt; g.heads_total2 = H; g.split_n = 2 * D; g.variant = m->o_gemm_variant();
     if (gemm_qkv_fused_ok(m->dt, g)) {
         ProfScope ps(m, RZ_PROF_GEMM, s);
         RZ_HIP(launch_gemm(m->dt, EPI_QKV, g, s));
@@ -515,9 +565,7 @@ int rz_destroy(rz_handle_t m) {
     (void)hipDeviceSynchronize();        // nothing of this handle may still be in flight when its buffers go away
     for (void* p : m->allocs) (void)hipFree(p);
     for (auto& kv : m->pos_tables) kv.second.buf.release();
-    DevBuf* bufs[] = {&m->h, &m->xn, &m->qk, &m->vt, &m->ctx, &m->mid, &m->vws, &m->qhat, &m->lnpart, &m->lnstat, &m->lnmu,
-                      &m->th, &m->txn, &m->tqkv, &m->tctx, &m->tmid, &m->tsum};
-    for (DevBuf* b : bufs) b->release();
+    if (m->ovf_host) (void)hipHostFree(m->ovf_host);
     for (auto& e : m->ev_pool) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
     if (m->side_ready) {
         for (int i = 0; i < 2; ++i) { (void)hipStreamDestroy(m->side[i]); (void)hipEventDestroy(m->side_done[i]); }
@@ -619,12 +667,16 @@ int rz_weights_ready(rz_handle_t m) {
             if ((rc = fold_block(m, b))) return rc;
     if (m->dt == RZ_F32 && m->split_dirty) {     // f16 [hi | hi | lo] copies of the vision encoder's matrices for the hi/lo-split GEMMs
         m->split_w.clear();
+        // overflow guard words: [0] activations (cleared by every forward), [1] weights (checked here, once)
+        RZ_HIP(m->ovf.ensure(8, true));
+        if (!m->ovf_host) RZ_HIP(hipHostMalloc((void**)&m->ovf_host, 8, hipHostMallocDefault));
+        RZ_HIP(hipMemset(m->ovf.p, 0, 8));
         auto split = [&](Tensor& t, size_t N, size_t K) -> int {
             if (!t.p3) {
                 RZ_HIP(hipMalloc(&t.p3, N * 3 * K * 2));
                 m->allocs.push_back(t.p3);
             }
-            RZ_HIP(launch_split3((const float*)t.p, (int64_t)K, t.p3, (int64_t)N, (int)K, 1, nullptr));
+            RZ_HIP(launch_split3((const float*)t.p, (int64_t)K, t.p3, (int64_t)N, (int)K, 1, (unsigned*)m->ovf.p + 1, nullptr));
             m->split_w.push_back({(const char*)t.p, N * K * 4, (const char*)t.p3});
             return 0;
         };
@@ -634,6 +686,8 @@ int rz_weights_ready(rz_handle_t m) {
             if ((rc = split(b.wqkv, 3 * D, D)) || (rc = split(b.wo, D, D)) || (rc = split(b.w1, F, D)) || (rc = split(b.w2, D, F))) return rc;
         }
         RZ_HIP(hipDeviceSynchronize());
+        RZ_HIP(hipMemcpy(m->ovf_host, m->ovf.p, 8, hipMemcpyDeviceToHost));
+        if (m->ovf_host[1]) m->split_w.clear();      // a weight beyond the f16 range: this checkpoint runs on the exact-fp32 GEMM kernels
         m->split_dirty = false;
     }
     return 0;
@@ -642,7 +696,7 @@ int rz_weights_ready(rz_handle_t m) {
 int rz_set_position_table(rz_handle_t m, int gh, int gw, const float* pos_host) {
     if (!m || !pos_host || gh <= 0 || gw <= 0) return fail(RZ_ERR_INVALID, "rz_set_position_table: bad argument");
     if (!m->cls_loaded || !m->patch_bias_loaded) return fail(RZ_ERR_STATE, "rz_set_position_table: load cls_token and patch bias first");
-    const int D = m->D, nv = 1 + gh * gw, np = pad_tokens(nv);
+    const int D = m->D, nv = 1 + gh * gw, np = m->pad_tokens(nv);
     std::vector<float> tbl((size_t)np * D, 0.f);
     for (int d = 0; d < D; ++d) tbl[d] = pos_host[d] + m->cls_host[d];
     for (int t = 1; t < nv; ++t)
@@ -659,7 +713,7 @@ int rz_set_position_table(rz_handle_t m, int gh, int gw, const float* pos_host) 
 int rz_reserve(rz_handle_t m, int max_batch, int max_tokens, int max_prompts, int max_len) {
     if (!m || max_batch < 0 || max_tokens < 0 || max_prompts < 0 || max_len < 0) return fail(RZ_ERR_INVALID, "rz_reserve: bad argument");
     const size_t es = dsize(m->dt), D = m->D, F = m->F;
-    const int npad = pad_tokens(max_tokens);
+    const int npad = m->pad_tokens(max_tokens);
     RZ_HIP(hipDeviceSynchronize());      // buffers may be re-allocated below: wait for any forward still using the old ones
     if (max_batch > 0 && max_tokens > 0) {
         const int B = std::max(max_batch, m->cap_batch), NP = std::max(npad, m->cap_npad);
@@ -701,8 +755,41 @@ int rz_reserve(rz_handle_t m, int max_batch, int max_tokens, int max_prompts, in
     return 0;
 }
 
+static int vision_forward_once(rz_handle_t m, const float* px, int B, int C, int Himg, int Wimg, float* tokens_out, void* stream);
+
 int rz_vision_forward(rz_handle_t m, const float* px, int B, int C, int Himg, int Wimg, float* tokens_out, void* stream) {
     if (!m || !px) return fail(RZ_ERR_INVALID, "rz_vision_forward: null argument");
+    hipStream_t s = (hipStream_t)stream;
+    // fp32 mode on the f16 matrix pipe: the planes are f16, so an activation beyond +-65504 would turn into inf where fp32 stays finite.
+    // Every producer of planes raises a device word (rz_common.h flag_f16_range); it is read here once per forward — one stream
+    // synchronisation, in the mode whose step takes 200 ms — and a forward that raised it is repeated on the exact-fp32 MFMA kernels:
+    // fresh launches on the same stream, same buffers, nothing of the first pass survives.  Under stream capture no synchronisation is
+    // possible: a captured fp32 forward is not guarded (option "f32_split_guard" = 0 gives the same behaviour outside a capture).
+    if (m->dt == RZ_F32) {       // builds the split weight copies and the guard words on first use
+        const int rc0 = rz_weights_ready(m);
+        if (rc0) return rc0;
+    }
+    const bool split = m->dt == RZ_F32 && (m->o_gemm_f32_split() || m->o_attn_f32_split()) && m->ovf.p && m->ovf_host;
+    bool guard = split && m->o_guard();
+    if (guard) {
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(s, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) guard = false;
+    }
+    if (split) RZ_HIP(hipMemsetAsync(m->ovf.p, 0, 4, s));
+    int rc = vision_forward_once(m, px, B, C, Himg, Wimg, tokens_out, stream);
+    if (rc || !guard) return rc;
+    RZ_HIP(hipMemcpyAsync(m->ovf_host, m->ovf.p, 4, hipMemcpyDeviceToHost, s));
+    RZ_HIP(hipStreamSynchronize(s));
+    if (m->ovf_host[0]) {
+        m->force_exact = true;
+        rc = vision_forward_once(m, px, B, C, Himg, Wimg, tokens_out, stream);
+        m->force_exact = false;
+        m->guard_reruns += 1;
+    }
+    return rc;
+}
+
+static int vision_forward_once(rz_handle_t m, const float* px, int B, int C, int Himg, int Wimg, float* tokens_out, void* stream) {
     hipStream_t s = (hipStream_t)stream;
     if (C != m->cfg.num_channels)   // TF:dinov2/modeling_dinov2.py:143-147
         return fail(RZ_ERR_INVALID, "Make sure that the channel dimension of the pixel values match with the one set in the configuration.");
@@ -729,7 +816,7 @@ int rz_vision_forward(rz_handle_t m, const float* px, int B, int C, int Himg, in
         const float* pxc = px + (size_t)c0 * C * Himg * Wimg;
         // fp32 mode on the f16 matrix pipe: activations between the kernels travel as hi/lo f16 planes (6 bytes per element where they feed
         // a GEMM: [hi | lo | hi] along K; 4 where they feed the attention: hi plane, lo plane)
-        const bool sp = m->dt == RZ_F32 && g_gemm_f32_split && g_attn_f32_split && !m->split_w.empty();
+        const bool sp = m->dt == RZ_F32 && m->o_gemm_f32_split() && m->o_attn_f32_split() && !m->split_w.empty();
         const size_t ex = m->dt == RZ_F32 ? 6 : es;
         char* xn = (char*)m->xn.p + row0 * D * ex;
         char* qkb = (char*)m->qk.p + row0 * 2 * D * es;
@@ -739,7 +826,8 @@ int rz_vision_forward(rz_handle_t m, const float* px, int B, int C, int Himg, in
         // auto: ~126 MiB of hidden activations per pass (4 images of 5376 rows at 16 bits), whole images only
         const size_t hid_row_bytes = (size_t)F * es;
         const int mlp_auto = (int)std::max<size_t>(1, ((size_t)132 << 20) / (hid_row_bytes * np));
-        const int mlp_images = g_mlp_chunk > 0 ? g_mlp_chunk : (g_mlp_chunk == 0 ? Bc : std::min(Bc, mlp_auto));
+        const int mlp_chunk = m->o_mlp_chunk();
+        const int mlp_images = mlp_chunk > 0 ? mlp_chunk : (mlp_chunk == 0 ? Bc : std::min(Bc, mlp_auto));
 
         {   // patch embedding: im2col + GEMM with (pos | cls | bias) table epilogue
             ProfScope ps(m, RZ_PROF_ROWOPS, s);
@@ -750,7 +838,7 @@ int rz_vision_forward(rz_handle_t m, const float* px, int B, int C, int Himg, in
 
         const int nblocks = (int)m->blocks.size();
         // LayerNorm fused into the GEMMs either side of it (gemm8.hip): every block of this chunk or none
-        const bool fused = g_ln_fused && nblocks > 0 && gemm_ln_fused_ok(m->dt, M, D, F);
+        const bool fused = m->o_ln_fused() && nblocks > 0 && gemm_ln_fused_ok(m->dt, M, D, F, m->o_gemm_variant());
         float* part = fused ? (float*)m->lnpart.p + row0 * 24 : nullptr;
         float* stat = fused ? (float*)m->lnstat.p + row0 * 2 : nullptr;
         float* lnmu = fused ? (float*)m->lnmu.p + row0 : nullptr;
@@ -773,7 +861,7 @@ int rz_vision_forward(rz_handle_t m, const float* px, int B, int C, int Himg, in
             if (sp) {
                 {
                     ProfScope ps(m, RZ_PROF_ROWOPS, s);
-                    RZ_HIP(launch_layernorm_split3(h, (const float*)b.ln1_g.p, (const float*)b.ln1_b.p, eps, xn, M, D, s));
+                    RZ_HIP(launch_layernorm_split3(h, (const float*)b.ln1_g.p, (const float*)b.ln1_b.p, eps, xn, M, D, (unsigned*)m->ovf.p, s));
                 }
                 // q | k -> hi / lo planes of [Bc][2H][np][64]; V^T -> hi / lo planes of [Bc][H][64][np]
                 const char* wv = (const char*)b.wqkv.p + (size_t)2 * D * D * 4;
@@ -790,7 +878,7 @@ int rz_vision_forward(rz_handle_t m, const float* px, int B, int C, int Himg, in
                 if ((rc = gemm_qkv(m, xn, b, M, np, qkb, vtb, s))) return rc;
             } else {
                 GemmArgs probe;
-                probe.A = xn; probe.lda = D; probe.W = b.wqkv.p; probe.ldw = D; probe.M = M; probe.N = 3 * D; probe.K = D; probe.out2 = vtb; probe.split_n = 2 * D;
+                probe.A = xn; probe.lda = D; probe.W = b.wqkv.p; probe.ldw = D; probe.M = M; probe.N = 3 * D; probe.K = D; probe.out2 = vtb; probe.split_n = 2 * D; probe.variant = m->o_gemm_variant();
                 if (gemm_qkv_fused_ok(m->dt, probe)) {
                     if ((rc = gemm_ln(m, EPI_QKV_LN, xn, b.wqkv, b.c1qkv, b.c2qkv, stat, M, 3 * D, np, qkb, 0, 2 * H, vtb, H, 2 * D, s))) return rc;
                 } else {        // small batches: the same projection as q|k and v launches of the 128x128 kernel
@@ -809,18 +897,18 @@ int rz_vision_forward(rz_handle_t m, const float* px, int B, int C, int Himg, in
                 const char* kb = qb + (size_t)H * np * 64 * es;
                 if (sp)                                         // planes in (f16: k heads start H*np*64 ELEMENTS behind q), [hi | lo | hi] ctx out
                     RZ_HIP(launch_flash_attn_split_planes(qb, qb + (size_t)H * np * 64 * 2, vtb, ctxb, (int64_t)2 * H * np * 64, (int64_t)M * 2 * D, (int64_t)M * D,
-                                                          Bc, H, nv, np, s));
-                else if (m->dt == RZ_F32 && g_attn_f32_split)      // hi/lo f16 planes of q, k, V^T live in `mid` (free between the QKV and fc1 GEMMs: 3/4 of it)
+                                                          Bc, H, nv, np, (unsigned*)m->ovf.p, s));
+                else if (m->dt == RZ_F32 && m->o_attn_f32_split())      // hi/lo f16 planes of q, k, V^T live in `mid` (free between the QKV and fc1 GEMMs: 3/4 of it)
                     RZ_HIP(launch_flash_attn_f32_split((const float*)qb, (const float*)kb, (const float*)vtb, (float*)ctxb, mid, (int64_t)2 * H * np * 64,
-                                                       Bc, H, nv, np, s));
+                                                       Bc, H, nv, np, (unsigned*)m->ovf.p, s));
                 else
-                    RZ_HIP(flash_attn(m->dt, qb, kb, vtb, ctxb, (int64_t)2 * H * np * 64, Bc, H, nv, np, s));
+                    RZ_HIP(flash_attn(m->o_attn_variant(), m->dt, qb, kb, vtb, ctxb, (int64_t)2 * H * np * 64, Bc, H, nv, np, s));
             }
             if (sp) {
                 if ((rc = gemm(m, EPI_RESID_SCALE, ctxb, D, b.wo.p, D, M, D, D, (const float*)b.bo.p, nullptr, 0, (const float*)b.ls1.p, h, D, np, 0, s, A_SPLIT))) return rc;
                 {
                     ProfScope ps(m, RZ_PROF_ROWOPS, s);
-                    RZ_HIP(launch_layernorm_split3(h, (const float*)b.ln2_g.p, (const float*)b.ln2_b.p, eps, xn, M, D, s));
+                    RZ_HIP(launch_layernorm_split3(h, (const float*)b.ln2_g.p, (const float*)b.ln2_b.p, eps, xn, M, D, (unsigned*)m->ovf.p, s));
                 }
             } else if (!fused) {
                 if ((rc = gemm(m, EPI_RESID_SCALE, ctxb, D, b.wo.p, D, M, D, D, (const float*)b.bo.p, nullptr, 0, (const float*)b.ls1.p, h, D, np, 0, s))) return rc;
@@ -864,7 +952,7 @@ int rz_vision_forward(rz_handle_t m, const float* px, int B, int C, int Himg, in
         }
         return 0;
     };
-    const int nstreams = (g_vision_streams == 2 && B >= 2) ? 2 : 1;
+    const int nstreams = (m->o_vision_streams() == 2 && B >= 2) ? 2 : 1;
     if (nstreams == 2) {
         if (!m->side_ready) {
             for (int i = 0; i < 2; ++i) {
@@ -884,7 +972,8 @@ int rz_vision_forward(rz_handle_t m, const float* px, int B, int C, int Himg, in
             RZ_HIP(hipStreamWaitEvent(s, m->side_done[i], 0));
         }
     } else {
-        const int chunk = (g_vision_chunk > 0 && g_vision_chunk < B) ? g_vision_chunk : B;
+        const int vchunk = m->o_vision_chunk();
+        const int chunk = (vchunk > 0 && vchunk < B) ? vchunk : B;
         for (int c0 = 0; c0 < B; c0 += chunk)
             if ((rc = run_chunk(c0, std::min(chunk, B - c0), s))) return rc;
     }
@@ -1019,7 +1108,7 @@ int rz_gemm(int dtype, int epilogue, const void* a, const void* w, const float* 
     memset(&g, 0, sizeof g);
     g.A = a; g.lda = K; g.W = w; g.ldw = K; g.M = M; g.N = N; g.K = K; g.bias = bias; g.out = out; g.ldo = N;
     g.rows_per_image = M;
-   
+    g.variant = g_opt.gemm_variant;
     RZ_HIP(launch_gemm(dtype, epilogue, g, (hipStream_t)stream));
     return 0;
 }
@@ -1037,6 +1126,7 @@ int rz_gemm_ex(int dtype, int epilogue, const void* a, int64_t lda, const void* 
     GemmArgs g;
     g.A = a; g.lda = lda; g.W = w; g.ldw = ldw; g.M = M; g.N = N; g.K = K; g.bias = bias; g.out = out; g.ldo = ldo;
     g.scale = scale; g.resid = resid; g.ldr = ldr; g.rows_per_image = rows_per_image > 0 ? rows_per_image : M; g.heads_total = heads_total;
+    g.variant = g_opt.gemm_variant;
     RZ_HIP(launch_gemm(dtype, epilogue, g, (hipStream_t)stream));
     return 0;
 }
@@ -1050,7 +1140,7 @@ int rz_gemm_qkv(int dtype, const void* x, const void* w, const float* bias, void
     GemmArgs g;
     g.A = x; g.lda = D; g.W = w; g.ldw = D; g.M = M; g.N = 3 * D; g.K = D; g.bias = bias; g.out = qk; g.ldo = 0;
     g.scale = nullptr; g.resid = nullptr; g.ldr = 0; g.rows_per_image = rows_per_image; g.heads_total = 2 * heads;
-    g.out2 = vt; g.heads_total2 = heads; g.split_n = 2 * D;
+    g.out2 = vt; g.heads_total2 = heads; g.split_n = 2 * D; g.variant = g_opt.gemm_variant;
     const bool fused = gemm_qkv_fused_ok(dtype, g);
     if (fused_out) *fused_out = fused ? 1 : 0;
     if (fused) {
@@ -1077,7 +1167,7 @@ int rz_flash_attention(int dtype, const void* q, const void* k, const void* vt, 
                        void* stream) {
     if (!q || !k || !vt || !ctx) return fail(RZ_ERR_INVALID, "rz_flash_attention: null argument");
     if (n_pad % 128 || n_valid <= 0 || n_valid > n_pad) return fail(RZ_ERR_INVALID, "rz_flash_attention: n_pad must be a multiple of 128 >= n_valid > 0");
-    RZ_HIP(flash_attn(dtype, q, k, vt, ctx, (int64_t)H * n_pad * 64, B, H, n_valid, n_pad, (hipStream_t)stream));
+    RZ_HIP(flash_attn(g_opt.attn_variant, dtype, q, k, vt, ctx, (int64_t)H * n_pad * 64, B, H, n_valid, n_pad, (hipStream_t)stream));
     return 0;
 }
 
@@ -1087,29 +1177,53 @@ int rz_flash_attention_f32_split(const float* q, const float* k, const float* vt
                                  void* stream) {
     if (!q || !k || !vt || !ctx || !ws) return fail(RZ_ERR_INVALID, "rz_flash_attention_f32_split: null argument");
     if (n_pad % 128 || n_valid <= 0 || n_valid > n_pad) return fail(RZ_ERR_INVALID, "rz_flash_attention_f32_split: n_pad must be a multiple of 128 >= n_valid > 0");
-    RZ_HIP(launch_flash_attn_f32_split(q, k, vt, ctx, ws, (int64_t)H * n_pad * 64, B, H, n_valid, n_pad, (hipStream_t)stream));
+    RZ_HIP(launch_flash_attn_f32_split(q, k, vt, ctx, ws, (int64_t)H * n_pad * 64, B, H, n_valid, n_pad, nullptr, (hipStream_t)stream));
     return 0;
 }
 
 int rz_debug_buffer(const char* what, void* dev_ptr) {
     if (!what) return fail(RZ_ERR_INVALID, "rz_debug_buffer: null name");
+#ifdef RZ_EXPERIMENTS
     if (!strcmp(what, "gemm_v8_stamps")) { gemm_v8_set_stamp_buffer(dev_ptr); return 0; }
-    return fail(RZ_ERR_INVALID, std::string("rz_debug_buffer: unknown buffer ") + what);
+#else
+    (void)dev_ptr;
+#endif
+    return fail(RZ_ERR_INVALID, std::string("rz_debug_buffer: unknown buffer ") + what + " (diagnostic buffers exist only in the -DRZ_EXPERIMENTS tools build)");
 }
 
 int rz_set_option(const char* name, int value) {
     if (!name) return fail(RZ_ERR_INVALID, "rz_set_option: null name");
-    if (!strcmp(name, "gemm_v1_only")) { gemm_force_v1(value != 0); return 0; }
-    if (!strcmp(name, "gemm_variant")) { gemm_set_variant(value); return 0; }
-    if (!strcmp(name, "gemm_skew")) { gemm_set_skew(value); return 0; }
-    if (!strcmp(name, "vision_chunk")) { g_vision_chunk = value; return 0; }
-    if (!strcmp(name, "vision_streams")) { g_vision_streams = value; return 0; }
-    if (!strcmp(name, "mlp_chunk")) { g_mlp_chunk = value; return 0; }
-    if (!strcmp(name, "attn_variant")) { g_attn_variant = value; return 0; }
-    if (!strcmp(name, "ln_fused")) { g_ln_fused = value; return 0; }
-    if (!strcmp(name, "attn_f32_split")) { g_attn_f32_split = value; return 0; }
-    if (!strcmp(name, "gemm_f32_split")) { g_gemm_f32_split = value; return 0; }
-    return fail(RZ_ERR_INVALID, std::string("rz_set_option: unknown option ") + name);
+    if (!strcmp(name, "gemm_v1_only")) { g_opt.gemm_variant = value ? 1 : 0; return 0; }
+    int* f = option_field(g_opt, name);
+    if (!f) return fail(RZ_ERR_INVALID, std::string("rz_set_option: unknown option ") + name);
+    *f = value;
+    return 0;
+}
+
+int rz_set_model_option(rz_handle_t m, const char* name, int value) {
+    if (!m || !name) return fail(RZ_ERR_INVALID, "rz_set_model_option: null argument");
+    int* f = option_field(m->opt, name);
+    if (!f) return fail(RZ_ERR_INVALID, std::string("rz_set_model_option: unknown option ") + name);
+    if (f == &m->opt.pad_rows) {
+        if (value != RZ_OPT_INHERIT && value != 0 && value != 128 && value != 256) return fail(RZ_ERR_INVALID, "rz_set_model_option: pad_rows is 0, 128 or 256");
+        RZ_HIP(hipDeviceSynchronize());
+        m->pos_tables.clear();           // tables and workspaces were sized by the old rule: the caller sets them again
+        m->cap_batch = m->cap_npad = 0;
+        m->last_batch = 0;
+    }
+    *f = value;
+    return 0;
+}
+
+int rz_get_model_option(rz_handle_t m, const char* name, int* value_out) {
+    if (!m || !name || !value_out) return fail(RZ_ERR_INVALID, "rz_get_model_option: null argument");
+    if (!strcmp(name, "f32_split_guard_reruns")) { *value_out = (int)std::min<int64_t>(m->guard_reruns, INT32_MAX); return 0; }
+    Options own = m->opt, proc = g_opt;
+    int* fo = option_field(own, name);
+    int* fp = option_field(proc, name);
+    if (!fo) return fail(RZ_ERR_INVALID, std::string("rz_get_model_option: unknown option ") + name);
+    *value_out = pick(*fo, *fp);
+    return 0;
 }
 
 int rz_profile_enable(rz_handle_t m, int enable) {

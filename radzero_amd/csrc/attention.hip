@@ -424,7 +424,7 @@ template <bool OUT_SPLIT>
 __global__ __launch_bounds__(256, 2) void flash_attn_split_kernel(const f16_t* __restrict__ q, const f16_t* __restrict__ k,
                                                                   const f16_t* __restrict__ vT, void* __restrict__ ctx_out,
                                                                   int64_t qk_batch_stride, int64_t qk_lo_off, int64_t v_lo_off,
-                                                                  int B, int H, int n_valid, int n_pad) {
+                                                                  int B, int H, int n_valid, int n_pad, unsigned* ovf_flag) {
     typedef f16x8 frag_t;
     constexpr int TILE = 64 * 128;                   // one plane of one 64-key tile
     constexpr int ES = 2;
@@ -662,7 +662,7 @@ __global__ __launch_bounds__(256, 2) void flash_attn_split_kernel(const f16_t* _
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt) {
                 f16x4 hi, lo;
-                split4(oacc[qt][dt] * inv, hi, lo);
+                split4(oacc[qt][dt] * inv, hi, lo, ovf_flag);
                 *reinterpret_cast<f16x4*>(o + dt * 16) = hi;
                 *reinterpret_cast<f16x4*>(o + D + dt * 16) = lo;
                 *reinterpret_cast<f16x4*>(o + 2 * D + dt * 16) = hi;
@@ -677,13 +677,13 @@ __global__ __launch_bounds__(256, 2) void flash_attn_split_kernel(const f16_t* _
 
 // x (fp32, B slabs of `per` contiguous elements `src_stride` apart) -> compact planes hi = f16(x), lo = f16(x - hi)   (per % 4 == 0)
 __global__ __launch_bounds__(256) void split_f16_kernel(const float* __restrict__ x, int64_t src_stride, f16_t* __restrict__ hi,
-                                                        f16_t* __restrict__ lo, int64_t per4) {
+                                                        f16_t* __restrict__ lo, int64_t per4, unsigned* ovf_flag) {
     const float* src = x + (int64_t)blockIdx.y * src_stride;
     const int64_t dst0 = (int64_t)blockIdx.y * per4 * 4;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < per4; i += (int64_t)gridDim.x * 256) {
         const f32x4 v = *reinterpret_cast<const f32x4*>(src + 4 * i);
-        const f16x4 h = pack4<f16_t>(v[0], v[1], v[2], v[3]);
-        const f16x4 l = pack4<f16_t>(v[0] - (float)h[0], v[1] - (float)h[1], v[2] - (float)h[2], v[3] - (float)h[3]);
+        f16x4 h, l;
+        split4(v, h, l, ovf_flag);
         *reinterpret_cast<f16x4*>(hi + dst0 + 4 * i) = h;
         *reinterpret_cast<f16x4*>(lo + dst0 + 4 * i) = l;
     }
@@ -694,31 +694,31 @@ size_t flash_attn_split_workspace_bytes(int B, int H, int n_pad) { return (size_
 // fp32 q, k ([B][H][n_pad][64] each, batch stride qk_batch_stride) and V^T ([B][H][64][n_pad]) -> fp32 ctx through the split kernel.
 // split_ws (flash_attn_split_workspace_bytes): planes q_hi q_lo k_hi k_lo v_hi v_lo, each B*H*n_pad*64 f16.
 hipError_t launch_flash_attn_f32_split(const float* q, const float* k, const float* vT, float* ctx, void* split_ws, int64_t qk_batch_stride,
-                                       int B, int H, int n_valid, int n_pad, hipStream_t s) {
+                                       int B, int H, int n_valid, int n_pad, unsigned* ovf_flag, hipStream_t s) {
     if (n_pad % FA_QROWS || n_valid <= 0 || n_valid > n_pad || B <= 0 || H <= 0 || !split_ws) return hipErrorInvalidValue;
     const int64_t per = (int64_t)H * n_pad * 64, n = (int64_t)B * per;
     f16_t* q_hi = reinterpret_cast<f16_t*>(split_ws);
     f16_t* k_hi = q_hi + 2 * n;
     f16_t* v_hi = q_hi + 4 * n;
     const dim3 sgrid(256, B);
-    hipLaunchKernelGGL(split_f16_kernel, sgrid, dim3(256), 0, s, q, qk_batch_stride, q_hi, q_hi + n, per / 4);
-    hipLaunchKernelGGL(split_f16_kernel, sgrid, dim3(256), 0, s, k, qk_batch_stride, k_hi, k_hi + n, per / 4);
-    hipLaunchKernelGGL(split_f16_kernel, sgrid, dim3(256), 0, s, vT, per, v_hi, v_hi + n, per / 4);
+    hipLaunchKernelGGL(split_f16_kernel, sgrid, dim3(256), 0, s, q, qk_batch_stride, q_hi, q_hi + n, per / 4, ovf_flag);
+    hipLaunchKernelGGL(split_f16_kernel, sgrid, dim3(256), 0, s, k, qk_batch_stride, k_hi, k_hi + n, per / 4, ovf_flag);
+    hipLaunchKernelGGL(split_f16_kernel, sgrid, dim3(256), 0, s, vT, per, v_hi, v_hi + n, per / 4, ovf_flag);
     const int nq = n_pad / FA_QROWS;
     dim3 grid(((B * H * nq + 7) / 8) * 8), block(256);
-    hipLaunchKernelGGL(flash_attn_split_kernel<false>, grid, block, 0, s, q_hi, k_hi, v_hi, (void*)ctx, per, n, n, B, H, n_valid, n_pad);
+    hipLaunchKernelGGL(flash_attn_split_kernel<false>, grid, block, 0, s, q_hi, k_hi, v_hi, (void*)ctx, per, n, n, B, H, n_valid, n_pad, ovf_flag);
     return hipGetLastError();
 }
 
 // The same kernel on operands that are ALREADY hi/lo planes (written by the split q|k / V^T epilogues, gemm_common.h): q_hi, k_hi
 // with batch stride qk_batch_stride, lo planes qk_lo_off / v_lo_off elements behind the hi planes; ctx3 = [rows][3 * H * 64] f16.
 hipError_t launch_flash_attn_split_planes(const void* q_hi, const void* k_hi, const void* v_hi, void* ctx3, int64_t qk_batch_stride,
-                                          int64_t qk_lo_off, int64_t v_lo_off, int B, int H, int n_valid, int n_pad, hipStream_t s) {
+                                          int64_t qk_lo_off, int64_t v_lo_off, int B, int H, int n_valid, int n_pad, unsigned* ovf_flag, hipStream_t s) {
     if (n_pad % FA_QROWS || n_valid <= 0 || n_valid > n_pad || B <= 0 || H <= 0) return hipErrorInvalidValue;
     const int nq = n_pad / FA_QROWS;
     dim3 grid(((B * H * nq + 7) / 8) * 8), block(256);
     hipLaunchKernelGGL(flash_attn_split_kernel<true>, grid, block, 0, s, (const f16_t*)q_hi, (const f16_t*)k_hi, (const f16_t*)v_hi, ctx3,
-                       qk_batch_stride, qk_lo_off, v_lo_off, B, H, n_valid, n_pad);
+                       qk_batch_stride, qk_lo_off, v_lo_off, B, H, n_valid, n_pad, ovf_flag);
     return hipGetLastError();
 }
 

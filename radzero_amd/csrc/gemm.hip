@@ -202,11 +202,8 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel_v3(GemmArgs g) {
     }
 }
 
-static int g_skew = 0;
-void gemm_set_skew(int t) { g_skew = t; }
-static int g_variant = 0;      // 0 = auto, 1/2/3 = force that kernel where its shape constraints hold
-void gemm_force_v1(bool on) { g_variant = on ? 1 : 0; }
-void gemm_set_variant(int v) { g_variant = v; }
+// Kernel choice: GemmArgs::variant (0 = auto; a forced kernel is used where its shape constraints hold).  No process-wide state
+// lives here: the caller (api.hip) resolves the handle's / the process-wide option into every launch.
 
 // big tiles pay off once their rounds over the 256 CUs are >= 55 % full (measured, bench.py --batch 1..7:
 // 126 tiles -> 128x128 kernel 6 % faster; 189 tiles -> 256x256 kernel 7 % faster; 315 tiles -> 1 % faster)
@@ -219,19 +216,19 @@ static bool big_tiles_pay(const GemmArgs& g) {
 // The merged q|k|v projection (EPI_QKV) exists only in the persistent kernel: callers ask first and fall back to the
 // separate EPI_HEADS + EPI_VT launches (fp32 mode, small batches, forced variants).
 bool gemm_qkv_fused_ok(int dtype, const GemmArgs& g) {
-    return (g_variant == 0 || g_variant == 8) && gemm_v8_ok(dtype, EPI_QKV, g) && (g_variant == 8 || big_tiles_pay(g));
+    return (g.variant == 0 || g.variant == 8) && gemm_v8_ok(dtype, EPI_QKV, g) && (g.variant == 8 || big_tiles_pay(g));
 }
 
 // May a Dinov2 block run with its LayerNorms fused into the GEMMs (EPI_*_LN)?  Every 16-bit shape does: the persistent kernel
 // takes the large ones, the 128x128 kernel the rest, with bit-identical arithmetic (gemm_common.h::gemm_epilogue_ln).
-bool gemm_ln_fused_ok(int dtype, int M, int D, int F) {
-    return dtype != DT_F32 && (g_variant == 0 || g_variant == 1 || g_variant == 8) && M > 0 && M % BM == 0 && D == 768 && F % BN == 0;
+bool gemm_ln_fused_ok(int dtype, int M, int D, int F, int variant) {
+    return dtype != DT_F32 && (variant == 0 || variant == 1 || variant == 8) && M > 0 && M % BM == 0 && D == 768 && F % BN == 0;
 }
 
 template <typename T>
 static hipError_t launch_gemm_t(int epi, const GemmArgs& g, hipStream_t s) {
     const bool ok3 = (g.M % BM2 == 0) && (g.M >= 4 * BM2) && (g.N % BN3 == 0);
-    int variant = g_variant;
+    int variant = g.variant;
     // measured on MI355X (tools/kbench.py, ms per layer of 8 images): v1 0.975, v3 0.825-0.867, v7 0.745-0.755; with fewer
     // than ~200 big tiles (single-image calls) the 128x128 kernel fills the 256 CUs better.
     // v7 (gemm7.hip, 16-bit only): K loop 1.40 us per 256x256x64 step against 1.68 for v3 (tools/kslope.py);
@@ -247,6 +244,9 @@ static hipError_t launch_gemm_t(int epi, const GemmArgs& g, hipStream_t s) {
         if (gemm_v8_ok(Traits<T>::kDType, epi, g)) return launch_gemm_v8(Traits<T>::kDType, epi, g, s);
         variant = epi > EPI_QKV ? 1 : 7;
     }
+#ifndef RZ_EXPERIMENTS
+    if (variant == 9) variant = 7;      // the stamped build exists only in the tools library
+#endif
     if (variant == 7 || variant == 9) {
         if (gemm_v7_ok(Traits<T>::kDType, g)) return launch_gemm_v7(variant, Traits<T>::kDType, epi, g, s);
         variant = ok3 ? 3 : 1;
@@ -289,7 +289,7 @@ hipError_t launch_gemm_split_f32out(int epi, const GemmArgs& g, hipStream_t s, b
     if (epi == EPI_RESID_SCALE || epi == EPI_RESID_ADD || epi == EPI_PATCH || epi == EPI_STORE_F32) return launch_gemm(DT_F16, epi, g, s);
     if (g.M <= 0 || g.N <= 0 || g.K <= 0 || g.M % BM || g.N % BN || (g.K * 2) % 128 || (g.lda * 2) % 16 || (g.ldw * 2) % 16) return hipErrorInvalidValue;
     const bool v3 = big_tiles_pay(g);
-    if (v3 && (g_variant == 0 || g_variant == 7) && gemm_v7_ok(DT_F16, g)) return launch_gemm_v7_f16_out(epi, g, split_out, s);   // the deeper-pipelined K loop
+    if (v3 && (g.variant == 0 || g.variant == 7) && gemm_v7_ok(DT_F16, g)) return launch_gemm_v7_f16_out(epi, g, split_out, s);   // the deeper-pipelined K loop
     const int ntiles = v3 ? (g.M / BM2) * (g.N / BN3) : (g.M / BM) * (g.N / BN);
     dim3 grid(ntiles), block(v3 ? 512 : 256);
 #define RZ_CASE(E, OT) \
@@ -317,15 +317,15 @@ hipError_t launch_gemm_split_f32out(int epi, const GemmArgs& g, hipStream_t s, b
 
 // src fp32 [rows][K] (row stride ld) -> dst f16 [rows][3K]: [hi | lo | hi] (activations) or, w_layout, [hi | hi | lo] (weights)
 __global__ __launch_bounds__(256) void split3_rows_kernel(const float* __restrict__ src, int64_t ld, f16_t* __restrict__ dst, int64_t rows,
-                                                          int K, int w_layout) {
+                                                          int K, int w_layout, unsigned* ovf_flag) {
     const int k4 = K / 4;
     const int64_t total = rows * k4;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
         const int64_t r = i / k4;
         const int c = (int)(i - r * k4) * 4;
         const f32x4 v = *reinterpret_cast<const f32x4*>(src + r * ld + c);
-        const f16x4 h = pack4<f16_t>(v[0], v[1], v[2], v[3]);
-        const f16x4 l = pack4<f16_t>(v[0] - (float)h[0], v[1] - (float)h[1], v[2] - (float)h[2], v[3] - (float)h[3]);
+        f16x4 h, l;
+        split4(v, h, l, ovf_flag);
         f16_t* o = dst + r * 3 * K + c;
         *reinterpret_cast<f16x4*>(o) = h;
         *reinterpret_cast<f16x4*>(o + K) = w_layout ? h : l;
@@ -333,17 +333,16 @@ __global__ __launch_bounds__(256) void split3_rows_kernel(const float* __restric
     }
 }
 
-hipError_t launch_split3(const float* src, int64_t ld, void* dst, int64_t rows, int K, int w_layout, hipStream_t s) {
+hipError_t launch_split3(const float* src, int64_t ld, void* dst, int64_t rows, int K, int w_layout, unsigned* ovf_flag, hipStream_t s) {
     if (rows <= 0 || K <= 0 || K % 4 || ld % 4) return hipErrorInvalidValue;
     const int64_t total = rows * (K / 4);
     const int blocks = (int)std::min<int64_t>((total + 255) / 256, 8192);
-    hipLaunchKernelGGL(split3_rows_kernel, dim3(blocks), dim3(256), 0, s, src, ld, (f16_t*)dst, rows, K, w_layout);
+    hipLaunchKernelGGL(split3_rows_kernel, dim3(blocks), dim3(256), 0, s, src, ld, (f16_t*)dst, rows, K, w_layout, ovf_flag);
     return hipGetLastError();
 }
 
 hipError_t launch_gemm(int dtype, int epi, const GemmArgs& g_in, hipStream_t s) {
-    GemmArgs g = g_in;
-    if (g_skew) g.skew_ticks = g_skew;
+    const GemmArgs& g = g_in;
     if (g.M <= 0 || g.N <= 0 || g.K <= 0) return hipErrorInvalidValue;
     if (g.M % BM || g.N % BN) return hipErrorInvalidValue;
     const int esz = dtype == DT_F32 ? 4 : 2;

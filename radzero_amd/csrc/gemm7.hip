@@ -245,8 +245,12 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel_v7(GemmArgs g) {
 template <typename T>
 static hipError_t launch_v7_t(int variant, int epi, const GemmArgs& g, hipStream_t s) {
     dim3 grid((g.M / V7_BM) * (g.N / V7_BN)), block(512);
+#ifdef RZ_EXPERIMENTS      // variant 9: the in-kernel s_memtime stamps of tools/kstamp.py (tools build only)
 #define RZ_CASE7(E) case E: if (variant == 9) { if constexpr (E == EPI_STORE) hipLaunchKernelGGL((gemm_kernel_v7<T, E, 2>), grid, block, 0, s, g); } \
                          else hipLaunchKernelGGL((gemm_kernel_v7<T, E, 0>), grid, block, 0, s, g); break;
+#else
+#define RZ_CASE7(E) case E: hipLaunchKernelGGL((gemm_kernel_v7<T, E, 0>), grid, block, 0, s, g); break;
+#endif
     switch (epi) {
         RZ_CASE7(EPI_STORE)
         RZ_CASE7(EPI_GELU)

@@ -348,7 +348,7 @@ __device__ __forceinline__ void v8_epilogue(const GemmArgs& g, const f32x4 (&acc
     }
 }
 
-// STAMP: diagnostic build (tools/kstamp8.py; never launched by the model): every wave sums the 100 MHz real-time ticks it
+// STAMP: diagnostic build (tools/kstamp8.py, compiled only with -DRZ_EXPERIMENTS; never launched by the model): every wave sums the 100 MHz real-time ticks it
 // spends in K loops and in epilogues and stores them, with the absolute time of its first 24 epilogue starts, into the
 // buffer passed as g.out2 — memory no other code of the kernel reads.
 template <typename T, int EPI, bool STAMP = false>
@@ -406,15 +406,6 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel_v8(GemmArgs g) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) acc[a][i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    // Start-up stagger: the workgroups of an XCD start in four groups, a quarter of `skew_ticks` apart, so that the
-    // HBM-bound epilogues of one group run beside the K loops of the others instead of all 256 CUs alternating in step
-    // between "matrix pipe busy, HBM idle" and "HBM saturated, matrix pipe idle".  The relative phase persists because
-    // every tile costs the same.  s_memrealtime ticks at 100 MHz whatever the shader clock does.
-    if (g.skew_ticks > 0) {
-        const unsigned long long wait = (unsigned long long)((slot & 3) * (g.skew_ticks >> 2));
-        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-        while (__builtin_amdgcn_s_memrealtime() - t0 < wait) __builtin_amdgcn_s_sleep(32);
-    }
     int idx = slot, m0, n0;
     tile_origin(idx, m0, n0);
     const char* Ab = reinterpret_cast<const char*>(g.A) + (int64_t)m0 * lda_b;
@@ -542,13 +533,16 @@ static int v8_grid() {
     return grid;
 }
 
+#ifdef RZ_EXPERIMENTS
 static void* g_stamp_buf = nullptr;
 void gemm_v8_set_stamp_buffer(void* p) { g_stamp_buf = p; }
+#endif
 
 template <typename T>
 static hipError_t launch_v8_t(int epi, const GemmArgs& g_in, hipStream_t s) {
     dim3 grid(v8_grid()), block(512);
     GemmArgs g = g_in;
+#ifdef RZ_EXPERIMENTS
     if (g_stamp_buf && (epi == EPI_HEADS || epi == EPI_GELU || epi == EPI_RESID_SCALE)) {     // diagnostic build, see STAMP above
         g.out2 = g_stamp_buf;
         if (epi == EPI_HEADS) hipLaunchKernelGGL((gemm_kernel_v8<T, EPI_HEADS, true>), grid, block, 0, s, g);
@@ -556,6 +550,7 @@ static hipError_t launch_v8_t(int epi, const GemmArgs& g_in, hipStream_t s) {
         else hipLaunchKernelGGL((gemm_kernel_v8<T, EPI_RESID_SCALE, true>), grid, block, 0, s, g);
         return hipGetLastError();
     }
+#endif
 #define RZ_CASE8(E) case E: hipLaunchKernelGGL((gemm_kernel_v8<T, E>), grid, block, 0, s, g); break;
     switch (epi) {
         RZ_CASE8(EPI_STORE)

@@ -206,14 +206,14 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, const f32x4 (&a
                     // (exact-erf GELU as in every fp32 epilogue); EPI_HEADS -> two planes `plane_off` elements apart
                     f16x4 hi, lo;
                     if constexpr (EPI == EPI_GELU) {
-                        split4((f32x4){gelu_erf(v[0]), gelu_erf(v[1]), gelu_erf(v[2]), gelu_erf(v[3])}, hi, lo);
+                        split4((f32x4){gelu_erf(v[0]), gelu_erf(v[1]), gelu_erf(v[2]), gelu_erf(v[3])}, hi, lo, g.ovf_flag);
                         f16_t* o = reinterpret_cast<f16_t*>(g.out) + (int64_t)m * 3 * g.ldo + n;
                         *reinterpret_cast<f16x4*>(o) = hi;
                         *reinterpret_cast<f16x4*>(o + g.ldo) = lo;
                         *reinterpret_cast<f16x4*>(o + 2 * g.ldo) = hi;
                     } else {
                         static_assert(EPI == EPI_HEADS, "split outputs: EPI_GELU, EPI_HEADS, EPI_VT");
-                        split4(v, hi, lo);
+                        split4(v, hi, lo, g.ovf_flag);
                         const int b = m / g.rows_per_image, tok = m - b * g.rows_per_image;
                         f16_t* o = reinterpret_cast<f16_t*>(g.out) +
                                    (((int64_t)b * g.heads_total + (n >> 6)) * g.rows_per_image + tok) * 64 + (n & 63);
@@ -262,7 +262,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, const f32x4 (&a
                 const int64_t idx = (((int64_t)b * g.heads_total + (n >> 6)) * 64 + (n & 63)) * g.rows_per_image + tok;
                 if constexpr (std::is_same<T, split_f16>::value) {
                     f16x4 hi, lo;
-                    split4((f32x4){a[0] + bv, a[1] + bv, a[2] + bv, a[3] + bv}, hi, lo);
+                    split4((f32x4){a[0] + bv, a[1] + bv, a[2] + bv, a[3] + bv}, hi, lo, g.ovf_flag);
                     f16_t* o = reinterpret_cast<f16_t*>(g.out) + idx;
                     *reinterpret_cast<f16x4*>(o) = hi;
                     *reinterpret_cast<f16x4*>(o + g.plane_off) = lo;

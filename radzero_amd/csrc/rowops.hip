@@ -63,7 +63,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
 // fp32 mode, hi/lo-split path: the LayerNorm output leaves as the next GEMM's A operand [rows][3D] f16 = [hi | lo | hi] (rz_common.h split4)
 template <int NV>
 __global__ __launch_bounds__(256) void layernorm_split3_kernel(const float* __restrict__ in, const float* __restrict__ gamma,
-                                                               const float* __restrict__ beta, float eps, f16_t* __restrict__ out3, int64_t rows) {
+                                                               const float* __restrict__ beta, float eps, f16_t* __restrict__ out3, int64_t rows, unsigned* ovf_flag) {
     constexpr int D = 256 * NV;
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -73,7 +73,7 @@ __global__ __launch_bounds__(256) void layernorm_split3_kernel(const float* __re
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
         f16x4 hi, lo;
-        split4(r.v[i], hi, lo);
+        split4(r.v[i], hi, lo, ovf_flag);
         f16_t* o = out3 + row * 3 * D + (lane + 64 * i) * 4;
         *reinterpret_cast<f16x4*>(o) = hi;
         *reinterpret_cast<f16x4*>(o + D) = lo;
@@ -81,9 +81,9 @@ __global__ __launch_bounds__(256) void layernorm_split3_kernel(const float* __re
     }
 }
 
-hipError_t launch_layernorm_split3(const float* in, const float* gamma, const float* beta, float eps, void* out3, int64_t rows, int D, hipStream_t s) {
+hipError_t launch_layernorm_split3(const float* in, const float* gamma, const float* beta, float eps, void* out3, int64_t rows, int D, unsigned* ovf_flag, hipStream_t s) {
     if (D != 768 || rows <= 0) return hipErrorInvalidValue;
-    hipLaunchKernelGGL((layernorm_split3_kernel<3>), dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, in, gamma, beta, eps, (f16_t*)out3, rows);
+    hipLaunchKernelGGL((layernorm_split3_kernel<3>), dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, in, gamma, beta, eps, (f16_t*)out3, rows, ovf_flag);
     return hipGetLastError();
 }
 

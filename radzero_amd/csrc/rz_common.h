@@ -80,7 +80,17 @@ template <typename T> __device__ __forceinline__ typename Traits<T>::vec4 pack4(
 
 // Output "type" of the fp32 mode's hi/lo-split path: a value x leaves an epilogue as f16 planes hi = f16(x), lo = f16(x - hi).
 struct split_f16 {};
-__device__ __forceinline__ void split4(const f32x4& v, f16x4& hi, f16x4& lo) {
+// Overflow guard of that path: the planes are f16, so a value beyond +-65504 (or a NaN) would become inf where fp32 stays finite.  Every
+// producer of planes ORs 1 into `*flag` when it meets one (integer compare on the magnitude bits: also true for NaN, and immune to
+// -fno-honor-nans); api.hip reads the word once per forward and repeats that forward on the exact-fp32 kernels.  Values below 6e-5 lose
+// (part of) their lo plane to f16's subnormal range: an ABSOLUTE error <= 2^-25 per element, far inside the 1e-3 parity bar.
+__device__ __forceinline__ void flag_f16_range(const f32x4& v, unsigned* flag) {
+    const unsigned a = max(max(__float_as_uint(v[0]) & 0x7fffffffu, __float_as_uint(v[1]) & 0x7fffffffu),
+                           max(__float_as_uint(v[2]) & 0x7fffffffu, __float_as_uint(v[3]) & 0x7fffffffu));
+    if (a > 0x477fe000u && flag) atomicOr(flag, 1u);          // 0x477fe000 = 65504.0f
+}
+__device__ __forceinline__ void split4(const f32x4& v, f16x4& hi, f16x4& lo, unsigned* flag = nullptr) {
+    flag_f16_range(v, flag);
     hi = pack4<f16_t>(v[0], v[1], v[2], v[3]);
     lo = pack4<f16_t>(v[0] - (float)hi[0], v[1] - (float)hi[1], v[2] - (float)hi[2], v[3] - (float)hi[3]);
 }

@@ -42,21 +42,21 @@ struct GemmArgs {
     const float* ln_gamma = nullptr; // EPI_RESID_SCALE_LN: gain of the LayerNorm that will consume ln_hb
     const float* ln_mu = nullptr;    // EPI_RESID_SCALE_LN: [M] centring constant of each row (its mean before this update): ln_hb = T((x - ln_mu[m]) * ln_gamma[n])
     int64_t plane_off = 0;        // hi/lo-split outputs (fp32 mode, EPI_HEADS / EPI_VT): elements from the hi plane to the lo plane
-    int skew_ticks = 0;           // persistent kernel: start-up stagger period in 10 ns ticks (0 = none), see gemm8.hip
+    unsigned* ovf_flag = nullptr; // hi/lo-split outputs: word that receives 1 when a value leaves the f16 range (rz_common.h flag_f16_range)
+    int variant = 0;              // kernel choice: 0 auto | 1 128x128 two-stage | 3 256x256 two-stage | 7 staggered 8-phase (gemm7.hip) | 8 persistent (gemm8.hip)
 };
 
 hipError_t launch_gemm(int dtype, int epi, const GemmArgs& g, hipStream_t s);
-void gemm_force_v1(bool on);   // A/B switch: use only the 128x128 two-stage kernel
-void gemm_v8_set_stamp_buffer(void* dev_u64);   // diagnostic: non-null => the stamped build of the persistent kernel writes 256 x 8 x 32 u64 there
-void gemm_set_skew(int ticks);  // experiment: start-up stagger of the persistent kernel (gemm8.hip), 10 ns ticks per full period
-void gemm_set_variant(int v);  // 0 auto, 1 = 128x128 two-stage, 3 = 256x256 two-stage, 7 = 256x256 staggered 8-phase (gemm7.hip), 8 = persistent (gemm8.hip), 9 = 7 + in-kernel stamps
+#ifdef RZ_EXPERIMENTS
+void gemm_v8_set_stamp_buffer(void* dev_u64);   // diagnostic build: non-null => the stamped persistent kernel writes 256 x 8 x 32 u64 there
+#endif
 bool gemm_v7_ok(int dtype, const GemmArgs& g);
 bool gemm_v8_ok(int dtype, int epi, const GemmArgs& g);
 bool gemm_qkv_fused_ok(int dtype, const GemmArgs& g);
-bool gemm_ln_fused_ok(int dtype, int M, int D, int F);   // may a Dinov2 block of M token rows use the fused-LayerNorm epilogues   // may EPI_QKV be launched for this shape (else: EPI_HEADS + EPI_VT)
+bool gemm_ln_fused_ok(int dtype, int M, int D, int F, int variant);   // may a Dinov2 block of M token rows use the fused-LayerNorm epilogues
 // fp32 mode on the f16 matrix pipe: operands split into f16 planes along K (gemm.hip)
 hipError_t launch_gemm_split_f32out(int epi, const GemmArgs& g, hipStream_t s, bool split_out = false);
-hipError_t launch_split3(const float* src, int64_t ld, void* dst, int64_t rows, int K, int w_layout, hipStream_t s);
+hipError_t launch_split3(const float* src, int64_t ld, void* dst, int64_t rows, int K, int w_layout, unsigned* ovf_flag, hipStream_t s);
 hipError_t launch_gemm_v8(int dtype, int epi, const GemmArgs& g, hipStream_t s);   // persistent 256x256 kernel (gemm8.hip)
 hipError_t launch_gemm_v7(int variant, int dtype, int epi, const GemmArgs& g, hipStream_t s);
 hipError_t launch_gemm_v7_f16_out(int epi, const GemmArgs& g, bool split_out, hipStream_t s);   // f16 operands, fp32 / hi-lo-split outputs
@@ -66,9 +66,9 @@ hipError_t launch_gemm_v7_f16_out(int epi, const GemmArgs& g, bool split_out, hi
 // q/k of image b start at q + b*qk_batch_stride (elements), heads contiguous ([H][Npad][64]).
 size_t flash_attn_split_workspace_bytes(int B, int H, int n_pad);
 hipError_t launch_flash_attn_f32_split(const float* q, const float* k, const float* vT, float* ctx, void* split_ws, int64_t qk_batch_stride,
-                                       int B, int H, int n_valid, int n_pad, hipStream_t s);
+                                       int B, int H, int n_valid, int n_pad, unsigned* ovf_flag, hipStream_t s);
 hipError_t launch_flash_attn_split_planes(const void* q_hi, const void* k_hi, const void* v_hi, void* ctx3, int64_t qk_batch_stride,
-                                          int64_t qk_lo_off, int64_t v_lo_off, int B, int H, int n_valid, int n_pad, hipStream_t s);
+                                          int64_t qk_lo_off, int64_t v_lo_off, int B, int H, int n_valid, int n_pad, unsigned* ovf_flag, hipStream_t s);
 hipError_t launch_flash_attn(int dtype, const void* q, const void* k, const void* vT, void* ctx,
                              int64_t qk_batch_stride, int B, int H, int n_valid, int n_pad, int waves, hipStream_t s);
 
@@ -89,7 +89,7 @@ hipError_t launch_ln_prepare(int dtype, const float* in, const float* gamma, con
 
 // LayerNorm over rows of 768: fp32 in; writes T-typed normalized copy (out_t, may be null) and/or
 // fp32 (out_f32, may alias in).
-hipError_t launch_layernorm_split3(const float* in, const float* gamma, const float* beta, float eps, void* out3, int64_t rows, int D, hipStream_t s);
+hipError_t launch_layernorm_split3(const float* in, const float* gamma, const float* beta, float eps, void* out3, int64_t rows, int D, unsigned* ovf_flag, hipStream_t s);
 hipError_t launch_layernorm(int dtype, const float* in, const float* gamma, const float* beta, float eps,
                             void* out_t, float* out_f32, int64_t rows, int D, hipStream_t s);
 

@@ -76,6 +76,31 @@ def relative_position_bias(rel_weight: torch.Tensor, seq_len: int, max_distance:
     return w[bucket].permute(2, 0, 1).contiguous()   # (H, L, L)
 
 
+def _resolve_device(spec) -> torch.device:
+    """device / device_map argument -> one indexed cuda device (see RadZeroModel.from_pretrained).  Pure host logic: no GPU call."""
+    if spec is None:
+        return torch.device("cuda", _current_cuda_index())
+    if isinstance(spec, dict):
+        targets = {str(_resolve_device(v)) for v in spec.values()}
+        if len(targets) != 1:
+            raise NotImplementedError(f"device_map places modules on different devices ({sorted(targets)}): one handle runs on one GPU")
+        return torch.device(targets.pop())
+    if isinstance(spec, int):
+        if spec < 0:
+            raise ValueError("device index must be >= 0")
+        return torch.device("cuda", spec)
+    if isinstance(spec, str) and spec in ("auto", "balanced", "balanced_low_0", "sequential"):
+        return torch.device("cuda", _current_cuda_index())
+    d = torch.device(spec)
+    if d.type != "cuda":
+        raise RuntimeError(f"RadZeroModel runs on an AMD GPU through libradzero_hip.so; device {spec!r} has no path here")
+    return d if d.index is not None else torch.device("cuda", _current_cuda_index())
+
+
+def _current_cuda_index() -> int:
+    return torch.cuda.current_device() if torch.cuda.is_available() else 0
+
+
 class RadZeroModel:
     """Drop-in for `CxrAlignModel` on the inference path (compute_logits_type == "radzero")."""
 
@@ -85,9 +110,9 @@ class RadZeroModel:
         if self.config.sim_op != "cos":
             raise NotImplementedError("only sim_op == 'cos' (released RadZero config) is implemented")
         self.dtype = torch_dtype
-        self._device = torch.device(device)
-        if self._device.type != "cuda":
+        if torch.device(device).type != "cuda":
             raise RuntimeError("RadZeroModel runs on an AMD GPU through libradzero_hip.so; there is no CPU path")
+        self._device = _resolve_device(device)          # torch.device("cuda") -> the current GPU, with its index
         if not torch.cuda.is_available():
             raise RuntimeError("no HIP device visible: radzero_amd has no CPU / PyTorch fallback")
         self._lib = _lib.load()
@@ -137,17 +162,25 @@ class RadZeroModel:
         return m
 
     @classmethod
-    def from_pretrained(cls, path: str, torch_dtype=torch.bfloat16, device="cuda:0", config: Optional[RadZeroConfig] = None,
-                        **_ignored) -> "RadZeroModel":
+    def from_pretrained(cls, path: str, torch_dtype=torch.bfloat16, device=None, config: Optional[RadZeroConfig] = None,
+                        device_map=None, trust_remote_code: bool = True, **_ignored) -> "RadZeroModel":
         """`AutoModel.from_pretrained("Deepnoid/RadZero", trust_remote_code=True, torch_dtype=..., device_map=...)`
-        analogue (README.md:77-82) for a LOCAL checkpoint directory / file (there is no network here)."""
+        analogue (README.md:77-82) for a LOCAL checkpoint directory / file (there is no network here).
+
+        `device_map` is honoured the way the README uses it — one device for the whole model: a device string / torch.device /
+        GPU index, "auto" / "cuda" / "balanced" / "sequential" (= the current GPU: the model is 0.8 GB, there is nothing to spread),
+        or a {"": device} dict.  A map that places modules on DIFFERENT devices, or anything on the CPU / disk, raises: this
+        implementation has one handle per GPU and no CPU path."""
         from .checkpoint import config_from_hf, load_checkpoint
         import os
+        if device is not None and device_map is not None and _resolve_device(device) != _resolve_device(device_map):
+            raise ValueError("from_pretrained: `device` and `device_map` name different devices")
+        dev = _resolve_device(device if device is not None else device_map)
         sd = load_checkpoint(path)
         if config is None:
             has_cfg = os.path.isdir(path) and os.path.exists(os.path.join(path, "config.json"))
             config = config_from_hf(path if has_cfg else {}, state_dict=sd)
-        return cls.from_state_dict(sd, config, torch_dtype=torch_dtype, device=device)
+        return cls.from_state_dict(sd, config, torch_dtype=torch_dtype, device=dev)
 
     def load_state_dict(self, state_dict, strict: bool = True):
         """Accepts the reference checkpoint's names (numpy arrays or torch tensors, any float dtype)."""
@@ -190,9 +223,9 @@ class RadZeroModel:
                 dtype = a
             elif isinstance(a, (str, torch.device)):
                 device = a
-        if device is not None and torch.device(device) != self._device and torch.device(device).type != "cuda":
+        if device is not None and torch.device(device).type != "cuda":
             raise RuntimeError("RadZeroModel cannot be moved off the GPU (no CPU path)")
-        new_device = torch.device(device) if device is not None else self._device
+        new_device = _resolve_device(device) if device is not None else self._device
         if (dtype is not None and dtype != self.dtype) or new_device != self._device:
             if dtype is not None and dtype not in _DTYPES:
                 raise NotImplementedError(f"unsupported dtype {dtype}")
@@ -291,7 +324,9 @@ class RadZeroModel:
         if not self.text_cache_enabled:
             return self.forward_text_model({"input_ids": ids, "attention_mask": mask})["text_features_wo_l2_norm"]
         ident = None
-        if torch.is_tensor(ids) and torch.is_tensor(mask):
+        # inference tensors (created under torch.inference_mode()) keep no version counter — reading `_version` raises — so an
+        # in-place write to them could not be noticed: they take the content key below
+        if torch.is_tensor(ids) and torch.is_tensor(mask) and not ids.is_inference() and not mask.is_inference():
             ident = (ids.data_ptr(), mask.data_ptr(), tuple(ids.shape), tuple(mask.shape), ids.dtype, mask.dtype,
                      str(ids.device), ids._version, mask._version)
             hit = self._text_ident_cache.get(ident)
@@ -413,10 +448,26 @@ class RadZeroModel:
     # ---- library switches ------------------------------------------------------------------------
     @staticmethod
     def set_option(name: str, value: int) -> None:
-        """Process-wide switch of the HIP library (include/radzero_hip.h, rz_set_option), e.g. set_option("gemm_f32_split", 0) and
-        set_option("attn_f32_split", 0): fp32 mode on the exact-fp32 MFMA kernels instead of the hi/lo-split f16 ones."""
+        """PROCESS-WIDE switch of the HIP library (include/radzero_hip.h, rz_set_option): for A/B tools.  Handles that have not set
+        the option themselves follow it."""
         lib = _lib.load()
         _lib.check(lib.rz_set_option(name.encode(), int(value)), "rz_set_option")
+
+    def set_model_option(self, name: str, value: Optional[int]) -> None:
+        """This model's own switch (rz_set_model_option), e.g. set_model_option("gemm_f32_split", 0): fp32 mode on the exact-fp32
+        MFMA kernels instead of the hi/lo-split f16 ones — other models of the process are unaffected.  None = follow the
+        process-wide value again."""
+        v = -(2 ** 31) if value is None else int(value)
+        with torch.cuda.device(self._device):
+            _lib.check(self._lib.rz_set_model_option(self._h, name.encode(), v), "rz_set_model_option")
+        if name == "pad_rows":                       # the library dropped its tables / workspace sizes
+            self._grids.clear()
+            self._reserved = (0, 0, 0, 0)
+
+    def get_model_option(self, name: str) -> int:
+        v = ctypes.c_int(0)
+        _lib.check(self._lib.rz_get_model_option(self._h, name.encode(), ctypes.byref(v)), "rz_get_model_option")
+        return int(v.value)
 
     # ---- measurement -----------------------------------------------------------------------------
     def profile(self, enable: bool, families=None):

@@ -83,8 +83,77 @@ def test_set_option_known_and_unknown_names():
     No compute call: runs without a GPU."""
     from radzero_amd.modeling import RadZeroModel
     defaults = {"gemm_variant": 0, "attn_variant": 0, "ln_fused": 1, "attn_f32_split": 1, "gemm_f32_split": 1, "vision_chunk": 0,
-                "vision_streams": 1, "mlp_chunk": 0, "gemm_skew": 0}
+                "vision_streams": 1, "mlp_chunk": 0, "pad_rows": 0, "f32_split_guard": 1, "gemm_v1_only": 0}
     for name, value in defaults.items():
         RadZeroModel.set_option(name, value)
     with pytest.raises(ValueError):
         RadZeroModel.set_option("no_such_option", 1)
+    with pytest.raises(ValueError):
+        RadZeroModel.set_option("gemm_skew", 0)          # an experiment of round 2, removed from the library
+    # the header documents exactly the options the library knows (VERDICT r2 item 10: gemm_f32_split was missing, gemm_skew stale)
+    hdr = open(os.path.join(ROOT, "include", "radzero_hip.h")).read()
+    documented = set(re.findall(r'^ \*\s+"([a-z_0-9]+)"', hdr, flags=re.M))
+    assert documented == set(defaults), (documented ^ set(defaults))
+
+
+def test_model_options_need_a_handle():
+    """rz_set_model_option / rz_get_model_option reject a null handle (no GPU needed); with a handle: tests/test_gpu_boundary.py."""
+    from radzero_amd import _lib
+    lib = _lib.load()
+    v = ctypes.c_int(0)
+    assert lib.rz_set_model_option(None, b"ln_fused", 0) == 10001
+    assert lib.rz_get_model_option(None, b"ln_fused", ctypes.byref(v)) == 10001
+    assert lib.rz_debug_buffer(b"gemm_v8_stamps", None) == 10001          # tools build only
+
+
+def test_device_map_resolution():
+    """README.md:77-82 passes device_map= to from_pretrained: one device for the whole model is honoured, anything else raises."""
+    import torch
+    from radzero_amd.modeling import _resolve_device
+    assert _resolve_device("cuda:3") == torch.device("cuda", 3)
+    assert _resolve_device(2) == torch.device("cuda", 2)
+    assert _resolve_device({"": "cuda:1"}) == torch.device("cuda", 1)
+    assert _resolve_device({"vision_model": 1, "text_model": "cuda:1"}) == torch.device("cuda", 1)
+    for spec in ("cuda", "auto", None, torch.device("cuda")):
+        d = _resolve_device(spec)
+        assert d.type == "cuda" and d.index is not None          # never an index-less device: the handle is bound to one GPU
+    with pytest.raises(NotImplementedError):
+        _resolve_device({"vision_model": 0, "text_model": 1})
+    for bad in ("cpu", {"": "cpu"}, {"": "disk"}):
+        with pytest.raises(RuntimeError):
+            _resolve_device(bad)
+
+
+def test_encode_prompts_cache_under_inference_mode():
+    """inference tensors keep no version counter; the identity cache level must step aside for them instead of raising.
+    Host logic only: the text encoder is replaced by a counter."""
+    import torch
+    from radzero_amd.modeling import RadZeroModel
+    m = RadZeroModel.__new__(RadZeroModel)
+    m.text_cache_enabled = True
+    m._text_cache, m._text_ident_cache = {}, {}
+    calls = []
+
+    def fake_text(enc):
+        calls.append(1)
+        return {"text_features_wo_l2_norm": enc["input_ids"].float().sum(1, keepdim=True)}
+    m.forward_text_model = fake_text
+    with torch.inference_mode():
+        ids = torch.arange(12).reshape(3, 4).clone()
+        mask = torch.ones_like(ids)
+        assert ids.is_inference()
+        a = m.encode_prompts({"input_ids": ids, "attention_mask": mask})
+        b = m.encode_prompts({"input_ids": ids, "attention_mask": mask})          # content key hit
+        assert len(calls) == 1 and torch.equal(a, b) and not m._text_ident_cache
+        ids2 = ids + 1
+        m.encode_prompts({"input_ids": ids2, "attention_mask": mask})
+        assert len(calls) == 2
+    ids3 = torch.arange(12).reshape(3, 4) + 7                                      # ordinary tensors: identity level, and it sees in-place writes
+    mask3 = torch.ones_like(ids3)
+    m.encode_prompts({"input_ids": ids3, "attention_mask": mask3})
+    m.encode_prompts({"input_ids": ids3, "attention_mask": mask3})
+    assert len(calls) == 3 and len(m._text_ident_cache) == 1
+    ids3.add_(1)
+    m.encode_prompts({"input_ids": ids3, "attention_mask": mask3})
+    assert len(calls) == 4
+    m._h = None

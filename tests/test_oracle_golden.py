@@ -51,6 +51,22 @@ def test_oracle_matches_reference_1024(oracle):
     assert int(np.argmax(out["logits"].numpy())) == int(np.argmax(g["logits"]))
 
 
+def test_oracle_matches_reference_1536(oracle):
+    """G9: BASELINE configs[4]'s per-GPU shape (one 1536^2 image, N = 11 882 tokens, 193 prompts) — the reference's own run
+    (tools/make_goldens.py --g9) against the oracle.  ~45 s of CPU on 8 cores (SDPA in every block: 2.3 GB peak)."""
+    g = load_golden("g9_s1536_b1_t193")
+    px, enc = _inputs(g)
+    oracle_sdpa = type(oracle)({k: v for k, v in oracle.P.items()}, oracle.cfg, attn_impl="sdpa")
+    with torch.no_grad():
+        out = oracle_sdpa.compute_logits(px, [enc])
+    sim = out["similarity_scores"].numpy().reshape(193, -1)
+    assert np.abs(out["logits"].numpy() - g["logits"]).max() <= 5e-4
+    assert np.abs(sim[:int(g["full_prompts"])] - g["scores_full"]).max() <= 5e-4
+    assert np.abs(sim[:, ::int(g["sample_stride"])] - g["samples"]).max() <= 5e-4
+    assert np.array_equal(sim.argmax(1), g["patch_argmax"])
+    assert int(np.argmax(out["logits"].numpy())) == int(np.argmax(g["logits"]))
+
+
 def test_oracle_stages(oracle):
     g = load_golden("g2_s224_b2_t3")
     px, enc = _inputs(g)

@@ -72,7 +72,7 @@ def load_reference_model(cfg, state_dict=None, attn_implementation="eager"):
         num_attention_heads=cfg.num_attention_heads, intermediate_size=cfg.text_intermediate_size,
         max_position_embeddings=cfg.max_position_embeddings, layer_norm_eps=cfg.text_layer_norm_eps,
         relative_attention_num_buckets=cfg.relative_attention_num_buckets)
-    mcfg._attn_implementation = attn_implementation
+    mcfg._attn_implementation = "eager"          # MPNet has no SDPA path in transformers; `attn_implementation` selects the vision side only
 
     class _AutoConfig:                      # configuration.py:25-27
         @staticmethod
@@ -113,7 +113,7 @@ def load_reference_model(cfg, state_dict=None, attn_implementation="eager"):
         pretrained_dir="/data/pretrained",          # exp/cxr_pt/configs/paths.yaml:11 (only read for m3ae)
     )
     rcfg = configuration.CxrAlignConfig(**model_config)
-    rcfg.align_transformer_config._attn_implementation = attn_implementation
+    rcfg.align_transformer_config._attn_implementation = "eager"     # the reference's AlignTransformer declares no SDPA support
     model = modeling.CxrAlignModel(rcfg).eval().float()
     # the released compute_logits reads an attribute __init__ never sets
     # (modeling.py:320); the only self-consistent branch is compute_i2t_loss == False.
