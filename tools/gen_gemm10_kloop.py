@@ -1,0 +1,153 @@
+"""Generate radzero_amd/csrc/gemm10_kloop.inc: the K loop of the 4-wave persistent GEMM (gemm10.hip) as inline-asm text.
+
+Why generated: the loop is 4 x 128 MFMAs with hand-placed LDS reads / LDS-DMA issues and asm-owned registers (256 accumulators
+in a[0:255], 128 fragment registers in v[128:255]); hipcc cannot be made to keep that allocation, and nobody
+should type 1 500 instruction lines by hand.  Run:  python tools/gen_gemm10_kloop.py   (writes the .inc; commit it).
+
+One asm block = the whole K loop of ONE 256x256 output tile for one wave (128x128 outputs):
+  FIRST pair of K tiles (K tile 0 starts from srcC = 0: no accumulator clearing), MID pairs in a scalar loop, LAST pair
+  (its LDS-DMA pieces belong to the NEXT output tile).  Per K tile t (LDS stage st = t & 1):
+    k-step 0: 64 MFMAs on fragment set 0; the 16 ds_read_b128 of k-step 1 (same stage) go into set 1 between them
+    X_t     : s_waitcnt vmcnt(..) lgkmcnt(0); s_barrier   -> every wave has finished READING stage st and every wave's pieces of
+              K tile t+1 have landed in stage st^1
+    k-step 1: 64 MFMAs on set 1; between them the wave's 16 LDS-DMA pieces of K tile t+2 (into stage st, free since X_t) and
+              the 16 ds_read_b128 of K tile t+1's k-step 0 (stage st^1) into set 0
+See gemm10.hip for the ordering argument (RAW / WAR) and the operand list.
+"""
+import os
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+OUT = os.path.join(ROOT, "radzero_amd", "csrc", "gemm10_kloop.inc")
+
+GLDS_EVERY = int(os.environ.get('RZ_V10_GLDS_EVERY', '4'))   # one LDS-DMA piece per this many MFMAs of k-step 1 (2: bunched in its first half; 4: spread over all of it)
+ABL = set(os.environ.get('RZ_V10_ABLATE', '').split(','))     # timing ablations (WRONG results): noglds, nowait, nords, nobar
+FRAG0 = 128            # v[128:255]: fragment set s at FRAG0 + 64 s: 8 A fragments (4 VGPRs each) then 8 W fragments
+ADDR0 = 120            # v[120:127]: LDS read addresses  [operand A/W][stage][ks]
+# scalar temporaries (clobbered)
+S_CA, S_CW, S_T, S_CNT, S_SA, S_SW = 64, 66, 68, 70, 71, 78      # running A / W source (pairs), temp pair, loop count, e*strideA (7), e*strideW (7)
+
+
+def fa(s, i): return f"v[{FRAG0 + 64 * s + 4 * i}:{FRAG0 + 64 * s + 4 * i + 3}]"
+def fw(s, j): return f"v[{FRAG0 + 64 * s + 32 + 4 * j}:{FRAG0 + 64 * s + 32 + 4 * j + 3}]"
+def acc(i, j): return f"a[{(i * 8 + j) * 4}:{(i * 8 + j) * 4 + 3}]"
+def addr(op, st, ks): return f"v{ADDR0 + op * 4 + st * 2 + ks}"
+
+
+class Emit:
+    def __init__(self): self.lines = []
+    def __call__(self, s): self.lines.append(s)
+
+
+def mfma(e, mn, swap, s, i, j, first):
+    a, w = fa(s, i), fw(s, j)
+    src_a, src_b = (w, a) if swap else (a, w)          # SWAP: D[n][m] (lane owns 4 consecutive columns n), else D[m][n]
+    e(f"v_mfma_f32_16x16x32_{mn} {acc(i, j)}, {src_a}, {src_b}, {'0' if first else acc(i, j)}")
+
+
+def read_frag(e, n, st, ks, s):
+    """fragment n of a k-step: n < 8 W fragment n, else A fragment n - 8 (the first MFMAs of a k-step need every W fragment)"""
+    if 'nords' in ABL: return
+    if n < 8: e(f"ds_read_b128 {fw(s, n)}, {addr(1, st, ks)} offset:{n * 2048}")
+    else: e(f"ds_read_b128 {fa(s, n - 8)}, {addr(0, st, ks)} offset:{(n - 8) * 2048}")
+
+
+def glds(e, p, st):
+    """LDS-DMA piece p of this wave for the K tile whose source is at s[S_CA] / s[S_CW]: p < 8 A rows 8p.., else W rows 8(p-8).."""
+    op, q = (0, p) if p < 8 else (1, p - 8)
+    base, stride0 = (S_CA, S_SA) if op == 0 else (S_CW, S_SW)
+    if q == 0:
+        src = f"s[{base}:{base + 1}]"
+    else:
+        e(f"s_add_u32 s{S_T}, s{base}, s{stride0 + q - 1}")
+        e(f"s_addc_u32 s{S_T + 1}, s{base + 1}, 0")
+        src = f"s[{S_T}:{S_T + 1}]"
+    e(f"s_add_i32 m0, %[{'ldsa' if op == 0 else 'ldsw'}], {st * 65536 + q * 1024}")
+    e("s_nop 0")
+    if 'noglds' not in ABL: e(f"global_load_lds_dwordx4 %[{'oa' if op == 0 else 'ow'}{q & 1}], {src}")
+
+
+def ktile(e, mn, swap, st, first_acc, vm_wait, src_update, read_next):
+    """One K tile in stage st.  vm_wait: text of the vmcnt part of X_t.  src_update: lines that move s[S_CA], s[S_CW] to the K tile
+    t+2 before its pieces are issued.  read_next: read K tile t+1's k-step-0 fragments at the end (False in an output tile's last K tile)."""
+    for idx in range(64):                                   # k-step 0
+        mfma(e, mn, swap, 0, idx // 8, idx % 8, first_acc)
+        if idx % 2 == 1 and idx // 2 < 16: read_frag(e, idx // 2, st, 1, 1)
+    if 'nowait' not in ABL: e(vm_wait)
+    e("s_waitcnt lgkmcnt(0)")
+    if 'nobar' not in ABL: e("s_barrier")
+    for ln in src_update: e(ln)
+    for idx in range(64):                                   # k-step 1
+        mfma(e, mn, swap, 1, idx // 8, idx % 8, False)
+        if idx % GLDS_EVERY == 0 and idx // GLDS_EVERY < 16: glds(e, idx // GLDS_EVERY, st)
+        if read_next and idx >= 32 and idx % 2 == 1: read_frag(e, (idx - 32) // 2, st ^ 1, 0, 0)
+    if read_next: e("s_waitcnt lgkmcnt(0)")
+
+
+ADV = [f"s_add_u32 s{S_CA}, s{S_CA}, 128", f"s_addc_u32 s{S_CA + 1}, s{S_CA + 1}, 0",
+       f"s_add_u32 s{S_CW}, s{S_CW}, 128", f"s_addc_u32 s{S_CW + 1}, s{S_CW + 1}, 0"]
+TO_NEXT = [f"s_mov_b32 s{S_CA}, %[anlo]", f"s_mov_b32 s{S_CA + 1}, %[anhi]", f"s_mov_b32 s{S_CW}, %[wnlo]", f"s_mov_b32 s{S_CW + 1}, %[wnhi]"]
+
+
+def block(mn, swap):
+    e = Emit()
+    # ---- set-up: LDS read addresses, source strides, running sources at K tile 2 of this output tile
+    for op, name in ((0, "va"), (1, "vw")):
+        e(f"v_mov_b32 {addr(op, 0, 0)}, %[{name}]")
+        e(f"v_xor_b32 {addr(op, 0, 1)}, 64, %[{name}]")
+        e(f"v_add_u32 {addr(op, 1, 0)}, 0x10000, %[{name}]")
+        e(f"v_add_u32 {addr(op, 1, 1)}, 0x10000, {addr(op, 0, 1)}")
+    for base, stride in ((S_SA, "sa8"), (S_SW, "sw8")):
+        e(f"s_mov_b32 s{base}, %[{stride}]")
+        for q in range(1, 7): e(f"s_add_u32 s{base + q}, s{base + q - 1}, %[{stride}]")
+    e(f"s_add_u32 s{S_CA}, %[ablo], 256"); e(f"s_addc_u32 s{S_CA + 1}, %[abhi], 0")
+    e(f"s_add_u32 s{S_CW}, %[wblo], 256"); e(f"s_addc_u32 s{S_CW + 1}, %[wbhi], 0")
+    e(f"s_lshr_b32 s{S_CNT}, %[nk], 1"); e(f"s_sub_u32 s{S_CNT}, s{S_CNT}, 2")        # MID pairs = nk/2 - 2
+    # fragments of K tile 0, k-step 0 (stage 0): landed and barrier-ed by the previous output tile's X (or the prologue)
+    for n in range(16): read_frag(e, n, 0, 0, 0)
+    e("s_waitcnt lgkmcnt(0)")
+    # ---- FIRST pair.  X_0 must retire this wave's pieces of K tile 1, which are OLDER than the previous epilogue's stores: after an
+    # epilogue the youngest %[extra] operations (stores) may stay in flight, on a workgroup's first output tile nothing may.
+    ktile_first_wait = "s_cmp_eq_u32 %[after], 0\ns_cbranch_scc1 1f\ns_waitcnt vmcnt(%[extra])\ns_branch 2f\n1:\ns_waitcnt vmcnt(0)\n2:"
+    ktile(e, mn, swap, 0, True, ktile_first_wait, [], True)
+    ktile(e, mn, swap, 1, False, "s_waitcnt vmcnt(0)", ADV, True)
+    # ---- MID pairs
+    e(f"s_cmp_eq_u32 s{S_CNT}, 0")
+    e("s_cbranch_scc1 4f")
+    e("3:")
+    ktile(e, mn, swap, 0, False, "s_waitcnt vmcnt(0)", ADV, True)
+    ktile(e, mn, swap, 1, False, "s_waitcnt vmcnt(0)", ADV, True)
+    e(f"s_sub_u32 s{S_CNT}, s{S_CNT}, 1")
+    e(f"s_cmp_lg_u32 s{S_CNT}, 0")
+    e("s_cbranch_scc1 3b")
+    e("4:")
+    # ---- LAST pair: pieces of the next output tile's K tiles 0 and 1
+    ktile(e, mn, swap, 0, False, "s_waitcnt vmcnt(0)", TO_NEXT, True)
+    ktile(e, mn, swap, 1, False, "s_waitcnt vmcnt(0)", ADV, False)
+    e("s_nop 15")
+    e("s_nop 15")           # MFMA results -> v_accvgpr_read (the compiler sees no MFMA here and would pad nothing)
+    return e.lines
+
+
+def c_string(lines):
+    out = []
+    for ln in lines:
+        for part in ln.split("\n"):
+            out.append('    "' + part + '\\n"')
+    return "\n".join(out)
+
+
+def main():
+    parts = ["// GENERATED by tools/gen_gemm10_kloop.py — do not edit.  Inline-asm text of gemm10.hip's K loop (see both files' headers).\n"]
+    for mn in ("bf16", "f16"):
+        for swap in (True, False):
+            name = f"RZ_V10_KLOOP_{mn.upper()}_{'SWAP' if swap else 'PLAIN'}"
+            lines = block(mn, swap)
+            n_mfma = sum(1 for l in lines if l.startswith("v_mfma"))
+            parts.append(f"// {name}: {len(lines)} lines, {n_mfma} MFMAs in the text (6 K-tile bodies)\n#define {name} \\\n" +
+                         " \\\n".join(c_string(lines).split("\n")) + "\n")
+    open(OUT, "w").write("\n".join(parts))
+    print("wrote", OUT, sum(len(p) for p in parts), "bytes")
+
+
+if __name__ == "__main__":
+    main()

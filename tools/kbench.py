@@ -160,7 +160,7 @@ if __name__ == "__main__":
     ap.add_argument("--attn-variant", type=int, default=0)
     ap.add_argument("--zeros", action="store_true")
     ap.add_argument("--tokens", type=int, default=5330, help="tokens per image for the attention bench (5330 = 1024^2, 11882 = 1536^2)")
-    ap.add_argument("--skew", type=int, default=0, help="persistent GEMM start-up stagger period, 10 ns ticks")
+    ap.add_argument("--variants", type=int, nargs="+", default=[8, 10], help="GEMM kernels of the `gemmab` A/B (interleaved rounds in one process)")
     a = ap.parse_args()
     if a.v1:
         lib.rz_set_option(b"gemm_v1_only", 1)
@@ -168,13 +168,11 @@ if __name__ == "__main__":
         lib.rz_set_option(b"attn_variant", a.attn_variant)
     if a.variant:
         lib.rz_set_option(b"gemm_variant", a.variant)
-    if a.skew:
-        lib.rz_set_option(b"gemm_skew", a.skew)
     if a.what in ("attn", "all"):
         bench_attn(a.images, n=a.tokens, dt=a.dtype, zeros=a.zeros)
     if a.what in ("gemm", "all"):
         bench_gemm(a.images, n=a.tokens, dt=a.dtype)
     if a.what == "gemmab":
-        bench_gemm_ab(a.images, dt=a.dtype)
+        bench_gemm_ab(a.images, dt=a.dtype, variants=tuple(a.variants))
     if a.what == "library":
         bench_library(a.images, dt=a.dtype)
