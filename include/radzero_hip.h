@@ -135,6 +135,26 @@ int rz_preprocess_image(const void* image_dev, int src_dtype, int height, int wi
                         const int32_t* coeffs_v_dev, int ksize_v, const float* mean3_host, const float* std3_host, float rescale,
                         int minmax_normalize, void* workspace_dev, float* pixel_values_out_dev, void* stream);
 
+/* The same for a BATCH of images of different sizes / dtypes in one set of launches (collate_fn processes the whole batch,
+ * dataset.py:31-51), with the AspectRatioBlipImageProcessor branch (processing.py:232-259: convert_to_rgb -> pad_to_square with
+ * fill 0 -> BlipImageProcessor) when pad_left / pad_top / padded_* describe the padded square:
+ *   pad_left = (max(w, h) - w) / 2, pad_top = (max(w, h) - h) / 2, padded_height = padded_width = max(w, h);
+ * for the plain BlipImageProcessor pad_* = 0 and padded_* = height / width.  The resampling tables are those of
+ * padded_width -> out_side (horizontal) and padded_height -> out_side (vertical).  descs_host: host array, copied before the call returns. */
+typedef struct rz_image_desc {
+    const void* image_dev;            /* (height, width, channels) of src_dtype: 0 uint8, 1 uint16, 2 float32 */
+    int32_t src_dtype, height, width, channels;
+    int32_t pad_left, pad_top, padded_height, padded_width;
+    const int32_t* bounds_h_dev; const int32_t* coeffs_h_dev; int32_t ksize_h;
+    const int32_t* bounds_v_dev; const int32_t* coeffs_v_dev; int32_t ksize_v;
+} rz_image_desc;
+/* bytes of workspace_dev the call below needs for these images (0 on a bad argument) */
+size_t rz_preprocess_batch_workspace(const rz_image_desc* descs_host, int n_images, int out_side);
+/* pixel_values_out_dev: fp32 (n_images, 3, out_side, out_side) — directly the input of rz_vision_forward */
+int rz_preprocess_batch(const rz_image_desc* descs_host, int n_images, int out_side, const float* mean3_host, const float* std3_host,
+                        float rescale, int minmax_normalize, void* workspace_dev, size_t workspace_bytes, float* pixel_values_out_dev,
+                        void* stream);
+
 /* ---- per-kernel entry points (used by the parity tests; all pointers device) ---- */
 /* C = A[M,K] W[N,K]^T + bias; dtype of A/W/out = rz_dtype; epilogue: 0 store, 1 GELU(erf), 7 store fp32 */
 int rz_gemm(int dtype, int epilogue, const void* a_dev, const void* w_dev, const float* bias_dev, void* out_dev, int m,
@@ -195,10 +215,10 @@ int rz_get_model_option(rz_handle_t h, const char* name, int* value_out);
 int rz_debug_buffer(const char* what, void* dev_ptr);
 
 /* ---- measurement: HIP-event timing of kernel families on the launch stream ---- */
-enum rz_prof_family { RZ_PROF_ATTN = 0, RZ_PROF_GEMM = 1, RZ_PROF_ROWOPS = 2, RZ_PROF_VLCABS = 3, RZ_PROF_NFAM = 4 };
+enum rz_prof_family { RZ_PROF_ATTN = 0, RZ_PROF_GEMM = 1, RZ_PROF_ROWOPS = 2, RZ_PROF_VLCABS = 3, RZ_PROF_POST = 4 /* map upsample / grounding */, RZ_PROF_NFAM = 5 };
 /* enable: 0 off | 1 every family | 1 + (mask << 1): only the families whose bit (1 << rz_prof_family) is set in mask */
 int rz_profile_enable(rz_handle_t h, int enable);
-/* after a stream synchronize: total milliseconds and launch count per family since enable; resets them */
+/* after a stream synchronize: total milliseconds and launch count per family (arrays of RZ_PROF_NFAM) since enable; resets them */
 int rz_profile_read(rz_handle_t h, float* ms_per_family, int64_t* launches_per_family);
 
 #ifdef __cplusplus

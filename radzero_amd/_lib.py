@@ -20,7 +20,7 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 ARCH = "gfx950"
 
 RZ_F32, RZ_BF16, RZ_F16 = 0, 1, 2
-PROF_FAMILIES = ("attn", "gemm", "rowops", "vlcabs")
+PROF_FAMILIES = ("attn", "gemm", "rowops", "vlcabs", "post")
 
 
 def _needs_rebuild() -> bool:
@@ -90,6 +90,14 @@ def _src_mtime(src: str) -> float:
     return max(os.path.getmtime(d) for d in deps if os.path.exists(d))
 
 
+class RzImageDesc(ctypes.Structure):
+    """rz_image_desc (include/radzero_hip.h)"""
+    _fields_ = [("image_dev", ctypes.c_void_p), ("src_dtype", ctypes.c_int32), ("height", ctypes.c_int32), ("width", ctypes.c_int32),
+                ("channels", ctypes.c_int32), ("pad_left", ctypes.c_int32), ("pad_top", ctypes.c_int32), ("padded_height", ctypes.c_int32),
+                ("padded_width", ctypes.c_int32), ("bounds_h_dev", ctypes.c_void_p), ("coeffs_h_dev", ctypes.c_void_p), ("ksize_h", ctypes.c_int32),
+                ("bounds_v_dev", ctypes.c_void_p), ("coeffs_v_dev", ctypes.c_void_p), ("ksize_v", ctypes.c_int32)]
+
+
 class RzConfig(ctypes.Structure):
     _fields_ = [
         ("compute_dtype", ctypes.c_int32), ("hidden_size", ctypes.c_int32), ("num_attention_heads", ctypes.c_int32),
@@ -120,6 +128,8 @@ SYMBOLS = {
     "rz_grounding_points_ex": (_I, [_P, _P, _L, _I, _I, _I, _I, _I, _P, _P, _P]),
     "rz_upsample_maps_ex": (_I, [_P, _P, _L, _I, _I, _I, _I, _I, _I, _P, _P]),
     "rz_preprocess_image": (_I, [_P, _I, _I, _I, _I, _I, _P, _P, _I, _P, _P, _I, _P, _P, _F, _I, _P, _P, _P]),
+    "rz_preprocess_batch_workspace": (ctypes.c_size_t, [ctypes.POINTER(RzImageDesc), _I, _I]),
+    "rz_preprocess_batch": (_I, [ctypes.POINTER(RzImageDesc), _I, _I, _P, _P, _F, _I, _P, ctypes.c_size_t, _P, _P]),
     "rz_gemm": (_I, [_I, _I, _P, _P, _P, _P, _I, _I, _I, _P]),
     "rz_gemm_ex": (_I, [_I, _I, _P, _L, _P, _L, _P, _P, _L, _P, _P, _L, _I, _I, _I, _I, _I, _P]),
     "rz_gemm_qkv": (_I, [_I, _P, _P, _P, _P, _P, _I, _I, _I, _P, _P]),

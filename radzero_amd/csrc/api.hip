@@ -184,12 +184,12 @@ struct rz_model {
     int last_batch = 0, last_nvalid = 0, last_npad = 0;
     // profiling
     bool prof = false;
-    unsigned prof_mask = 0xF;   // kernel families that record events (bit = rz_prof_family)
+    unsigned prof_mask = 0x1F;   // kernel families that record events (bit = rz_prof_family)
     struct Ev { hipEvent_t a, b; int fam; };
     std::vector<Ev> ev_pool;
     size_t ev_used = 0;
-    float prof_ms[RZ_PROF_NFAM] = {0, 0, 0, 0};
-    int64_t prof_n[RZ_PROF_NFAM] = {0, 0, 0, 0};
+    float prof_ms[RZ_PROF_NFAM] = {};
+    int64_t prof_n[RZ_PROF_NFAM] = {};
     std::vector<void*> allocs;
     hipStream_t side[2] = {nullptr, nullptr};
     hipEvent_t side_done[2] = {nullptr, nullptr}, fork = nullptr;
@@ -1060,7 +1060,7 @@ int rz_upsample_maps_ex(rz_handle_t m, const float* maps, int64_t map_stride, in
         return fail(RZ_ERR_INVALID, "rz_upsample_maps: bad argument");
     hipStream_t s = (hipStream_t)stream;
     if (m) {
-        ProfScope ps(m, RZ_PROF_VLCABS, s);
+        ProfScope ps(m, RZ_PROF_POST, s);
         RZ_HIP(launch_upsample_bilinear(maps, map_stride, out, nullptr, n_maps, grid, out_h, out_w, apply_sigmoid, keep_aspect_ratio, s));
     } else {
         RZ_HIP(launch_upsample_bilinear(maps, map_stride, out, nullptr, n_maps, grid, out_h, out_w, apply_sigmoid, keep_aspect_ratio, s));
@@ -1078,7 +1078,11 @@ int rz_grounding_points_ex(rz_handle_t m, const float* maps, int64_t map_stride,
     if (!maps || !xy_out || !keys_ws || n_maps <= 0 || grid <= 0 || out_h <= 0 || out_w <= 0 || map_stride < (int64_t)grid * grid)
         return fail(RZ_ERR_INVALID, "rz_grounding_points: bad argument");
     hipStream_t s = (hipStream_t)stream;
-    (void)m;
+    if (m) {
+        ProfScope ps(m, RZ_PROF_POST, s);
+        RZ_HIP(launch_grounding_points(maps, map_stride, (unsigned long long*)keys_ws, xy_out, n_maps, grid, out_h, out_w, keep_aspect_ratio, s));
+        return 0;
+    }
     RZ_HIP(launch_grounding_points(maps, map_stride, (unsigned long long*)keys_ws, xy_out, n_maps, grid, out_h, out_w, keep_aspect_ratio, s));
     return 0;
 }
@@ -1097,6 +1101,58 @@ int rz_preprocess_image(const void* image, int src_dtype, int height, int width,
     unsigned char* ws8 = (unsigned char*)workspace + 16;
     RZ_HIP(launch_preprocess(image, src_dtype, height, width, channels, out_side, bounds_h, coeffs_h, ksize_h, bounds_v, coeffs_v, ksize_v,
                              mean3_host, std3_host, rescale, ws8, mm, pixel_values_out, minmax_normalize, (hipStream_t)stream));
+    return 0;
+}
+
+namespace {
+struct PreDescHost {       // = preprocess.hip's PreDesc
+    const void* img; int dtype, H, W, C;
+    int pad_left, pad_top, PH, PW;
+    const int* bounds_h; const int* kk_h; int ksize_h;
+    const int* bounds_v; const int* kk_v; int ksize_v;
+    int64_t a8, b8, c8;
+};
+// lays the per-image byte buffers out behind the descriptor block; returns the total, 0 on a bad descriptor
+size_t preprocess_layout(const rz_image_desc* d, int n, int S, std::vector<PreDescHost>* out, int* max_ph) {
+    if (!d || n <= 0 || S <= 0) return 0;
+    size_t off = preprocess_batch_desc_bytes(n);
+    if (out) out->resize(n);
+    int mph = 0;
+    for (int i = 0; i < n; ++i) {
+        const rz_image_desc& e = d[i];
+        if (!e.image_dev || e.height <= 0 || e.width <= 0 || (e.channels != 1 && e.channels != 3) || e.src_dtype < 0 || e.src_dtype > 2) return 0;
+        if (e.pad_left < 0 || e.pad_top < 0 || e.padded_height < e.height + e.pad_top || e.padded_width < e.width + e.pad_left) return 0;
+        if (!e.bounds_h_dev || !e.coeffs_h_dev || !e.bounds_v_dev || !e.coeffs_v_dev || e.ksize_h <= 0 || e.ksize_v <= 0) return 0;
+        const size_t C = e.channels, PH = e.padded_height, PW = e.padded_width;
+        PreDescHost p{e.image_dev, e.src_dtype, e.height, e.width, e.channels, e.pad_left, e.pad_top, e.padded_height, e.padded_width,
+                      e.bounds_h_dev, e.coeffs_h_dev, e.ksize_h, e.bounds_v_dev, e.coeffs_v_dev, e.ksize_v, 0, 0, 0};
+        p.a8 = (int64_t)off; off += (PH * PW * C + 255) / 256 * 256;
+        p.b8 = (int64_t)off; off += (PH * (size_t)S * C + 255) / 256 * 256;
+        p.c8 = (int64_t)off; off += ((size_t)S * S * C + 255) / 256 * 256;
+        if (out) (*out)[i] = p;
+        mph = std::max(mph, e.padded_height);
+    }
+    if (max_ph) *max_ph = mph;
+    return off;
+}
+}  // namespace
+
+size_t rz_preprocess_batch_workspace(const rz_image_desc* descs, int n, int out_side) { return preprocess_layout(descs, n, out_side, nullptr, nullptr); }
+
+int rz_preprocess_batch(const rz_image_desc* descs, int n, int out_side, const float* mean3_host, const float* std3_host, float rescale,
+                        int minmax_normalize, void* workspace, size_t workspace_bytes, float* pixel_values_out, void* stream) {
+    if (!descs || !mean3_host || !std3_host || !workspace || !pixel_values_out) return fail(RZ_ERR_INVALID, "rz_preprocess_batch: null argument");
+    static_assert(sizeof(PreDescHost) % 8 == 0, "descriptor block keeps the min/max words aligned");
+    std::vector<PreDescHost> dd;
+    int max_ph = 0;
+    const size_t need = preprocess_layout(descs, n, out_side, &dd, &max_ph);
+    if (need == 0) return fail(RZ_ERR_INVALID, "rz_preprocess_batch: bad image descriptor (shape, dtype, padding or tables)");
+    if (workspace_bytes < need) return fail(RZ_ERR_STATE, "rz_preprocess_batch: workspace too small (rz_preprocess_batch_workspace)");
+    if (!minmax_normalize)
+        for (int i = 0; i < n; ++i)
+            if (descs[i].src_dtype != 0) return fail(RZ_ERR_INVALID, "rz_preprocess_batch: without min-max normalisation the images must be uint8");
+    RZ_HIP(launch_preprocess_batch(dd.data(), n, max_ph, out_side, mean3_host, std3_host, rescale, (unsigned char*)workspace, pixel_values_out,
+                                   minmax_normalize, (hipStream_t)stream));
     return 0;
 }
 
@@ -1229,7 +1285,7 @@ int rz_get_model_option(rz_handle_t m, const char* name, int* value_out) {
 int rz_profile_enable(rz_handle_t m, int enable) {
     if (!m) return fail(RZ_ERR_INVALID, "null handle");
     m->prof = enable != 0;
-    m->prof_mask = enable > 1 ? ((unsigned)enable >> 1) & 0xFu : 0xFu;      // enable = 1: every family; 1 | mask << 1: only the families in mask
+    m->prof_mask = enable > 1 ? ((unsigned)enable >> 1) & 0x1Fu : 0x1Fu;      // enable = 1: every family; 1 | mask << 1: only the families in mask
     m->ev_used = 0;
     for (int i = 0; i < RZ_PROF_NFAM; ++i) { m->prof_ms[i] = 0.f; m->prof_n[i] = 0; }
     return 0;

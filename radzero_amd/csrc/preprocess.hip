@@ -32,12 +32,19 @@ __global__ __launch_bounds__(256) void minmax_kernel(const S* __restrict__ img, 
 template <typename S>
 __global__ __launch_bounds__(256) void to8_kernel(const S* __restrict__ img, int64_t n, const unsigned* __restrict__ mm,
                                                   unsigned char* __restrict__ out) {
+#pragma clang fp contract(off)
     const float smin = ord2f(mm[0]), smax = ord2f(mm[1]);
     // cv2.normalize(NORM_MINMAX, alpha=0, beta=255): scale = 255 / (smax - smin) (0 when the image is constant), shift = -smin*scale
+    // Exact ties DO occur ((v - min) * 255 / (max - min) = k + 1/2 for integer data), and which way they fall depends on the rounding of the
+    // intermediate products: the form pinned here is the documented restatement radzero_amd.synthetic.minmax_to_u8 — v * scale and
+    // min * scale each rounded to double, then subtracted (NO fused multiply-add: hipcc contracts by default, and HIP's __dmul_rn / __dsub_rn are
+    // plain operators compiled with that default, so they do not help: contraction is switched off for this function by the pragma below).  cv2 itself
+    // (float32 multiply-add inside convertTo) is not installed anywhere this code runs: that one step stays unpinned.
     const double scale = (double)(smax - smin) > 2.220446049250313e-16 ? 255.0 / (double)(smax - smin) : 0.0;
-    const double shift = -(double)smin * scale;
+    const double lo_scaled = (double)smin * scale;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
-        const double v = (double)load_px(img, i) * scale + shift;
+        const double prod = (double)load_px(img, i) * scale;      // rounded product ...
+        const double v = prod - lo_scaled;                           // ... then the subtraction: contraction is off in this function
         int r = (int)rint(v);                          // round half to even (cvRound)
         r = r < 0 ? 0 : (r > 255 ? 255 : r);
         out[i] = (unsigned char)r;
@@ -124,6 +131,136 @@ hipError_t launch_preprocess(const void* img, int src_dtype, int H, int W, int C
     hipLaunchKernelGGL(resample_v_kernel, dim3((S * C + 255) / 256, S), dim3(256), 0, s, b8, c8, bounds_v, kk_v, ksize_v, S, C);
     hipLaunchKernelGGL(normalize_kernel, dim3((S * S + 255) / 256), dim3(256), 0, s, c8, out, S * S, C, rescale, mean[0], mean[1], mean[2],
                        stdv[0], stdv[1], stdv[2]);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Batched form (round 3): B images of different sizes / dtypes per launch, grid.y (or .z) = image; optional pad-to-square of
+// AspectRatioBlipImageProcessor (processing.py:247-259: ImageOps.expand with fill 0 AFTER the 8-bit conversion and the grey->RGB
+// replication, so padding the single grey channel with 0 is the same image).  One descriptor per image in device memory.
+// ---------------------------------------------------------------------------------------------------
+struct PreDesc {
+    const void* img; int dtype, H, W, C;             // raw image
+    int pad_left, pad_top, PH, PW;                    // padded size (= H, W without padding)
+    const int* bounds_h; const int* kk_h; int ksize_h;   // PW -> S
+    const int* bounds_v; const int* kk_v; int ksize_v;   // PH -> S
+    int64_t a8, b8, c8;                               // byte offsets in the workspace: [PH][PW][C], [PH][S][C], [S][S][C]
+};
+
+__device__ __forceinline__ float load_any(const PreDesc& d, int64_t i) {
+    return d.dtype == 0 ? (float)((const unsigned char*)d.img)[i] : d.dtype == 1 ? (float)((const unsigned short*)d.img)[i] : ((const float*)d.img)[i];
+}
+
+__global__ __launch_bounds__(256) void minmax_batch_kernel(const PreDesc* __restrict__ descs, unsigned* __restrict__ mm) {
+    const PreDesc d = descs[blockIdx.y];
+    const int64_t n = (int64_t)d.H * d.W * d.C;
+    float lo = INFINITY, hi = -INFINITY;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const float v = load_any(d, i);
+        lo = fminf(lo, v);
+        hi = fmaxf(hi, v);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { lo = fminf(lo, __shfl_xor(lo, o, 64)); hi = fmaxf(hi, __shfl_xor(hi, o, 64)); }
+    if ((threadIdx.x & 63) == 0 && n > 0) { atomicMin(mm + 2 * blockIdx.y, f2ord(lo)); atomicMax(mm + 2 * blockIdx.y + 1, f2ord(hi)); }
+}
+
+__global__ __launch_bounds__(256) void init_minmax_kernel(unsigned* __restrict__ mm, int n) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) { mm[2 * i] = 0xFFFFFFFFu; mm[2 * i + 1] = 0u; }
+}
+
+// 8-bit conversion (cv2.normalize NORM_MINMAX, or a plain copy of uint8 data) into the zero-padded square
+__global__ __launch_bounds__(256) void to8_pad_batch_kernel(const PreDesc* __restrict__ descs, const unsigned* __restrict__ mm,
+                                                            unsigned char* __restrict__ ws, int minmax) {
+#pragma clang fp contract(off)
+    const PreDesc d = descs[blockIdx.y];
+    double scale = 1.0, lo_scaled = 0.0;
+    if (minmax) {
+        const float smin = ord2f(mm[2 * blockIdx.y]), smax = ord2f(mm[2 * blockIdx.y + 1]);
+        scale = (double)(smax - smin) > 2.220446049250313e-16 ? 255.0 / (double)(smax - smin) : 0.0;
+        lo_scaled = (double)smin * scale;
+    }
+    unsigned char* out = ws + d.a8;
+    const int64_t n = (int64_t)d.PH * d.PW * d.C;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const int c = (int)(i % d.C);
+        const int64_t p = i / d.C;
+        const int x = (int)(p % d.PW) - d.pad_left, y = (int)(p / d.PW) - d.pad_top;
+        int r = 0;
+        if (x >= 0 && x < d.W && y >= 0 && y < d.H) {
+            const double prod = (double)load_any(d, ((int64_t)y * d.W + x) * d.C + c) * scale;      // see to8_kernel
+            const double v = prod - lo_scaled;
+            r = (int)rint(v);                          // round half to even (cvRound)
+            r = r < 0 ? 0 : (r > 255 ? 255 : r);
+        }
+        out[i] = (unsigned char)r;
+    }
+}
+
+__global__ __launch_bounds__(256) void resample_h_batch_kernel(const PreDesc* __restrict__ descs, unsigned char* __restrict__ ws, int S) {
+    const PreDesc d = descs[blockIdx.z];
+    const int y = blockIdx.y, idx = blockIdx.x * 256 + threadIdx.x;
+    if (y >= d.PH || idx >= S * d.C) return;
+    const int xx = idx / d.C, c = idx - xx * d.C;
+    const int xmin = d.bounds_h[2 * xx], xcnt = d.bounds_h[2 * xx + 1];
+    const int* k = d.kk_h + xx * d.ksize_h;
+    int ss = 1 << 21;
+    const unsigned char* row = ws + d.a8 + ((int64_t)y * d.PW + xmin) * d.C + c;
+    for (int x = 0; x < xcnt; ++x) ss += (int)row[(int64_t)x * d.C] * k[x];
+    ss >>= 22;
+    ws[d.b8 + ((int64_t)y * S + xx) * d.C + c] = (unsigned char)(ss < 0 ? 0 : (ss > 255 ? 255 : ss));
+}
+
+__global__ __launch_bounds__(256) void resample_v_batch_kernel(const PreDesc* __restrict__ descs, unsigned char* __restrict__ ws, int S) {
+    const PreDesc d = descs[blockIdx.z];
+    const int yy = blockIdx.y, idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= S * d.C) return;
+    const int ymin = d.bounds_v[2 * yy], ycnt = d.bounds_v[2 * yy + 1];
+    const int* k = d.kk_v + yy * d.ksize_v;
+    int ss = 1 << 21;
+    const unsigned char* col = ws + d.b8 + (int64_t)ymin * S * d.C + idx;
+    for (int y = 0; y < ycnt; ++y) ss += (int)col[(int64_t)y * S * d.C] * k[y];
+    ss >>= 22;
+    ws[d.c8 + (int64_t)yy * S * d.C + idx] = (unsigned char)(ss < 0 ? 0 : (ss > 255 ? 255 : ss));
+}
+
+__global__ __launch_bounds__(256) void normalize_batch_kernel(const PreDesc* __restrict__ descs, const unsigned char* __restrict__ ws,
+                                                              float* __restrict__ out, int n_px, float rescale, float m0, float m1, float m2,
+                                                              float s0, float s1, float s2) {
+    const PreDesc d = descs[blockIdx.y];
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n_px) return;
+    const float mean[3] = {m0, m1, m2}, sd[3] = {s0, s1, s2};
+    const unsigned char* in = ws + d.c8;
+    float* o = out + (int64_t)blockIdx.y * 3 * n_px;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const float v = (float)in[(int64_t)i * d.C + (d.C == 3 ? c : 0)] * rescale;
+        o[(int64_t)c * n_px + i] = (v - mean[c]) / sd[c];
+    }
+}
+
+size_t preprocess_batch_desc_bytes(int n) { return ((size_t)n * sizeof(PreDesc) + 8 * (size_t)n + 255) / 256 * 256; }
+
+// descs_host: n descriptors with a8 / b8 / c8 already laid out BEHIND the descriptor block (preprocess_batch_desc_bytes(n)); ws: the
+// workspace (descriptor block first: [n PreDesc][n x 2 u32 min/max]).
+hipError_t launch_preprocess_batch(const void* descs_host, int n, int max_ph, int S, const float* mean, const float* stdv, float rescale,
+                                   unsigned char* ws, float* out, int minmax_normalize, hipStream_t s) {
+    if (!descs_host || !ws || !out || n <= 0 || S <= 0 || max_ph <= 0) return hipErrorInvalidValue;
+    hipError_t e = hipMemcpyAsync(ws, descs_host, (size_t)n * sizeof(PreDesc), hipMemcpyHostToDevice, s);
+    if (e != hipSuccess) return e;
+    const PreDesc* dd = reinterpret_cast<const PreDesc*>(ws);
+    unsigned* mm = reinterpret_cast<unsigned*>(ws + (size_t)n * sizeof(PreDesc));
+    if (minmax_normalize) {
+        hipLaunchKernelGGL(init_minmax_kernel, dim3((n + 255) / 256), dim3(256), 0, s, mm, n);
+        hipLaunchKernelGGL(minmax_batch_kernel, dim3(256, n), dim3(256), 0, s, dd, mm);
+    }
+    hipLaunchKernelGGL(to8_pad_batch_kernel, dim3(256, n), dim3(256), 0, s, dd, mm, ws, minmax_normalize);
+    hipLaunchKernelGGL(resample_h_batch_kernel, dim3((S * 3 + 255) / 256, max_ph, n), dim3(256), 0, s, dd, ws, S);
+    hipLaunchKernelGGL(resample_v_batch_kernel, dim3((S * 3 + 255) / 256, S, n), dim3(256), 0, s, dd, ws, S);
+    hipLaunchKernelGGL(normalize_batch_kernel, dim3((S * S + 255) / 256, n), dim3(256), 0, s, dd, ws, out, S * S, rescale, mean[0], mean[1],
+                       mean[2], stdv[0], stdv[1], stdv[2]);
     return hipGetLastError();
 }
 

@@ -135,6 +135,11 @@ hipError_t launch_preprocess(const void* img, int src_dtype, int H, int W, int C
                              const int* bounds_v, const int* kk_v, int ksize_v, const float* mean, const float* stdv, float rescale,
                              unsigned char* ws8, unsigned* mm, float* out, int minmax_normalize, hipStream_t s);
 
+// batched form: `descs_host` = n internal descriptors (preprocess.hip PreDesc, built by api.hip), copied to the head of `ws`
+size_t preprocess_batch_desc_bytes(int n);
+hipError_t launch_preprocess_batch(const void* descs_host, int n, int max_ph, int S, const float* mean, const float* stdv, float rescale,
+                                   unsigned char* ws, float* out, int minmax_normalize, hipStream_t s);
+
 // strided gather of valid tokens: src [B][Npad][D] -> dst [B][N][D]
 hipError_t launch_copy_tokens(const float* src, float* dst, int B, int n_valid, int n_pad, int D, hipStream_t s);
 

@@ -478,7 +478,7 @@ class RadZeroModel:
         _lib.check(self._lib.rz_profile_enable(self._h, code), "rz_profile_enable")
 
     def profile_read(self):
-        ms = (ctypes.c_float * 4)()
-        n = (ctypes.c_int64 * 4)()
+        ms = (ctypes.c_float * len(_lib.PROF_FAMILIES))()
+        n = (ctypes.c_int64 * len(_lib.PROF_FAMILIES))()
         _lib.check(self._lib.rz_profile_read(self._h, ms, n), "rz_profile_read")
         return {f: {"ms": float(ms[i]), "launches": int(n[i])} for i, f in enumerate(_lib.PROF_FAMILIES)}

@@ -30,3 +30,24 @@ def synthetic_prompts(n_prompts: int, min_len: int = 6, max_len: int = 10, seed:
         ids[i, n - 1] = EOS
         mask[i, :n] = 1
     return ids, mask
+
+
+def synthetic_cxr_raw(dtype: str, shape, seed: int) -> np.ndarray:
+    """A raw chest-X-ray-like image as a detector / DICOM delivers it (before any preprocessing): smooth anatomy-like field + noise,
+    8-bit or 12-bit-in-uint16.  Inputs of the preprocessing fixture (tools/make_goldens_preprocess.py) and of `bench.py --raw-images`."""
+    rng = np.random.default_rng(seed)
+    h, w = shape
+    yy, xx = np.mgrid[0:h, 0:w].astype(np.float64)
+    field = 0.5 + 0.3 * np.sin(xx / w * 5.1 + 0.3) * np.cos(yy / h * 3.7) + 0.15 * np.exp(-(((xx - 0.6 * w) / (0.2 * w)) ** 2 + ((yy - 0.4 * h) / (0.3 * h)) ** 2))
+    field += rng.standard_normal((h, w)) * 0.04
+    top = 255 if dtype == "uint8" else 4095
+    return np.clip(field * top, 3 if dtype == "uint8" else 40, top - (5 if dtype == "uint8" else 77)).astype(dtype)
+
+
+def minmax_to_u8(raw: np.ndarray) -> np.ndarray:
+    """cv2.normalize(raw, None, 0, 255, NORM_MINMAX, CV_8U) restated (cv2 is not installed anywhere this runs: UNPINNED):
+    saturate(round_half_even(v * 255 / (max - min) - min * 255 / (max - min))), all channels together, scale 0 for a constant image."""
+    a = raw.astype(np.float64)
+    lo, hi = a.min(), a.max()
+    scale = 255.0 / (hi - lo) if hi - lo > 2.220446049250313e-16 else 0.0
+    return np.clip(np.rint(a * scale - lo * scale), 0, 255).astype(np.uint8)

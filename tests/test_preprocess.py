@@ -72,6 +72,7 @@ def test_device_preprocess_matches_reference_pipeline(dtype, shape, size):
         pre = DevicePreprocessor(size, minmax_normalize=True)
     t = torch.from_numpy(raw.astype(np.int32) if dtype == np.uint16 else raw)
     out = pre(t).cpu().numpy()
+    assert np.array_equal(out, pre.single_image_entry(t).cpu().numpy())          # batched kernels == the one-image entry point, bit for bit
     ref = _reference_pipeline(raw, size, True)
     assert out.shape == ref.shape == (1, 3, size, size)
     assert np.abs(out - ref).max() <= 2e-6          # identical bytes; float rescale/normalise rounding only
@@ -86,3 +87,99 @@ def test_device_preprocess_constant_image_and_errors():
     assert np.abs(out - ref).max() <= 2e-6            # constant image -> all zeros after min-max (scale 0)
     with pytest.raises(ValueError):
         pre(torch.zeros(10, 10, 2, dtype=torch.uint8))
+
+
+# ---- the REAL image processors (tests/golden/preprocess_blip.npz, tools/make_goldens_preprocess.py): transformers' BlipImageProcessor
+# and the reference's own AspectRatioBlipImageProcessor, run in the build container on 8-bit images (cv2's min-max step itself is not
+# installed anywhere: unpinned, restated in radzero_amd.synthetic.minmax_to_u8) --------------------------------------------------------
+import os
+import zlib
+
+from conftest import GOLDEN_DIR
+from radzero_amd.synthetic import minmax_to_u8, synthetic_cxr_raw
+
+
+def _pre_cases():
+    z = np.load(os.path.join(GOLDEN_DIR, "preprocess_blip.npz"), allow_pickle=False)
+    stride = int(z["sample_stride"])
+    for name in [str(n) for n in z["cases"]]:
+        code, h, w, seed, size, aspect = (int(v) for v in z[name + "|meta"])
+        yield name, ("uint8", "uint16")[code], (h, w), seed, size, bool(aspect), z[name + "|moments"], z[name + "|samples"], int(z[name + "|u8_crc"][0]), z[name + "|mean_std"], stride
+
+
+def _pad_square(a8):
+    h, w = a8.shape
+    side = max(h, w)
+    out = np.zeros((side, side), np.uint8)
+    out[(side - h) // 2:(side - h) // 2 + h, (side - w) // 2:(side - w) // 2 + w] = a8
+    return out
+
+
+@pytest.mark.parametrize("case", list(_pre_cases()), ids=lambda c: c[0])
+def test_host_tables_and_padding_reproduce_the_real_processors(case):
+    """CPU: min-max -> [pad_to_square] -> the host's Pillow tables applied in numpy give EXACTLY the bytes the real processor resized to
+    (CRC32 of the uint8 image recovered from its fp32 output): pins resample_tables, the pass order, and the padding arithmetic."""
+    name, dtype, shape, seed, size, aspect, _, _, crc, _, _ = case
+    a8 = minmax_to_u8(synthetic_cxr_raw(dtype, shape, seed))
+    if aspect:
+        a8 = _pad_square(a8)
+    got = _resample_numpy(a8, size, size)
+    rgb = np.repeat(got[None], 3, axis=0)                       # grey -> RGB replication, channel-first like pixel_values
+    assert zlib.crc32(rgb.tobytes()) == crc, name
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("aspect", [False, True])
+def test_device_batch_matches_the_real_processors(aspect):
+    """GPU: ONE batched call per processor kind over all of its fixture images (different sizes and dtypes in the same batch, 8-bit and
+    16-bit; for the AspectRatio processor: tall, wide and odd-difference paddings) against the real processors' outputs: identical
+    bytes after the resize, float rescale / normalise within 2e-6, float64 moments."""
+    from radzero_amd.preprocess import DevicePreprocessor
+    cases = [c for c in _pre_cases() if c[5] == aspect]
+    for size in sorted({c[4] for c in cases}):
+        group = [c for c in cases if c[4] == size]
+        pre = DevicePreprocessor(size, keep_aspect_ratio=aspect)
+        raws = [synthetic_cxr_raw(c[1], c[2], c[3]) for c in group]
+        out = pre([torch.from_numpy(r.astype(np.int32) if r.dtype == np.uint16 else r) for r in raws]).cpu().numpy()
+        assert out.shape == (len(group), 3, size, size)
+        for o, c in zip(out, group):
+            name, _, _, _, _, _, moments, samples, crc, mean_std, stride = c
+            assert np.abs(o.reshape(3, -1)[:, ::stride] - samples).max() <= 2e-6, name
+            m = np.stack([o.astype(np.float64).sum((1, 2)), (o.astype(np.float64) ** 2).sum((1, 2))], 1)
+            assert np.abs(m - moments).max() <= 2e-6 * size * size * 4, name
+            u8 = np.rint((o.astype(np.float64) * mean_std[1][:, None, None] + mean_std[0][:, None, None]) * 255.0).astype(np.uint8)
+            assert zlib.crc32(u8.tobytes()) == crc, name
+
+
+@pytest.mark.gpu
+def test_device_batch_feeds_the_model_and_rejects_bad_batches(cfg, state_dict):
+    """The batch's output tensor is directly rz_vision_forward's input; ragged batches keep per-image independence (an image alone ==
+    the same image inside a batch, bit for bit); bad descriptors are refused by the C-ABI, not by a fault."""
+    import ctypes
+    from radzero_amd import _lib
+    from radzero_amd.config import RadZeroConfig
+    from radzero_amd.modeling import RadZeroModel
+    from radzero_amd.preprocess import DevicePreprocessor
+    from radzero_amd.weights import make_state_dict
+    pre = DevicePreprocessor(224)
+    raws = [synthetic_cxr_raw("uint16", (300 + 17 * i, 280 - 9 * i), 100 + i) for i in range(5)]
+    ts = [torch.from_numpy(r.astype(np.int32)) for r in raws]
+    batch = pre(ts)
+    for i in (0, 3):
+        assert torch.equal(pre(ts[i])[0], batch[i])
+    small = RadZeroConfig(vit_layers=1, align_layers=1, text_layers=1)
+    m = RadZeroModel.from_state_dict(make_state_dict(small, 3), small, torch_dtype=torch.float32, device="cuda:0").eval()
+    try:
+        toks = m.forward_vision_model(batch)["vision_tokens"]
+        assert toks.shape == (5, 257, 768) and torch.isfinite(toks).all()
+    finally:
+        m.close()
+    with pytest.raises(ValueError):
+        pre([])
+    with pytest.raises(ValueError):
+        pre([torch.zeros(10, 10, 2, dtype=torch.uint8)])
+    lib = _lib.load()
+    d = (_lib.RzImageDesc * 1)()
+    assert lib.rz_preprocess_batch_workspace(d, 1, 224) == 0                      # null image / zero shape
+    mean = (ctypes.c_float * 3)(0, 0, 0)
+    assert lib.rz_preprocess_batch(d, 1, 224, mean, mean, 1.0, 1, ctypes.c_void_p(batch.data_ptr()), 16, ctypes.c_void_p(batch.data_ptr()), None) == 10001
