@@ -185,6 +185,28 @@ size_t rz_flash_attention_split_workspace(int batch, int heads, int n_pad);
 int rz_flash_attention_f32_split(const float* q_dev, const float* k_dev, const float* v_t_dev, float* ctx_dev, void* workspace_dev,
                                  int batch, int heads, int n_valid, int n_pad, void* stream);
 
+/* ---- the text side and the patch embedding, kernel by kernel (the model reaches them through rz_text_forward /
+ *      rz_vision_forward) ---- */
+/* MPNetEmbeddings (TF:mpnet/modeling_mpnet.py:58-95; position ids skip pads, :873-881): word_emb[ids] + pos_emb[pos_ids] -> LayerNorm.
+ * input_ids_dev int64 (n_prompts, len); word_emb_dev fp32 (vocab, 768); pos_emb_dev fp32 (max_pos, 768);
+ * h_out_dev fp32 (n_prompts*len, 768); xn_out_dev the same rows in `dtype` (the first projection's operand). */
+int rz_text_embed_ln(int dtype, const int64_t* input_ids_dev, const float* word_emb_dev, const float* pos_emb_dev, const float* gamma_dev,
+                     const float* beta_dev, float eps, float* h_out_dev, void* xn_out_dev, int n_prompts, int len, int vocab_size,
+                     int max_position_embeddings, int pad_token_id, void* stream);
+/* MPNet self-attention (TF:mpnet/modeling_mpnet.py:115-200): qkv_dev `dtype` (n_prompts*len, 3*heads*64) = q | k | v with q already
+ * scaled by 1/sqrt(64); scores = q k^T + rel_bias[h][i][j] + (mask[t][j] ? 0 : -FLT_MAX); ctx_out_dev `dtype` (n_prompts*len, heads*64). */
+int rz_text_attention(int dtype, const void* qkv_dev, const float* rel_bias_dev, const int64_t* attention_mask_dev, void* ctx_out_dev,
+                      int n_prompts, int len, int heads, void* stream);
+/* masked mean pool (modeling.py:148-156): out[t] = sum_i h[t][i] mask[t][i] / max(sum_i mask[t][i], 1e-9); h_dev fp32 (n_prompts, len, dim) */
+int rz_masked_meanpool(const float* h_dev, const int64_t* attention_mask_dev, float* out_dev, int n_prompts, int len, int dim, void* stream);
+/* Dinov2PatchEmbeddings + cls token + position embeddings (TF:dinov2/modeling_dinov2.py:97-149) as im2col + GEMM with the table epilogue:
+ * pixel_values_dev fp32 (batch, channels, height, width); weight_dev `dtype` (768, k_pad) = the conv kernel flattened (c, ky, kx) and zero
+ * padded to k_pad = round_up(channels*patch*patch, 64); table_dev fp32 (n_pad, 768) = row 0: cls + pos[0], rows 1..grid_h*grid_w: conv
+ * bias + pos[t], 0 on pad rows; n_pad a multiple of 128 >= 1 + grid_h*grid_w; im2col_ws_dev: batch*n_pad*k_pad elements of `dtype`;
+ * out_dev fp32 (batch*n_pad, 768) = the residual stream the first block reads. */
+int rz_patch_embed(int dtype, const float* pixel_values_dev, int batch, int channels, int height, int width, int patch, const void* weight_dev,
+                   int k_pad, const float* table_dev, int n_pad, void* im2col_ws_dev, float* out_dev, void* stream);
+
 /* Tuning / A-B switches.  rz_set_option sets the PROCESS-WIDE value (what the measurement tools flip); rz_set_model_option sets one
  * handle's own value, which then overrides the process-wide one for that handle only (INT32_MIN = follow the process-wide value again):
  * two handles of one process can differ.  Defaults are the measured-fastest choices.

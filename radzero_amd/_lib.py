@@ -137,6 +137,10 @@ SYMBOLS = {
     "rz_flash_attention": (_I, [_I, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "rz_flash_attention_split_workspace": (ctypes.c_size_t, [_I, _I, _I]),
     "rz_flash_attention_f32_split": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "rz_text_embed_ln": (_I, [_I, _P, _P, _P, _P, _P, _F, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "rz_text_attention": (_I, [_I, _P, _P, _P, _P, _I, _I, _I, _P]),
+    "rz_masked_meanpool": (_I, [_P, _P, _P, _I, _I, _I, _P]),
+    "rz_patch_embed": (_I, [_I, _P, _I, _I, _I, _I, _I, _P, _I, _P, _I, _P, _P, _P]),
     "rz_set_option": (_I, [ctypes.c_char_p, _I]),
     "rz_set_model_option": (_I, [_P, ctypes.c_char_p, _I]),
     "rz_get_model_option": (_I, [_P, ctypes.c_char_p, ctypes.POINTER(_I)]),

@@ -1237,6 +1237,43 @@ int rz_flash_attention_f32_split(const float* q, const float* k, const float* vt
     return 0;
 }
 
+int rz_text_embed_ln(int dtype, const int64_t* ids, const float* word_emb, const float* pos_emb, const float* gamma, const float* beta, float eps,
+                     float* h_out, void* xn_out, int T, int L, int vocab, int max_pos, int pad_id, void* stream) {
+    if (!ids || !word_emb || !pos_emb || !gamma || !beta || !h_out || !xn_out) return fail(RZ_ERR_INVALID, "rz_text_embed_ln: null argument");
+    if (dtype < 0 || dtype > 2 || T <= 0 || L <= 0 || vocab <= 0 || max_pos <= 0) return fail(RZ_ERR_INVALID, "rz_text_embed_ln: bad shape / dtype");
+    RZ_HIP(launch_text_embed(dtype, ids, word_emb, pos_emb, gamma, beta, eps, h_out, xn_out, T, L, 768, vocab, max_pos, pad_id, (hipStream_t)stream));
+    return 0;
+}
+
+int rz_text_attention(int dtype, const void* qkv, const float* rel_bias, const int64_t* mask, void* ctx, int T, int L, int H, void* stream) {
+    if (!qkv || !rel_bias || !mask || !ctx) return fail(RZ_ERR_INVALID, "rz_text_attention: null argument");
+    if (dtype < 0 || dtype > 2 || T <= 0 || L <= 0 || H <= 0) return fail(RZ_ERR_INVALID, "rz_text_attention: bad shape / dtype");
+    RZ_HIP(launch_text_attn(dtype, qkv, rel_bias, mask, ctx, T, L, H, (hipStream_t)stream));
+    return 0;
+}
+
+int rz_masked_meanpool(const float* h, const int64_t* mask, float* out, int T, int L, int D, void* stream) {
+    if (!h || !mask || !out || T <= 0 || L <= 0 || D <= 0) return fail(RZ_ERR_INVALID, "rz_masked_meanpool: bad argument");
+    RZ_HIP(launch_masked_meanpool(h, mask, out, T, L, D, (hipStream_t)stream));
+    return 0;
+}
+
+int rz_patch_embed(int dtype, const float* px, int B, int C, int Himg, int Wimg, int P, const void* weight, int k_pad, const float* table,
+                   int n_pad, void* ws, float* out, void* stream) {
+    if (!px || !weight || !table || !ws || !out) return fail(RZ_ERR_INVALID, "rz_patch_embed: null argument");
+    if (dtype < 0 || dtype > 2 || B <= 0 || C <= 0 || P <= 0) return fail(RZ_ERR_INVALID, "rz_patch_embed: bad shape / dtype");
+    const int gh = Himg / P, gw = Wimg / P;
+    if (gh <= 0 || gw <= 0 || n_pad % 128 || n_pad < 1 + gh * gw || k_pad % 64 || k_pad < C * P * P)
+        return fail(RZ_ERR_INVALID, "rz_patch_embed: n_pad must be a multiple of 128 >= 1 + grid, k_pad a multiple of 64 >= channels*patch^2");
+    hipStream_t s = (hipStream_t)stream;
+    RZ_HIP(launch_im2col(dtype, px, ws, B, C, Himg, Wimg, P, gh, gw, n_pad, k_pad, s));
+    GemmArgs g;
+    g.A = ws; g.lda = k_pad; g.W = weight; g.ldw = k_pad; g.M = B * n_pad; g.N = 768; g.K = k_pad; g.bias = nullptr; g.out = out; g.ldo = 768;
+    g.scale = table; g.resid = nullptr; g.ldr = 0; g.rows_per_image = n_pad; g.heads_total = 0; g.variant = g_opt.gemm_variant;
+    RZ_HIP(launch_gemm(dtype, EPI_PATCH, g, s));
+    return 0;
+}
+
 int rz_debug_buffer(const char* what, void* dev_ptr) {
     if (!what) return fail(RZ_ERR_INVALID, "rz_debug_buffer: null name");
 #ifdef RZ_EXPERIMENTS

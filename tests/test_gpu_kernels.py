@@ -387,3 +387,106 @@ def test_gemm_v10_whole_model_bit_identical_to_v8(dt):
         finally:
             m.close()
     assert torch.isfinite(outs[10]).all() and torch.equal(outs[8], outs[10])
+
+
+# ---- the text side and the patch embedding, kernel by kernel (SURVEY.md §8(b) list) ------------------------------
+@pytest.mark.parametrize("dt", ["f32", "bf16", "f16"])
+@pytest.mark.parametrize("T,L", [(3, 9), (1, 1), (5, 130)])
+def test_text_embed_ln_vs_pytorch(lib, dt, T, L):
+    """MPNetEmbeddings (TF:mpnet/modeling_mpnet.py:58-95): pads keep position id `pad`, real tokens count from pad + 1; then LayerNorm."""
+    code, tdt = DT[dt]
+    V, MP, PAD, D = 997, 514, 1, 768
+    g = torch.Generator().manual_seed(T * 131 + L)
+    ids = torch.randint(4, V, (T, L), generator=g)
+    lens = torch.randint(1, L + 1, (T,), generator=g)
+    lens[0] = L
+    for t in range(T):
+        ids[t, lens[t]:] = PAD
+    if L > 3:
+        ids[-1, 1] = PAD                                      # a pad in the middle: position ids skip it (cumsum of the non-pad mask)
+    word, pos = torch.randn(V, D, generator=g), torch.randn(MP, D, generator=g)
+    gamma, beta = torch.rand(D, generator=g) + 0.5, torch.randn(D, generator=g) * 0.1
+    m = (ids != PAD).long()
+    pos_ids = torch.cumsum(m, 1) * m + PAD
+    ref = torch.nn.functional.layer_norm(word[ids] + pos[pos_ids], (D,), gamma, beta, 1e-5).reshape(T * L, D)
+    h = torch.empty(T * L, D, device="cuda")
+    xn = torch.empty(T * L, D, device="cuda", dtype=tdt)
+    d = [t.cuda() for t in (ids, word, pos, gamma, beta)]          # named: a temporary's memory would be recycled before the launch
+    check(lib, lib.rz_text_embed_ln(code, P(d[0]), P(d[1]), P(d[2]), P(d[3]), P(d[4]), 1e-5, P(h), P(xn), T, L, V, MP, PAD, stream()))
+    torch.cuda.synchronize()
+    assert (h.cpu() - ref).abs().max().item() <= 2e-5
+    assert (xn.float().cpu() - ref).abs().max().item() <= {"f32": 2e-5, "bf16": 3e-2, "f16": 4e-3}[dt]
+
+
+@pytest.mark.parametrize("dt", ["f32", "bf16", "f16"])
+@pytest.mark.parametrize("T,L", [(4, 12), (2, 1), (3, 77)])
+def test_text_attention_vs_pytorch(lib, dt, T, L):
+    """MPNet self-attention with the additive relative-position bias and the key-padding mask as HF applies it (additive -FLT_MAX: a
+    fully masked row becomes uniform, not NaN), against softmax in fp32 on the same (rounded) operands."""
+    code, tdt = DT[dt]
+    H, D = 12, 768
+    g = torch.Generator().manual_seed(T * 17 + L)
+    qkv = (torch.randn(T * L, 3 * D, generator=g) * 0.6).to(tdt)
+    bias = torch.randn(H, L, L, generator=g) * 0.5
+    mask = torch.ones(T, L, dtype=torch.int64)
+    for t in range(T):
+        mask[t, torch.randint(1, L + 1, (1,), generator=g).item():] = 0
+    if T > 1:
+        mask[1] = 0                                           # a prompt with every key masked
+    ctx = torch.empty(T * L, D, device="cuda", dtype=tdt)
+    d = [t.cuda() for t in (qkv, bias, mask)]
+    check(lib, lib.rz_text_attention(code, P(d[0]), P(d[1]), P(d[2]), P(ctx), T, L, H, stream()))
+    torch.cuda.synchronize()
+    x = qkv.float().view(T, L, 3, H, 64)
+    q, k, v = (x[:, :, i].permute(0, 2, 1, 3) for i in range(3))                    # (T, H, L, 64); q is pre-scaled by contract
+    s = q @ k.transpose(-1, -2) + bias[None] + (1.0 - mask[:, None, None, :].float()) * torch.finfo(torch.float32).min
+    ref = (torch.softmax(s, -1) @ v).permute(0, 2, 1, 3).reshape(T * L, D)
+    assert torch.isfinite(ctx).all()
+    assert (ctx.float().cpu() - ref).abs().max().item() <= {"f32": 2e-5, "bf16": 2e-2, "f16": 3e-3}[dt]
+
+
+@pytest.mark.parametrize("T,L", [(5, 11), (1, 1), (3, 130)])
+def test_masked_meanpool_vs_pytorch(lib, T, L):
+    D = 768
+    g = torch.Generator().manual_seed(T + L)
+    h = torch.randn(T, L, D, generator=g)
+    mask = (torch.rand(T, L, generator=g) > 0.3).long()
+    mask[0] = 0                                               # modeling.py:154: clamp(min=1e-9) -> zeros, not NaN
+    out = torch.empty(T, D, device="cuda")
+    d = [h.cuda(), mask.cuda()]
+    check(lib, lib.rz_masked_meanpool(P(d[0]), P(d[1]), P(out), T, L, D, stream()))
+    torch.cuda.synchronize()
+    ref = (h * mask[..., None]).sum(1) / mask.sum(1, keepdim=True).clamp(min=1e-9)
+    assert (out.cpu() - ref).abs().max().item() <= 1e-5 and float(out[0].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("dt", ["f32", "bf16", "f16"])
+@pytest.mark.parametrize("B,Himg,Wimg", [(2, 224, 224), (1, 266, 154), (3, 70, 98)])
+def test_patch_embed_vs_pytorch_conv(lib, dt, B, Himg, Wimg):
+    """Dinov2PatchEmbeddings + cls + position table as im2col + GEMM with the table epilogue, against F.conv2d (stride = kernel = 14)
+    in fp32 on the same rounded operands; trailing pixels that do not fill a patch are dropped exactly as the conv drops them."""
+    code, tdt = DT[dt]
+    C, Pp, D = 3, 14, 768
+    gh, gw = Himg // Pp, Wimg // Pp
+    nv, npad, kp, kpad = 1 + gh * gw, (1 + gh * gw + 127) // 128 * 128, C * Pp * Pp, 640
+    g = torch.Generator().manual_seed(Himg + Wimg + B)
+    px = torch.randn(B, C, Himg, Wimg, generator=g)
+    w = torch.randn(D, C, Pp, Pp, generator=g) / math.sqrt(kp)
+    cb, cls, pos = torch.randn(D, generator=g) * 0.1, torch.randn(D, generator=g), torch.randn(nv, D, generator=g) * 0.2
+    table = torch.zeros(npad, D)
+    table[0] = cls + pos[0]
+    table[1:nv] = pos[1:] + cb
+    wp = torch.zeros(D, kpad)
+    wp[:, :kp] = w.reshape(D, kp)
+    ws = torch.empty(B * npad * kpad, device="cuda", dtype=tdt)
+    out = torch.full((B * npad, D), float("nan"), device="cuda")
+    d = [px.cuda(), wp.to(tdt).cuda(), table.cuda()]
+    check(lib, lib.rz_patch_embed(code, P(d[0]), B, C, Himg, Wimg, Pp, P(d[1]), kpad, P(d[2]), npad, P(ws), P(out), stream()))
+    torch.cuda.synchronize()
+    conv = torch.nn.functional.conv2d(px.to(tdt).float(), w.to(tdt).float(), None, stride=Pp).flatten(2).transpose(1, 2)     # (B, gh*gw, D)
+    ref = torch.cat([cls.expand(B, 1, D) + pos[0], conv + cb + pos[1:]], 1)
+    got = out.view(B, npad, D).cpu()
+    assert torch.isfinite(got).all()
+    assert (got[:, :nv] - ref).abs().max().item() <= {"f32": 2e-4, "bf16": 2e-3, "f16": 2e-3}[dt]
+    assert float(got[:, nv:].abs().max()) == 0.0 if npad > nv else True          # pad rows: zero rows of the table, zero im2col rows
+    assert lib.rz_patch_embed(code, P(d[0]), B, C, Himg, Wimg, Pp, P(d[1]), kpad, P(d[2]), npad - 1, P(ws), P(out), stream()) == 10001
