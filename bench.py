@@ -35,7 +35,7 @@ DTYPES = {"bf16": torch.bfloat16, "f16": torch.float16, "f32": torch.float32}
 def pmc_traffic(kernel, batch, side, dtype):
     """HBM bytes per launch of `kernel` from the committed PMC passes (a separate rocprofv3 --pmc run cannot happen inside
     this process); null unless the passes were taken on exactly this workload."""
-    for rnd in ("r02", "r01"):
+    for rnd in ("r03", "r02", "r01"):
         try:
             rec = json.load(open(os.path.join(ROOT, "profiles", rnd, "hbm_traffic_pmc.json")))
             c = rec["config"]
@@ -333,12 +333,12 @@ def main():
     ap.add_argument("--all-kernel-events", action="store_true", help="A/B: record HIP events for every kernel family inside the timed region (default: "
                     "the dominant kernel's family only; the other families are timed over two extra, un-timed steps)")
     ap.add_argument("--no-other-configs", action="store_true", help="skip the short runs of BASELINE configs[3], configs[4] per-GPU shape and the fp32 mode")
-    ap.add_argument("--attn-variant", type=int, default=None, help="A/B switch (rz_set_option): 1 = default (4 waves x 32 rows; bf16 without the running maximum), 417 = with it, 16 = VALU row sums, 8 = 8 waves, 64 = 64 query rows per wave")
+    ap.add_argument("--attn-variant", type=int, default=None, help="A/B switch (rz_set_option): 1 = default (4 waves x 32 rows; bf16 without the running maximum), 417 = with it")
     ap.add_argument("--ln-fused", type=int, default=None, help="A/B switch: 1 fused LayerNorm (default, 16-bit modes), 0 stand-alone LayerNorm kernels")
     ap.add_argument("--vision-chunk", type=int, default=None, help="images per internal pass of the vision encoder (0 = whole batch)")
     ap.add_argument("--mlp-chunk", type=int, default=None, help="images per fc1->fc2 pass (-1 = auto, 0 = whole batch)")
     ap.add_argument("--vision-streams", type=int, default=None, help="2 = split the batch over two internal HIP streams")
-    ap.add_argument("--gemm-variant", type=int, default=None, help="A/B switch: 0 auto, 1..4 force a GEMM tile variant")
+    ap.add_argument("--gemm-variant", type=int, default=None, help="A/B switch: 0 auto, 1 / 3 / 7 / 8 / 10 force that GEMM kernel (include/radzero_hip.h)")
     args = ap.parse_args()
 
     # HSA reads its environment at hsa_init, i.e. at the first torch.cuda call below: set these before anything touches the GPU

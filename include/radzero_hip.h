@@ -212,6 +212,7 @@ int rz_patch_embed(int dtype, const float* pixel_values_dev, int batch, int chan
  * two handles of one process can differ.  Defaults are the measured-fastest choices.
  *   "gemm_variant"     0 auto | 1 128x128 two-stage | 3 256x256 two-stage | 7 256x256 staggered 8-phase (16-bit, gemm7.hip)
  *                      | 8 the same K loop as a persistent kernel, one workgroup per CU (16-bit, gemm8.hip; default for big shapes)
+ *                      | 10 persistent, four waves x 128x128, accumulators in AGPRs, generated inline-asm K loop (gemm10.hip; bit-identical, 7 % slower)
  *   "gemm_v1_only"     (process-wide only) 1 = same as gemm_variant 1
  *   "attn_variant"     0 default (16x16x32 MFMA, 4 waves x 32 query rows, row sums on the matrix pipe; bf16 without the running
  *                      maximum in the hot loop) | 417 the same with it (what f16 always runs)

@@ -725,14 +725,18 @@ hipError_t launch_flash_attn_split_planes(const void* q_hi, const void* k_hi, co
 hipError_t launch_flash_attn(int dtype, const void* q, const void* k, const void* vT, void* ctx,
                              int64_t qk_batch_stride, int B, int H, int n_valid, int n_pad, int waves, hipStream_t s) {
     if (n_pad % FA_QROWS || n_valid <= 0 || n_valid > n_pad || B <= 0 || H <= 0) return hipErrorInvalidValue;
-    // `waves` selects the kernel shape (option attn_variant; every shape passes the same tests):
-    //   4   default: 4 waves x 32 query rows, row sums on the matrix pipe; bf16 without the running maximum (NOMAX)
-    //   417 the default shape with the running maximum tracked in every tile (what f16 always runs; the bf16 second pass)
-    //   16  the default shape with VALU row sums (fp32 operands always: the ones-row sums cost 8 exact-f32 MFMAs per tile and push
-    //       the kernel to one wave per SIMD — 119-129 against 110 TFLOP/s)
-    //   8   8 waves x 32 rows (256-row query blocks), 64: 4 waves x 64 rows — 16-bit operands, n_pad % 256 == 0
+    // `waves` = option attn_variant:  4 (default) 4 waves x 32 query rows, row sums on the matrix pipe, bf16 without the running maximum
+    // in the hot loop (NOMAX); 417 the same shape with the running maximum tracked in every tile (what f16 always runs; bf16's second
+    // pass).  fp32 operands: VALU row sums (the ones-row sums would cost 8 exact-f32 MFMAs per tile).
+    // Measured and retired (rounds 1-2; compiled only with -DRZ_EXPERIMENTS): 16 = VALU row sums for 16-bit operands,
+    // 8 = 8 waves x 32 rows, 64 = 4 waves x 64 rows.
     int qt = 2;
+#ifdef RZ_EXPERIMENTS
     const bool ls = (waves == 4 || waves == 417) && dtype != DT_F32;
+#else
+    if (waves != 4 && waves != 417) waves = 4;
+    const bool ls = dtype != DT_F32;
+#endif
     const bool track = (waves == 417) || dtype == DT_F16;
     if (waves == 417 || waves == 16) waves = 4;
     if (waves == 64) { waves = 4; qt = 4; }
@@ -743,11 +747,15 @@ hipError_t launch_flash_attn(int dtype, const void* q, const void* k, const void
     dim3 grid(((pairs * nq + 7) / 8) * 8), block(64 * waves);
 #define RZ_FA(TT, NWV, QTV, LSV, NOMAXV) hipLaunchKernelGGL((flash_attn_kernel<TT, NWV, QTV, LSV, NOMAXV>), grid, block, 0, s, (const TT*)q, \
                                                             (const TT*)k, (const TT*)vT, (TT*)ctx, qk_batch_stride, B, H, n_valid, n_pad)
+#ifdef RZ_EXPERIMENTS
 #define RZ_FA16(TT)                                                   \
     if (ls) RZ_FA(TT, 4, 2, true, false);                             \
     else if (waves == 8) RZ_FA(TT, 8, 2, false, false);               \
     else if (qt == 4) RZ_FA(TT, 4, 4, false, false);                  \
     else RZ_FA(TT, 4, 2, false, false)
+#else
+#define RZ_FA16(TT) RZ_FA(TT, 4, 2, true, false)
+#endif
     switch (dtype) {
         case DT_F32: RZ_FA(float, 4, 2, false, false); break;
         case DT_BF16: if (ls && !track) RZ_FA(bf16_t, 4, 2, true, true); else { RZ_FA16(bf16_t); } break;

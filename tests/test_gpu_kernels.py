@@ -84,11 +84,11 @@ def _attn_ref(q, k, v):
     return torch.einsum("bhqk,bhkd->bhqd", torch.softmax(s, -1), v)
 
 
-@pytest.fixture(params=[1, 417, 16, 8, 64],
-                ids=["mfma16", "mfma16trackedMax", "mfma16valuRowSums", "mfma16x8waves", "mfma16x64rows"])
+@pytest.fixture(params=[1, 417], ids=["mfma16", "mfma16trackedMax"])
 def attn_variant(request, lib):
     """Every selectable shape of the flash-attention kernel must pass every attention test (1 = the default: for bf16 no running
-    maximum in the hot loop + overflow check; 417 = the same shape with the running maximum tracked in every tile)."""
+    maximum in the hot loop + overflow check; 417 = the same shape with the running maximum tracked in every tile).  The retired
+    shapes of rounds 1-2 (VALU row sums, 8 waves, 64 rows per wave) live behind -DRZ_EXPERIMENTS and are no longer in the library."""
     lib.rz_set_option(b"attn_variant", request.param)
     yield request.param
     lib.rz_set_option(b"attn_variant", 0)

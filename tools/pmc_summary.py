@@ -33,7 +33,7 @@ def counters(sub):
 
 
 def short(name):
-    for key in ("flash_attn_kernel", "gemm_kernel_v8", "gemm_kernel_v7", "gemm_kernel_v3", "gemm_kernel", "layernorm_kernel", "ln_prepare_kernel",
+    for key in ("flash_attn_kernel", "gemm_kernel_v10", "gemm_kernel_v8", "gemm_kernel_v7", "gemm_kernel_v3", "gemm_kernel", "layernorm_kernel", "ln_prepare_kernel",
                 "ln_finalize_kernel", "vlcabs_scores_kernel", "vlcabs_partial_kernel", "vlcabs_finalize_kernel", "vlcabs_kernel", "im2col_kernel"):
         if key in name:
             return key
@@ -73,6 +73,52 @@ for key, v in by.items():
     fm, wm = sum(f) / len(f), sum(w) / len(w)
     traffic["kernels"][key] = {"launches_sampled": len(f), "FETCH_SIZE_KiB_raw": round(fm, 1), "WRITE_SIZE_KiB_raw": round(wm, 1),
                                "hbm_bytes_per_launch": int((2 * fm + wm) * 1024)}
+
+# ---- per template instantiation of the persistent GEMM: FETCH / WRITE per epilogue, next to the algorithmic bytes.
+# EPI_RESID_SCALE_LN serves two shapes (out-proj K = 768, fc2 K = 3072): its launches are split at the midpoint of their fetch sizes.
+import re
+EPI_NAMES = {0: "EPI_STORE", 1: "EPI_GELU", 2: "EPI_HEADS", 3: "EPI_VT", 4: "EPI_RESID_SCALE", 5: "EPI_RESID_ADD", 6: "EPI_PATCH", 7: "EPI_STORE_F32",
+             8: "EPI_QKV", 9: "EPI_RESID_SCALE_LN", 10: "EPI_QKV_LN", 11: "EPI_GELU_LN"}
+M, D, F, KP, NP = 32 * 5376, 768, 3072, 640, 5376          # B = 32 images x 5376 padded token rows; bf16 operands (2 B), fp32 residual (4 B)
+ALGO = {   # (read bytes, written bytes) per launch, formulas in DESIGN.md §4
+    ("EPI_PATCH", None): (M * KP * 2 + NP * D * 4 + D * KP * 2, M * D * 4),
+    ("EPI_QKV_LN", None): (M * D * 2 + M * 8 + 3 * D * D * 2, M * 3 * D * 2),
+    ("EPI_GELU_LN", None): (M * D * 2 + M * 8 + F * D * 2, M * F * 2),
+    ("EPI_RESID_SCALE_LN", "small"): (M * D * 2 + M * D * 4 + M * 4 + D * D * 2, M * D * 4 + M * D * 2 + M * 96),        # out-proj
+    ("EPI_RESID_SCALE_LN", "large"): (M * F * 2 + M * D * 4 + M * 4 + D * F * 2, M * D * 4 + M * D * 2 + M * 96),        # fc2 feeding a fused LayerNorm
+    ("EPI_RESID_SCALE", None): (M * F * 2 + M * D * 4 + D * F * 2, M * D * 4),                                            # fc2 of the last ViT / last align block
+}
+
+
+def epi_of(name):
+    m = re.search(r"gemm_kernel_v(?:8|10)<[^,>]+,\s*(?:\(rz::Epilogue\))?(\d+)", name) or re.search(r"gemm_kernel_v(?:8|10)I[^L]*Li(\d+)E", name)
+    return EPI_NAMES.get(int(m.group(1))) if m else None
+
+
+per = {}
+for k in set(fetch) | set(write):
+    e = epi_of(k)
+    if not e or ("bf16" not in k and "DF16b" not in k):
+        continue
+    f, w = fetch.get(k, {}).get("FETCH_SIZE", []), write.get(k, {}).get("WRITE_SIZE", [])
+    n = min(len(f), len(w))                     # same command, same dispatch order in both passes
+    if not n:
+        continue
+    rows = [(2 * f[i] * 1024, w[i] * 1024) for i in range(n)]
+    groups = {None: rows}
+    if e == "EPI_RESID_SCALE_LN":
+        mid = (min(r[0] for r in rows) + max(r[0] for r in rows)) / 2
+        groups = {"small": [r for r in rows if r[0] < mid], "large": [r for r in rows if r[0] >= mid]}
+    for tag, rr in groups.items():
+        if not rr:
+            continue
+        rd, wr = sum(r[0] for r in rr) / len(rr), sum(r[1] for r in rr) / len(rr)
+        a = ALGO.get((e, tag))
+        per[e + ("" if tag is None else {"small": " (out-proj, K=768)", "large": " (fc2, K=3072)"}[tag])] = {
+            "launches_sampled": len(rr), "hbm_read_bytes": int(rd), "hbm_write_bytes": int(wr), "hbm_bytes": int(rd + wr),
+            "algorithmic_read_bytes": a[0] if a else None, "algorithmic_write_bytes": a[1] if a else None,
+            "ratio_to_algorithmic": round((rd + wr) / (a[0] + a[1]), 3) if a else None}
+traffic["gemm_per_instantiation"] = per
 json.dump(traffic, open(os.path.join(summ, "hbm_traffic_pmc.json"), "w"), indent=1)
 
 sq, dur = counters("pmc_sq")

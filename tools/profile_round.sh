@@ -21,7 +21,16 @@ echo "[profile] WRITE_SIZE pass done"
 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU --output-format csv -d $OUT/pmc_sq -- $PMCB > $OUT/pmc_sq.json 2> $OUT/pmc_sq.err
 echo "[profile] SQ pass done"
 python3 bench.py --steps 20 --warmup 5 > $OUT/bench_default.json 2> $OUT/bench_default.err
+echo "[profile] default bench done"
 python3 tools/pmc_summary.py $R $OUT
+# 4. the other single-GPU BASELINE workloads: kernel trace + stats only
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_cfg4 -- python3 bench.py --batch 16 --prompts 64 --min-len 8 --max-len 32 --maps upsample --steps 5 --warmup 2 --no-cpu-baseline --no-other-configs > $OUT/bench_cfg4_under_rocprof.json 2> $OUT/trace_cfg4.err
+echo "[profile] cfg4 trace done"
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_cfg5 -- python3 bench.py --dtype f16 --batch 1 --side 1536 --prompts 193 --min-len 6 --max-len 16 --steps 10 --warmup 3 --no-cpu-baseline --no-other-configs > $OUT/bench_cfg5_under_rocprof.json 2> $OUT/trace_cfg5.err
+echo "[profile] cfg5 trace done"
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_f32 -- python3 bench.py --dtype f32 --steps 2 --warmup 1 --no-cpu-baseline --no-other-configs > $OUT/bench_f32_under_rocprof.json 2> $OUT/trace_f32.err
+echo "[profile] fp32-mode trace done"
+for c in cfg4 cfg5 f32; do f=$(find $OUT/trace_$c -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $OUT/summary/kernel_stats_$c.csv; cp $OUT/bench_${c}_under_rocprof.json $OUT/summary/ || true; done
 # drop the bulky per-dispatch traces, keep the summaries (gpurun merges <= 64 MiB back)
 find $OUT -name "*kernel_trace.csv" -size +20M -delete || true
 ls -la $OUT | head -30
