@@ -13,7 +13,7 @@ from concurrent.futures import ThreadPoolExecutor
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG_DIR, "csrc")
 LIB_PATH = os.environ.get("RZ_LIB_PATH") or os.path.join(PKG_DIR, "libradzero_hip.so")   # RZ_LIB_PATH: A/B of two builds in one gpurun call
-SOURCES = ["gemm.hip", "gemm7.hip", "gemm8.hip", "gemm10.hip", "attention.hip", "rowops.hip", "vlcabs.hip", "preprocess.hip", "api.hip"]
+SOURCES = ["gemm.hip", "gemm7.hip", "gemm8.hip", "gemm10.hip", "gemm11.hip", "attention.hip", "rowops.hip", "vlcabs.hip", "preprocess.hip", "api.hip"]
 # attention.hip: fmaxf chains on MFMA outputs fuse into v_max3_f32 without a canonicalising v_max each
 EXTRA_FLAGS = {"attention.hip": ["-fno-honor-nans"]}
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")

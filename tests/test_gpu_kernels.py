@@ -194,7 +194,7 @@ def test_upsample(lib, g, size):
     assert (out_s.cpu() - torch.sigmoid(ref)).abs().max().item() <= 1e-5
 
 
-@pytest.mark.parametrize("variant", [1, 3, 7, 8, 10])
+@pytest.mark.parametrize("variant", [1, 3, 7, 8, 10, 11])
 @pytest.mark.parametrize("dt", ["f32", "bf16", "f16"])
 def test_gemm_variants_agree(lib, variant, dt):
     """All tile variants (128x128 two-stage, 256x256 two-stage, 256x256 staggered 8-phase) against the fp32 reference,
@@ -222,7 +222,7 @@ def test_gemm_variants_agree(lib, variant, dt):
     assert (resid - (resid0 + scale * ref)).abs().max().item() <= 2e-4 * math.sqrt(K / 64)
 
 
-@pytest.mark.parametrize("variant", [7, 8, 10])
+@pytest.mark.parametrize("variant", [7, 8, 10, 11])
 @pytest.mark.parametrize("K", [128, 192, 256, 640, 768, 3072])
 @pytest.mark.parametrize("dt", ["bf16", "f16"])
 @pytest.mark.parametrize("M", [4096, 33792])
@@ -278,7 +278,7 @@ def test_gemm_staggered_race_screen_full_size(lib, shape):
     try:
         check(lib, lib.rz_gemm_ex(1, 0, P(a), K, P(w), K, P(bias), P(ref), N, None, None, 0, M, N // 64, M, N, K, stream()))
         outs = []
-        for variant in (7, 8, 10):
+        for variant in (7, 8, 10, 11):
             check(lib, lib.rz_set_option(b"gemm_variant", variant))
             these = [torch.zeros_like(ref) for _ in range(10)]
             for o in these:
@@ -363,7 +363,7 @@ def test_fused_layernorm_model_path_matches_standalone(lib, dt, rows, images):
 
 
 @pytest.mark.parametrize("dt", ["bf16", "f16"])
-def test_gemm_v10_whole_model_bit_identical_to_v8(dt):
+def test_gemm_v10_v11_whole_model_bit_identical_to_v8(dt):
     """gemm10.hip inside the model (merged q|k|v with both operand orders, fused-LayerNorm producer / consumer epilogues, GELU, patch
     table, residual epilogues at every tile seam) against gemm8.hip: the K order per accumulator and the epilogue arithmetic are the
     same, so the vision tokens and the scores must not differ by a bit — 2 images of 1024^2 (42 x 3 ... 42 x 12 tiles per GEMM)."""
@@ -376,7 +376,7 @@ def test_gemm_v10_whole_model_bit_identical_to_v8(dt):
     g = torch.Generator(device="cuda").manual_seed(5)
     px = torch.randn((4, 3, 1024, 1024), generator=g, device="cuda")
     outs = {}
-    for variant in (8, 10):
+    for variant in (8, 10, 11):
         m = RadZeroModel.from_state_dict(sd, cfg, torch_dtype=tdt, device="cuda:0").eval()
         try:
             m.set_model_option("gemm_variant", variant)
@@ -386,7 +386,7 @@ def test_gemm_v10_whole_model_bit_identical_to_v8(dt):
             outs[variant] = toks[0]
         finally:
             m.close()
-    assert torch.isfinite(outs[10]).all() and torch.equal(outs[8], outs[10])
+    assert torch.isfinite(outs[10]).all() and torch.equal(outs[8], outs[10]) and torch.equal(outs[8], outs[11])
 
 
 # ---- the text side and the patch embedding, kernel by kernel (SURVEY.md §8(b) list) ------------------------------
