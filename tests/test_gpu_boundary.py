@@ -184,8 +184,18 @@ def _rccl_child(q):
         enc = {"input_ids": torch.from_numpy(ids).cuda(), "attention_mask": torch.from_numpy(mask).cuda()}
         batches = [torch.from_numpy(synthetic_pixels(b, 224, 40 + i)) for i, b in enumerate((2, 2, 1))]
         plain_feats = model.forward_text_model(enc)["text_features_wo_l2_norm"]
+        calls = []                                    # every collective issued from here on: (name, dtype, shape of the payload, device type)
+        for name in ("all_gather_into_tensor", "all_gather", "gather", "all_reduce", "broadcast", "reduce_scatter_tensor", "all_to_all_single"):
+            orig = getattr(dist, name)
+
+            def spy(*a, _orig=orig, _name=name, **k):
+                t = a[1] if _name == "all_gather_into_tensor" else a[0] if torch.is_tensor(a[0]) else a[1]
+                calls.append((_name, str(t.dtype), list(t.shape), t.device.type))
+                return _orig(*a, **k)
+            setattr(dist, name, spy)
         dist_feats = sharded_text_features(lambda e: model.forward_text_model(e)["text_features_wo_l2_norm"], enc,
                                            feature_dim=cfg.hidden_size)                 # all_gather_into_tensor over RCCL
+        text_calls, calls[:] = list(calls), []
         plain = calculate_similarities(batches, {"encoded_key_phrases": enc}, model)
         distd = calculate_similarities(batches, {"encoded_key_phrases": enc}, model, distributed=True)
         g = gather_logits(torch.from_numpy(plain).cuda())
@@ -193,7 +203,8 @@ def _rccl_child(q):
         torch.cuda.synchronize()
         q.put({"feats_equal": bool(torch.equal(plain_feats, dist_feats)), "logits_equal": bool(np.array_equal(plain, distd)),
                "gather_equal": bool(np.array_equal(g.cpu().numpy(), plain)), "shape": list(plain.shape),
-               "backend": dist.get_backend()})
+               "backend": dist.get_backend(), "text_calls": text_calls, "image_loop_calls": sorted({c[0] for c in calls}),
+               "image_loop_float_payloads": sorted({tuple(c[2]) for c in calls if "float" in c[1]})})
         model.close()
         dist.destroy_process_group()
     except Exception as e:      # report instead of hanging the parent
@@ -213,5 +224,11 @@ def test_dp_driver_over_rccl_single_rank_child():
     res = q.get(timeout=600)
     p.join(timeout=120)
     assert "error" not in res, res
+    text_calls, loop_calls, payloads = res.pop("text_calls"), res.pop("image_loop_calls"), res.pop("image_loop_float_payloads")
     assert res == {"feats_equal": True, "logits_equal": True, "gather_equal": True, "shape": [5, 5], "backend": "nccl"}, res
+    # the prompt exchange is ONE all_gather_into_tensor of (ceil(T / W), 768) fp32 on the device — 5 x 768 x 4 B here
+    assert text_calls == [["all_gather_into_tensor", "torch.float32", [5, 768], "cuda"]] or text_calls == [("all_gather_into_tensor", "torch.float32", [5, 768], "cuda")], text_calls
+    # ... and the image loop has NO data-path collective: only the result gather of (rows, T) logits (row counts exchanged first) and the barrier
+    assert set(loop_calls) <= {"all_gather", "gather"}, loop_calls
+    assert all(len(pl) == 2 and pl[1] == 5 for pl in payloads), payloads          # float payloads are (rows, T) logits, never tokens / maps
     assert p.exitcode == 0
