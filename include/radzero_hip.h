@@ -223,6 +223,9 @@ int rz_patch_embed(int dtype, const float* pixel_values_dev, int batch, int chan
  *                      not under stream capture); rz_get_model_option(h, "f32_split_guard_reruns") counts the repeats
  *   "ln_fused"         1 (default) = the blocks' LayerNorms are fused into the GEMMs either side of them (16-bit modes);
  *                      0 = stand-alone LayerNorm kernels everywhere
+ *   "sim_op"           VL-CABS similarity (losses.py:207-217): 0 (default) "cos" — the released config; 1 "dot" — RadZeroLoss's constructor
+ *                      default: LayerNorm without L2 normalisation, scores / sqrt(hidden), both sides normalised in the final logit.
+ *                      (A checkpoint tensor "loss_fns.RadZeroLoss.attn_temperature", when loaded, is the score temperature of "cos".)
  *   "pad_rows"         token rows per image are padded to: 0 (default) a multiple of 128, of 256 where that costs < 2 % more rows
  *                      | 128 | 256 always that multiple.  Setting it on a handle drops its position tables and workspace sizes
  *                      (call rz_set_position_table / rz_reserve again).

@@ -189,12 +189,21 @@ def masked_mean_pool(token_embeddings, attention_mask):
 # --------------------------------------------------------------------------------------------
 # VL-CABS head
 # --------------------------------------------------------------------------------------------
-def vlcabs(text_features, vision_tokens, ln_w, ln_b, ln_eps, temperature):
-    """exp/cxr_pt/model/losses.py:71-105 (shared LN on both sides, CLS kept) + :187-240 (SimilarityLogit,
-    sim_op='cos').  text_features (T, D) pre-LN; vision_tokens (B, N, D) pre-LN.
+def vlcabs(text_features, vision_tokens, ln_w, ln_b, ln_eps, temperature, sim_op="cos"):
+    """exp/cxr_pt/model/losses.py:71-105 (shared LN on both sides, CLS kept) + :187-240 (SimilarityLogit).
+    text_features (T, D) pre-LN; vision_tokens (B, N, D) pre-LN; temperature: the score temperature of sim_op 'cos'
+    (exp(attn_temperature) if the checkpoint has one, else exp(loss_temperature): losses.py:175-181).
     Returns t2i_logits (T, B) (before the reference's .squeeze()) and pre-softmax scores (B, T, N)."""
     q = layer_norm(text_features, ln_w, ln_b, ln_eps)          # losses.py:163-164
     v = layer_norm(vision_tokens, ln_w, ln_b, ln_eps)          # losses.py:90-91
+    if sim_op == "dot":                                        # losses.py:214-215: no normalisation, denominator sqrt(D)
+        scores = torch.einsum("td,bnd->btn", q, v) / math.sqrt(v.shape[-1])
+        p = torch.softmax(scores, dim=-1)
+        agg = l2_normalize(torch.einsum("btn,bnd->btd", p, v))  # losses.py:224, :227
+        logits_bt = torch.einsum("td,btd->bt", l2_normalize(q), agg)   # losses.py:226, :229-231
+        return logits_bt.t().contiguous(), scores
+    if sim_op != "cos":
+        raise NotImplementedError                               # losses.py:216-217
     qn = l2_normalize(q)                                       # losses.py:212
     vn = l2_normalize(v)                                       # losses.py:213
     scores = torch.einsum("td,bnd->btn", qn, vn) / temperature  # losses.py:219-221
@@ -302,9 +311,10 @@ class OracleModel:
         vt = self.forward_vision_model(pixel_values)["vision_tokens"]
         if text_features is None:
             text_features = self.text_features(encoded_key_phrases[0])
-        tau = float(torch.exp(P["loss_fns.RadZeroLoss.loss_temperature"])[0])
+        key = "loss_fns.RadZeroLoss.attn_temperature"           # losses.py:175-181: the attention temperature wins when it exists
+        tau = float(torch.exp(P[key if key in P else "loss_fns.RadZeroLoss.loss_temperature"])[0])
         t2i, scores = vlcabs(text_features, vt, P["loss_fns.RadZeroLoss.layer_norm.weight"],
-                             P["loss_fns.RadZeroLoss.layer_norm.bias"], cfg.shared_layer_norm_eps, tau)
+                             P["loss_fns.RadZeroLoss.layer_norm.bias"], cfg.shared_layer_norm_eps, tau, cfg.sim_op)
         t2i = t2i.squeeze()                                     # losses.py:229-231 .squeeze() degeneracy
         sim = scores[:, :, 1:] if cfg.use_vision_cls_token else scores   # modeling.py:311-317
         # modeling.py:322-328: divides by the (1,)-shaped parameter .exp() -> a 0-d t2i becomes (1,)

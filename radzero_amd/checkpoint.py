@@ -159,6 +159,7 @@ def config_from_hf(path_or_dict, state_dict=None) -> RadZeroConfig:
         relative_attention_num_buckets=t.get("relative_attention_num_buckets", base.relative_attention_num_buckets),
         loss_temperature=loss.get("loss_temperature", base.loss_temperature),
         sim_op=loss.get("sim_op", base.sim_op),
+        attn_temperature=loss.get("attn_temperature", base.attn_temperature),
     )
     facts = _shape_facts(state_dict)
     text_heads = facts.pop("text_num_attention_heads", None)          # MPNet's head count (relative_attention_bias columns)

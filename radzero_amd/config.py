@@ -1,3 +1,4 @@
+from __future__ import annotations
 """Hyper-parameters of the RadZero VL-CABS inference path.
 
 Field names follow the reference's YAML / HF configs so a reference user finds the same knobs:
@@ -38,7 +39,8 @@ class RadZeroConfig:
     loss_temperature: float = 0.07          # stored as log(0.07) in the checkpoint
     shared_layer_norm_eps: float = 1e-5     # nn.LayerNorm default (losses.py:51)
     use_vision_cls_token: bool = True
-    sim_op: str = "cos"
+    sim_op: str = "cos"                     # "cos" (released radzero.yaml:44) | "dot" (RadZeroLoss's constructor default, losses.py:45, :214-215)
+    attn_temperature: float | None = None   # losses.py:57-63: a separate temperature for the score softmax ("cos" only); None = the loss temperature
 
     @property
     def head_dim(self) -> int:

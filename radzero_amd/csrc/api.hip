@@ -36,12 +36,13 @@ struct Options {
     int gemm_f32_split;   // fp32 mode: the vision encoder's GEMMs on the f16 matrix pipe with hi/lo-split operands (0 = exact-fp32 MFMAs)
     int attn_f32_split;   // fp32 mode: attention on the f16 matrix pipe with hi/lo-split operands (0 = exact-fp32 MFMAs)
     int ln_fused;         // 1 = fuse the blocks' LayerNorms into the GEMMs either side where the persistent kernel applies (16-bit modes)
+    int sim_op;           // VL-CABS similarity: 0 = "cos" (released config), 1 = "dot" (losses.py:214-215)
     int pad_rows;         // token rows per image: 0 = multiple of 128, of 256 when that costs < 2 % more rows | 128 | 256 = always that multiple
     int f32_split_guard;  // fp32 mode: 1 = a forward whose f16 planes overflowed is repeated on the exact-fp32 kernels (default)
 };
-Options g_opt = {0, 1, 0, 0, 0, 1, 1, 1, 0, 1};
+Options g_opt = {0, 1, 0, 0, 0, 1, 1, 1, 0, 0, 1};
 const Options kInherit = {RZ_OPT_INHERIT, RZ_OPT_INHERIT, RZ_OPT_INHERIT, RZ_OPT_INHERIT, RZ_OPT_INHERIT, RZ_OPT_INHERIT, RZ_OPT_INHERIT,
-                          RZ_OPT_INHERIT, RZ_OPT_INHERIT, RZ_OPT_INHERIT};
+                          RZ_OPT_INHERIT, RZ_OPT_INHERIT, RZ_OPT_INHERIT, RZ_OPT_INHERIT};
 int* option_field(Options& o, const char* name) {
     if (!strcmp(name, "vision_chunk")) return &o.vision_chunk;
     if (!strcmp(name, "vision_streams")) return &o.vision_streams;
@@ -51,6 +52,7 @@ int* option_field(Options& o, const char* name) {
     if (!strcmp(name, "gemm_f32_split")) return &o.gemm_f32_split;
     if (!strcmp(name, "attn_f32_split")) return &o.attn_f32_split;
     if (!strcmp(name, "ln_fused")) return &o.ln_fused;
+    if (!strcmp(name, "sim_op")) return &o.sim_op;
     if (!strcmp(name, "pad_rows")) return &o.pad_rows;
     if (!strcmp(name, "f32_split_guard")) return &o.f32_split_guard;
     return nullptr;
@@ -148,6 +150,7 @@ struct rz_model {
     bool o_attn_f32_split() const { return pick(opt.attn_f32_split, g_opt.attn_f32_split) != 0 && !force_exact; }
     bool o_ln_fused() const { return pick(opt.ln_fused, g_opt.ln_fused) != 0; }
     int o_pad_rows() const { return pick(opt.pad_rows, g_opt.pad_rows); }
+    bool o_sim_dot() const { return pick(opt.sim_op, g_opt.sim_op) == 1; }
     bool o_guard() const { return pick(opt.f32_split_guard, g_opt.f32_split_guard) != 0; }
     bool force_exact = false;            // set while a forward is repeated on the exact-fp32 kernels (overflow guard)
     // padded token rows per image: a multiple of 128 (every GEMM M-tile and attention query block is full); of 256 when that costs less
@@ -164,8 +167,8 @@ struct rz_model {
     std::vector<TextLayer> tlayers;
     Tensor patch_w, vit_ln_g, vit_ln_b, word_emb, pos_emb, temb_ln_g, temb_ln_b, shared_ln_g, shared_ln_b;
     std::vector<float> cls_host, patch_bias_host;
-    bool cls_loaded = false, patch_bias_loaded = false, tau_loaded = false;
-    float tau = 0.07f;
+    bool cls_loaded = false, patch_bias_loaded = false, tau_loaded = false, attn_tau_loaded = false;
+    float tau = 0.07f, attn_tau = 0.07f;      // exp(loss_temperature); exp(attn_temperature) when the checkpoint carries one (losses.py:57-63)
     // position tables per grid: [n_pad][D] fp32 = pos (+cls | +conv bias), zero on pad rows
     struct PosTable { DevBuf buf; int n_valid, n_pad; };
     std::map<std::pair<int, int>, PosTable> pos_tables;
@@ -633,6 +636,12 @@ int rz_load_weight(rz_handle_t m, const char* name, const float* data, int64_t n
         m->tau_loaded = true;
         return 0;
     }
+    if (!strcmp(name, "loss_fns.RadZeroLoss.attn_temperature")) {      // only present when the config sets one (losses.py:57-63)
+        if (numel != 1) return fail(RZ_ERR_INVALID, "bad numel for attn_temperature");
+        m->attn_tau = expf(data[0]);
+        m->attn_tau_loaded = true;
+        return 0;
+    }
     // tensors the path never reads: position_embeddings (interpolated on the host and passed through
     // rz_set_position_table), mask_token, pooler, relative_attention_bias (passed expanded to rz_text_forward)
     if (!strcmp(name, "vision_model.embeddings.position_embeddings") || !strcmp(name, "vision_model.embeddings.mask_token") ||
@@ -1041,10 +1050,14 @@ int rz_vlcabs(rz_handle_t m, const float* text_features, int T, int B, float* sc
     hipStream_t s = (hipStream_t)stream;
     const int D = m->D;
     ProfScope ps(m, RZ_PROF_VLCABS, s);
+    const bool dot = m->o_sim_dot();
+    // losses.py:214-221: "cos" divides the cosines by the temperature (attn_temperature if the checkpoint has one, else the loss
+    // temperature, :175-181), "dot" divides the raw products by sqrt(D); modeling.py:322-328 divides the logits by the loss temperature
+    const float denom = dot ? sqrtf((float)D) : (m->attn_tau_loaded ? m->attn_tau : m->tau);
     RZ_HIP(launch_ln_l2norm(text_features, D, (const float*)m->shared_ln_g.p, (const float*)m->shared_ln_b.p,
-                            m->cfg.shared_layer_norm_eps, (float*)m->qhat.p, T, D, s));
+                            m->cfg.shared_layer_norm_eps, (float*)m->qhat.p, T, D, dot ? 0 : 1, s));
     RZ_HIP(launch_vlcabs((const float*)m->h.p, (const float*)m->shared_ln_g.p, (const float*)m->shared_ln_b.p,
-                         m->cfg.shared_layer_norm_eps, (const float*)m->qhat.p, m->tau, (float*)m->vws.p,
+                         m->cfg.shared_layer_norm_eps, (const float*)m->qhat.p, denom, m->tau, dot ? 1 : 0, (float*)m->vws.p,
                          scores, t2i, logits, B, T, m->last_nvalid, m->last_npad, D, s));
     return 0;
 }

@@ -190,7 +190,7 @@ hipError_t launch_ln_prepare(int dtype, const float* in, const float* gamma, con
 template <int NV>
 __global__ __launch_bounds__(256) void ln_l2norm_kernel(const float* __restrict__ in, int64_t ld_in,
                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                        float eps, float* __restrict__ out, int64_t rows) {
+                                                        float eps, float* __restrict__ out, int64_t rows, int l2) {
     constexpr int D = 256 * NV;
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -200,15 +200,15 @@ __global__ __launch_bounds__(256) void ln_l2norm_kernel(const float* __restrict_
     float q = 0.f;
 #pragma unroll
     for (int i = 0; i < NV; ++i) q += (r.v[i][0] * r.v[i][0] + r.v[i][1] * r.v[i][1]) + (r.v[i][2] * r.v[i][2] + r.v[i][3] * r.v[i][3]);
-    const float nrm = fmaxf(sqrtf(wave_sum(q)), 1e-12f);   // F.normalize: x / max(||x||, eps)
+    const float nrm = l2 ? fmaxf(sqrtf(wave_sum(q)), 1e-12f) : 1.0f;   // F.normalize: x / max(||x||, eps); sim_op "dot": LayerNorm only
 #pragma unroll
     for (int i = 0; i < NV; ++i) *reinterpret_cast<f32x4*>(out + row * D + (lane + 64 * i) * 4) = r.v[i] / nrm;
 }
 
 hipError_t launch_ln_l2norm(const float* in, int64_t ld_in, const float* gamma, const float* beta, float eps,
-                            float* out, int64_t rows, int D, hipStream_t s) {
+                            float* out, int64_t rows, int D, int l2, hipStream_t s) {
     if (D != 768 || rows <= 0) return hipErrorInvalidValue;
-    hipLaunchKernelGGL((ln_l2norm_kernel<3>), dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, in, ld_in, gamma, beta, eps, out, rows);
+    hipLaunchKernelGGL((ln_l2norm_kernel<3>), dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, in, ld_in, gamma, beta, eps, out, rows, l2);
     return hipGetLastError();
 }
 

@@ -112,13 +112,15 @@ hipError_t launch_masked_meanpool(const float* h, const int64_t* mask, float* ou
 
 // shared LN + L2 normalise rows (fp32 -> fp32).  in rows have stride ld_in.
 hipError_t launch_ln_l2norm(const float* in, int64_t ld_in, const float* gamma, const float* beta, float eps,
-                            float* out, int64_t rows, int D, hipStream_t s);
+                            float* out, int64_t rows, int D, int l2, hipStream_t s);
 
 // VL-CABS: tokens [B][Npad][D] fp32 (shared LN + L2 normalisation applied inside), qhat [T][D] -> scores [B][T][N] (= cos/tau),
 // t2i_logits [T][B], logits [B][T] (= t2i^T / tau).  ws: float workspace.
 size_t vlcabs_workspace_floats(int B, int T, int n_pad, int D);
+// sim_dot = 0: cosine (tokens and queries L2-normalised), scores / score_denominator (= tau); 1: losses.py's "dot": LayerNorm only,
+// scores / score_denominator (= sqrt(D)), both sides normalised in the final logit.  logits = t2i^T / logit_tau.
 hipError_t launch_vlcabs(const float* tokens, const float* ln_gamma, const float* ln_beta, float ln_eps,
-                         const float* qhat, float tau, float* ws, float* scores, float* t2i_logits,
+                         const float* qhat, float score_denominator, float logit_tau, int sim_dot, float* ws, float* scores, float* t2i_logits,
                          float* logits, int B, int T, int n_valid, int n_pad, int D, hipStream_t s);
 
 // bilinear upsample (align_corners=False) of patch-grid maps [M][g][g] -> [M][H][W], optional sigmoid;

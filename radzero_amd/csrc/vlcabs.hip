@@ -5,6 +5,10 @@
 //   S     = qhat . vhat / tau                             (losses.py:219-221)          [vlcabs_kernel]
 //   p     = softmax_N(S); agg = p . vhat                  (losses.py:222-224)          [vlcabs_kernel + finalize]
 //   logit = qhat . agg/||agg||                            (losses.py:226-233)          [finalize]
+// sim_op == "dot" (losses.py:214-215; RadZeroLoss's constructor default, not the released config): vhat = LN_shared(tokens) and
+// q = LN_shared(text) WITHOUT the L2 normalisation, S = q . vhat / sqrt(D), and the final logit normalises both: q/||q|| . agg/||agg||.
+// tau of S = exp(attn_temperature) when the checkpoint has one, else exp(loss_temperature) (losses.py:175-181); the returned
+// `logits` are always divided by exp(loss_temperature) (modeling.py:322-328).
 //
 // Softmax over N tokens is split into 128-token chunks (online-softmax partials m, l, agg[D]) that the
 // finalize kernel merges, so the token tensor is streamed once and nothing of size N x N exists.
@@ -32,7 +36,7 @@ constexpr int VC_LDS_STRIDE = 772;      // floats; 772 mod 64 = 4 spreads the 16
 __global__ __launch_bounds__(256) void vlcabs_kernel(const float* __restrict__ tokens, const float* __restrict__ gamma,
                                                      const float* __restrict__ beta, float eps, const float* __restrict__ qhat,
                                                      float inv_tau, float* __restrict__ ws, float* __restrict__ scores, int T,
-                                                     int n_valid, int n_pad) {
+                                                     int n_valid, int n_pad, int l2_tokens) {
     constexpr int D = 768, REC = D + 2;
     __shared__ __attribute__((aligned(16))) float vs[16 * VC_LDS_STRIDE];
     __shared__ float sred[4][16][17];        // [wave][prompt][token]: K-quarter partial scores
@@ -81,7 +85,7 @@ __global__ __launch_bounds__(256) void vlcabs_kernel(const float* __restrict__ t
                 v[i] = v[i] * rstd * gm + be;
                 n2 += (v[i][0] * v[i][0] + v[i][1] * v[i][1]) + (v[i][2] * v[i][2] + v[i][3] * v[i][3]);
             }
-            const float inv = 1.0f / fmaxf(sqrtf(wave_sum(n2)), 1e-12f);
+            const float inv = l2_tokens ? 1.0f / fmaxf(sqrtf(wave_sum(n2)), 1e-12f) : 1.0f;
 #pragma unroll
             for (int i = 0; i < 3; ++i) *reinterpret_cast<f32x4*>(vs + rl * VC_LDS_STRIDE + (lane + 64 * i) * 4) = v[i] * inv;
         }
@@ -167,7 +171,7 @@ __device__ __forceinline__ float block_sum_256(float v, float* red) {
 // ---- merge chunks, normalise, dot with qhat ----
 __global__ __launch_bounds__(256) void vlcabs_finalize_kernel(const float* __restrict__ ws, const float* __restrict__ qhat,
                                                               float tau, float* __restrict__ t2i_logits,
-                                                              float* __restrict__ logits, int T, int B, int nchunks) {
+                                                              float* __restrict__ logits, int T, int B, int nchunks, int normalize_q) {
     constexpr int D = 768, REC = D + 2;
     __shared__ float red[4];
     const int t = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
@@ -187,8 +191,10 @@ __global__ __launch_bounds__(256) void vlcabs_finalize_kernel(const float* __res
     const float n2 = block_sum_256(a0 * a0 + a1 * a1 + a2 * a2, red);
     const float* qv = qhat + (int64_t)t * D;
     const float dot = block_sum_256(qv[tid] * a0 + qv[tid + 256] * a1 + qv[tid + 512] * a2, red);
+    // sim_op "dot": the query rows are not normalised yet (losses.py:226 normalises them only here)
+    const float q2 = normalize_q ? block_sum_256(qv[tid] * qv[tid] + qv[tid + 256] * qv[tid + 256] + qv[tid + 512] * qv[tid + 512], red) : 1.0f;
     if (tid == 0) {
-        const float lg = dot / fmaxf(sqrtf(n2), 1e-12f);
+        const float lg = dot / (fmaxf(sqrtf(n2), 1e-12f) * (normalize_q ? fmaxf(sqrtf(q2), 1e-12f) : 1.0f));
         t2i_logits[(int64_t)t * B + b] = lg;
         logits[(int64_t)b * T + t] = lg / tau;
     }
@@ -199,13 +205,13 @@ size_t vlcabs_workspace_floats(int B, int T, int n_pad, int D) {
 }
 
 hipError_t launch_vlcabs(const float* tokens, const float* ln_gamma, const float* ln_beta, float ln_eps,
-                         const float* qhat, float tau, float* ws, float* scores, float* t2i_logits,
+                         const float* qhat, float score_denominator, float logit_tau, int sim_dot, float* ws, float* scores, float* t2i_logits,
                          float* logits, int B, int T, int n_valid, int n_pad, int D, hipStream_t s) {
     if (D != 768 || B <= 0 || T <= 0 || n_pad % VC_CHUNK || n_valid > n_pad) return hipErrorInvalidValue;
     const int nchunks = n_pad / VC_CHUNK;
     hipLaunchKernelGGL(vlcabs_kernel, dim3((T + VC_TG - 1) / VC_TG, nchunks, B), dim3(256), 0, s, tokens, ln_gamma, ln_beta, ln_eps,
-                       qhat, 1.0f / tau, ws, scores, T, n_valid, n_pad);
-    hipLaunchKernelGGL(vlcabs_finalize_kernel, dim3(T, B), dim3(256), 0, s, ws, qhat, tau, t2i_logits, logits, T, B, nchunks);
+                       qhat, 1.0f / score_denominator, ws, scores, T, n_valid, n_pad, sim_dot ? 0 : 1);
+    hipLaunchKernelGGL(vlcabs_finalize_kernel, dim3(T, B), dim3(256), 0, s, ws, qhat, logit_tau, t2i_logits, logits, T, B, nchunks, sim_dot ? 1 : 0);
     return hipGetLastError();
 }
 

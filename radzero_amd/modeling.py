@@ -107,8 +107,8 @@ class RadZeroModel:
     def __init__(self, config: Optional[RadZeroConfig] = None, torch_dtype: torch.dtype = torch.bfloat16,
                  device: str | torch.device = "cuda:0"):
         self.config = config or RadZeroConfig()
-        if self.config.sim_op != "cos":
-            raise NotImplementedError("only sim_op == 'cos' (released RadZero config) is implemented")
+        if self.config.sim_op not in ("cos", "dot"):
+            raise NotImplementedError(f"sim_op {self.config.sim_op!r}: SimilarityLogit knows 'cos' and 'dot' (losses.py:207-217)")
         self.dtype = torch_dtype
         if torch.device(device).type != "cuda":
             raise RuntimeError("RadZeroModel runs on an AMD GPU through libradzero_hip.so; there is no CPU path")
@@ -141,6 +141,7 @@ class RadZeroModel:
             pad_token_id=c.pad_token_id, shared_layer_norm_eps=c.shared_layer_norm_eps)
         with torch.cuda.device(self._device):
             _lib.check(self._lib.rz_create(ctypes.byref(rc), ctypes.byref(self._h)), "rz_create")
+            _lib.check(self._lib.rz_set_model_option(self._h, b"sim_op", 1 if c.sim_op == "dot" else 0), "rz_set_model_option(sim_op)")
 
     def close(self):
         if getattr(self, "_h", None) is not None and self._h.value:

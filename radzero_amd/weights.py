@@ -100,6 +100,8 @@ def checkpoint_spec(cfg: RadZeroConfig) -> "OrderedDict[str, tuple]":
     spec["loss_fns.RadZeroLoss.layer_norm.weight"] = ((d,), "ln_w")
     spec["loss_fns.RadZeroLoss.layer_norm.bias"] = ((d,), "ln_b")
     spec["loss_fns.RadZeroLoss.loss_temperature"] = ((1,), "log_temperature")
+    if getattr(cfg, "attn_temperature", None) is not None:          # the Parameter exists only when the config sets it (losses.py:57-63)
+        spec["loss_fns.RadZeroLoss.attn_temperature"] = ((1,), "log_attn_temperature")
     return spec
 
 
@@ -131,6 +133,8 @@ def _make(seed: int, name: str, shape, kind: str, cfg: RadZeroConfig) -> np.ndar
         return _normal(seed, name, shape, 0.7)
     if kind == "log_temperature":
         return np.array([math.log(cfg.loss_temperature)], np.float32)
+    if kind == "log_attn_temperature":
+        return np.array([math.log(cfg.attn_temperature)], np.float32)
     raise KeyError(kind)
 
 

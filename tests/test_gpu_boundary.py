@@ -204,7 +204,8 @@ def _rccl_child(q):
         q.put({"feats_equal": bool(torch.equal(plain_feats, dist_feats)), "logits_equal": bool(np.array_equal(plain, distd)),
                "gather_equal": bool(np.array_equal(g.cpu().numpy(), plain)), "shape": list(plain.shape),
                "backend": dist.get_backend(), "text_calls": text_calls, "image_loop_calls": sorted({c[0] for c in calls}),
-               "image_loop_float_payloads": sorted({tuple(c[2]) for c in calls if "float" in c[1]})})
+               "image_loop_prompt_exchanges": [c[2] for c in calls if c[0] == "all_gather_into_tensor"],
+               "image_loop_float_payloads": sorted({tuple(c[2]) for c in calls if "float" in c[1] and c[0] != "all_gather_into_tensor"})})
         model.close()
         dist.destroy_process_group()
     except Exception as e:      # report instead of hanging the parent
@@ -225,10 +226,13 @@ def test_dp_driver_over_rccl_single_rank_child():
     p.join(timeout=120)
     assert "error" not in res, res
     text_calls, loop_calls, payloads = res.pop("text_calls"), res.pop("image_loop_calls"), res.pop("image_loop_float_payloads")
+    prompt_x = res.pop("image_loop_prompt_exchanges")
     assert res == {"feats_equal": True, "logits_equal": True, "gather_equal": True, "shape": [5, 5], "backend": "nccl"}, res
     # the prompt exchange is ONE all_gather_into_tensor of (ceil(T / W), 768) fp32 on the device — 5 x 768 x 4 B here
     assert text_calls == [["all_gather_into_tensor", "torch.float32", [5, 768], "cuda"]] or text_calls == [("all_gather_into_tensor", "torch.float32", [5, 768], "cuda")], text_calls
-    # ... and the image loop has NO data-path collective: only the result gather of (rows, T) logits (row counts exchanged first) and the barrier
-    assert set(loop_calls) <= {"all_gather", "gather"}, loop_calls
+    # ... and the batch driver (calculate_similarities(distributed=True), 3 image batches) issues that prompt exchange exactly ONCE (cached
+    # for the later batches) and otherwise NO data-path collective: only the result gather of (rows, T) logits, row counts exchanged first
+    assert prompt_x == [[5, 768]], prompt_x
+    assert set(loop_calls) <= {"all_gather", "gather", "all_gather_into_tensor"}, loop_calls
     assert all(len(pl) == 2 and pl[1] == 5 for pl in payloads), payloads          # float payloads are (rows, T) logits, never tokens / maps
     assert p.exitcode == 0

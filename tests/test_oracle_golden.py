@@ -137,3 +137,23 @@ def test_oracle_matches_reference_on_outlier_checkpoint(cfg, state_dict):
     assert np.abs(out["logits"].numpy() - g["logits"]).max() <= TOL
     assert np.abs(out["similarity_scores"].numpy() - g["similarity_scores"]).max() <= 5 * TOL
     assert float(g["residual_absmax_per_layer"].max()) > 400.0
+
+
+@pytest.mark.parametrize("name,over", [("g10_dot_s224_b2_t3", dict(sim_op="dot")), ("g11_attntemp_s224_b2_t3", dict(attn_temperature=0.2))])
+def test_oracle_head_variants_match_reference(name, over, cfg):
+    """G10 / G11: the reference run with sim_op 'dot' (losses.py:214-215) and with a separate attn_temperature (losses.py:57-63,
+    :175-181): the oracle's restatement of both branches against the reference's own outputs."""
+    import dataclasses
+    from oracle.radzero_oracle import OracleModel
+    from radzero_amd.weights import make_state_dict
+    g = load_golden(name)
+    c2 = dataclasses.replace(cfg, **over)
+    sd = make_state_dict(c2, int(g["weights_seed"]))
+    assert state_dict_digest(sd) == str(g["weights_digest"])
+    assert ("loss_fns.RadZeroLoss.attn_temperature" in sd) == ("attn_temperature" in over)
+    px, enc = _inputs(g)
+    with torch.no_grad():
+        out = OracleModel(sd, c2, attn_impl="eager").compute_logits(px, [enc])
+    for key in ("logits", "similarity_scores", "t2i_logits"):
+        assert np.abs(out[key].numpy() - g[key]).max() <= TOL, (name, key)
+    assert np.array_equal(np.argmax(out["logits"].numpy(), 1), np.argmax(g["logits"], 1))

@@ -108,6 +108,17 @@ def main():
     cfg = RadZeroConfig()
     seed = 20260103
     sd = make_state_dict(cfg, seed)
+    if "--head-variants" in sys.argv:
+        # G10 / G11 (round 3): the two VL-CABS capabilities beside the released config — sim_op "dot" (RadZeroLoss's constructor
+        # default, losses.py:45, :214-215) and a separate attn_temperature (losses.py:57-63, :175-181) — run by the reference itself
+        import dataclasses
+        for name, over in (("g10_dot_s224_b2_t3", dict(sim_op="dot")), ("g11_attntemp_s224_b2_t3", dict(attn_temperature=0.2))):
+            c2 = dataclasses.replace(cfg, **over)
+            sd2 = make_state_dict(c2, seed)
+            meta = dict(weights_seed=seed, weights_digest=state_dict_digest(sd2), torch_version=torch.__version__, attn_implementation="eager",
+                        sim_op=c2.sim_op, attn_temperature=-1.0 if c2.attn_temperature is None else c2.attn_temperature)
+            run_case(load_reference_model(c2, sd2, attn_implementation="eager"), name, 224, 2, 3, 5, 12, 1245, 4332, meta)
+        return
     if "--g9" in sys.argv:
         # G9 (round 3): configs[4]'s per-GPU shape.  SDPA attention in the 12 ViT blocks (the reference's AlignTransformer and MPNet are eager-only; eager everywhere would hold 12 x 11882^2 fp32 scores
         # = 6.8 GB twice per layer); SDPA vs eager on the reference is <= 2e-6 on the G7 scores (checked by --g9-check).

@@ -107,7 +107,7 @@ def load_reference_model(cfg, state_dict=None, attn_implementation="eager"):
                                       use_layer_norm=False),
         loss=dict(apply=["RadZeroLoss"], ratio=[1.0],
                   RadZeroLoss=dict(hidden_dim=cfg.hidden_size, mpnce_row_sum=False, mpnce_col_sum=False,
-                                   attn_temperature=None, loss_temperature=cfg.loss_temperature,
+                                   attn_temperature=getattr(cfg, "attn_temperature", None), loss_temperature=cfg.loss_temperature,
                                    text_features_l2_norm=False, sim_op=cfg.sim_op)),
         compute_logits_type="radzero",
         pretrained_dir="/data/pretrained",          # exp/cxr_pt/configs/paths.yaml:11 (only read for m3ae)
