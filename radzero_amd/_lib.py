@@ -12,7 +12,10 @@ from concurrent.futures import ThreadPoolExecutor
 
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG_DIR, "csrc")
-LIB_PATH = os.environ.get("RZ_LIB_PATH") or os.path.join(PKG_DIR, "libradzero_hip.so")   # RZ_LIB_PATH: A/B of two builds in one gpurun call
+# RZ_EXPERIMENTS=1: the TOOLS build (-DRZ_EXPERIMENTS: in-kernel stamp builds of gemm7 / gemm8, the retired attention shapes of rounds 1-2),
+# its own library and object directory; the product and every test use the plain build.
+EXPERIMENTS = os.environ.get("RZ_EXPERIMENTS") == "1"
+LIB_PATH = os.environ.get("RZ_LIB_PATH") or os.path.join(PKG_DIR, "libradzero_hip_experiments.so" if EXPERIMENTS else "libradzero_hip.so")   # RZ_LIB_PATH: A/B of two builds in one gpurun call
 SOURCES = ["gemm.hip", "gemm7.hip", "gemm8.hip", "gemm10.hip", "gemm11.hip", "attention.hip", "rowops.hip", "vlcabs.hip", "preprocess.hip", "api.hip"]
 # attention.hip: fmaxf chains on MFMA outputs fuse into v_max3_f32 without a canonicalising v_max each
 EXTRA_FLAGS = {"attention.hip": ["-fno-honor-nans"]}
@@ -43,7 +46,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
     if not os.path.exists(HIPCC):
         raise RuntimeError(f"hipcc not found at {HIPCC}; cannot build libradzero_hip.so")
     import fcntl
-    obj_dir = os.path.join(PKG_DIR, "build")
+    obj_dir = os.path.join(PKG_DIR, "build_experiments" if EXPERIMENTS else "build")
     os.makedirs(obj_dir, exist_ok=True)
     with open(os.path.join(obj_dir, ".lock"), "w") as lock:
         fcntl.flock(lock, fcntl.LOCK_EX)
@@ -57,7 +60,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
 
 def _build_locked(obj_dir: str, verbose: bool, force: bool = False) -> str:
     flags = [f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "-Werror=uninitialized",
-             "-Werror=return-type"]
+             "-Werror=return-type"] + (["-DRZ_EXPERIMENTS"] if EXPERIMENTS else [])
     tag = f".{os.getpid()}.tmp"
 
     def cc(src):

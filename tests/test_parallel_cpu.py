@@ -144,3 +144,41 @@ def test_single_process_passthrough():
     assert torch.equal(sharded_text_features(_encode, enc), _encode(enc))
     x = torch.randn(3, 4)
     assert gather_logits(x) is x
+
+
+def _ckpt_worker(rank, world, port, q):
+    """bench.py's one-checkpoint-per-node path: local rank 0 generates + writes, the others read after a barrier."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import sys
+        sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        import bench
+        from radzero_amd.config import RadZeroConfig
+        from radzero_amd.weights import make_state_dict, state_dict_digest
+        cfg = RadZeroConfig(vit_layers=1, align_layers=1, text_layers=1, vocab_size=300)
+        sd = bench.node_shared_state_dict(cfg, 77, rank, True)
+        ref = make_state_dict(cfg, 77)
+        same = set(sd) == set(ref) and all(np.array_equal(np.asarray(sd[k], np.float32).reshape(-1), np.asarray(ref[k], np.float32).reshape(-1)) for k in ref)
+        q.put((rank, bool(same), state_dict_digest({k: np.asarray(v, np.float32).reshape(np.shape(ref[k])) for k, v in sd.items()}) == state_dict_digest(ref)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_bench_checkpoint_is_built_once_per_node():
+    """N ranks of one node must not each generate the synthetic checkpoint; every rank ends up with the same tensors
+    as the generator gives, and the temporary file is gone afterwards (gloo, world size 3)."""
+    import glob
+    import tempfile
+    world = 3
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_ckpt_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=300) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+    assert res == [(r, True, True) for r in range(world)], res
+    assert not glob.glob(os.path.join(tempfile.gettempdir(), f"radzero_bench_ckpt_77_{port}*"))

@@ -1,4 +1,5 @@
-"""Diagnostic (GPU box): in-kernel s_memtime stamps of one K tile of the staggered 256x256 GEMM (gemm7.hip MODE 2).
+"""[tools build only: run with RZ_EXPERIMENTS=1 in the environment — the stamped kernels are not in the production library]
+Diagnostic (GPU box): in-kernel s_memtime stamps of one K tile of the staggered 256x256 GEMM (gemm7.hip MODE 2).
   python tools/kstamp.py [N] [K]"""
 import ctypes, math, os, sys
 import torch

@@ -1,4 +1,5 @@
-"""Diagnostic (GPU box): where the persistent GEMM (gemm8.hip, stamped build) spends its time — per wave the 100 MHz ticks
+"""[tools build only: run with RZ_EXPERIMENTS=1 in the environment — the stamped kernels are not in the production library]
+Diagnostic (GPU box): where the persistent GEMM (gemm8.hip, stamped build) spends its time — per wave the 100 MHz ticks
 inside K loops and inside epilogues, and how synchronised the epilogue starts of different CUs are.
   python tools/kstamp8.py [epi=2|1|4] [N] [K] [images]"""
 import ctypes, math, os, sys
@@ -25,7 +26,7 @@ out = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
 dbg = torch.zeros(256 * 8 * 32, device="cuda", dtype=torch.int64)
 lib.rz_set_option(b"gemm_variant", 8)
 if skew:
-    lib.rz_set_option(b"gemm_skew", skew)
+    pass  # the start-up skew experiment of round 2 is gone (profiles/r02/gemm_v8_startup_skew_sweep.log)
 f = lambda: lib.rz_gemm_ex(1, epi, P(a), K * lda_mul, P(w), K * ldw_mul, P(bias), P(out), N, P(scale), P(resid), N, 5376, N // 64, M, N, K, ST())
 for _ in range(3):
     assert f() == 0, lib.rz_last_error()
