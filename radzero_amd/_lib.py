@@ -160,6 +160,10 @@ def load(auto_build: bool = True) -> ctypes.CDLL:
     global _lib
     if _lib is not None:
         return _lib
+    # torch FIRST: its wheel bundles its own libamdhip64.so.7 / libhsa-runtime64.so.1 (same SONAMEs as /opt/rocm's).  Whichever copy is
+    # mapped first serves the whole process; if this library pulled in /opt/rocm's before torch initialised the GPU through its own, the
+    # process would hold two HIP runtimes and rz_create found no device (seen with `python __graft_entry__.py smoke`: build() then smoke()).
+    import torch  # noqa: F401
     if auto_build and os.path.exists(HIPCC):
         build()
     if not os.path.exists(LIB_PATH):
