@@ -235,6 +235,9 @@ def short_run(sd, cfg, device, dtype, B, S, T, maps, min_len, max_len, steps=5, 
         enc = {"input_ids": torch.from_numpy(ids).to(device), "attention_mask": torch.from_numpy(mask).to(device)}
         tf = model.forward_text_model(enc)["text_features_wo_l2_norm"]
         pipe = InputPipeline(pipeline, px, device) if pipeline else None
+        # per-pixel maps land in ONE buffer re-used by every step (4.29 GB at cfg 4): a fresh torch.empty per step put a hipMalloc of
+        # that size inside some timed regions (325 against 402 images/s between two runs of the same tree)
+        maps_buf = torch.empty((B * T, S, S), dtype=torch.float32, device=device) if maps == "upsample" else None
 
         def step():
             if pipe is not None:
@@ -244,7 +247,7 @@ def short_run(sd, cfg, device, dtype, B, S, T, maps, min_len, max_len, steps=5, 
                 return out
             out = model.compute_logits(px, [enc], text_features=tf)
             if maps == "upsample":
-                out["similarity_maps"] = model.upsample_similarity(out["similarity_scores"], (S, S))
+                out["similarity_maps"] = model.upsample_similarity(out["similarity_scores"], (S, S), out=maps_buf)
             elif maps == "points":
                 out["grounding_points"] = model.grounding_points(out["similarity_scores"], (S, S))
             return out
@@ -392,6 +395,7 @@ def main():
     torch.cuda.synchronize()
     text_ms = (time.time() - t0) * 1e3
 
+    main_maps_buf = torch.empty((B * T, S, S), dtype=torch.float32, device=device) if args.maps == "upsample" else None
     mode = "host" if args.host_pixels else {None: None, "device": "raw", "host": "rawhost"}[args.raw_images]
     pipe = InputPipeline(mode, pixels, device, overlap=not args.no_overlap) if mode else None
 
@@ -402,8 +406,8 @@ def main():
             pipe.done(slot)
         else:
             out = model.compute_logits(pixels, [enc], text_features=text_features)
-        if args.maps == "upsample":      # (B, T, S, S) fp32 per-pixel maps (interpolate_similarity_scores semantics)
-            out["similarity_maps"] = model.upsample_similarity(out["similarity_scores"], (S, S))
+        if args.maps == "upsample":      # (B, T, S, S) fp32 per-pixel maps (interpolate_similarity_scores semantics), into one re-used buffer
+            out["similarity_maps"] = model.upsample_similarity(out["similarity_scores"], (S, S), out=main_maps_buf)
         elif args.maps == "points":      # fused upsample + argmax (get_grounding_point semantics), map never written
             out["grounding_points"] = model.grounding_points(out["similarity_scores"], (S, S))
         return out

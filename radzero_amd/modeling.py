@@ -374,9 +374,11 @@ class RadZeroModel:
     # ---- similarity-map post-processing (segmentation_utils.py:62-70, attention_map_base.py:57) ---
     @torch.no_grad()
     def upsample_similarity(self, similarity_scores: torch.Tensor, size, sigmoid: bool = False,
-                            keep_aspect_ratio: bool = False) -> torch.Tensor:
+                            keep_aspect_ratio: bool = False, out: Optional[torch.Tensor] = None) -> torch.Tensor:
         """(..., g*g) patch-grid scores -> (..., H, W) bilinear (align_corners=False) [+ sigmoid].
-        keep_aspect_ratio: the AspectRatioBlipImageProcessor branch (upsample to the padded square, crop the image area)."""
+        keep_aspect_ratio: the AspectRatioBlipImageProcessor branch (upsample to the padded square, crop the image area).
+        out: optional contiguous fp32 buffer of n_maps*H*W elements to write into (a serving loop re-uses one 4.3 GB buffer at
+        BASELINE cfg 4 instead of allocating it per batch)."""
         hh, ww = int(size[0]), int(size[1])
         g = int(round(math.sqrt(similarity_scores.shape[-1])))
         if g * g != similarity_scores.shape[-1]:
@@ -388,7 +390,10 @@ class RadZeroModel:
             flat, stride = s, s.stride(1)          # e.g. the [:, :, 1:] view of the (B, T, N) score tensor: no copy
         else:
             flat, stride = s.contiguous(), g * g
-        out = torch.empty((n_maps, hh, ww), dtype=torch.float32, device=self._device)
+        if out is None:
+            out = torch.empty((n_maps, hh, ww), dtype=torch.float32, device=self._device)
+        elif out.numel() != n_maps * hh * ww or out.dtype != torch.float32 or not out.is_contiguous() or out.device != self._device:
+            raise ValueError("out must be a contiguous fp32 tensor of n_maps*H*W elements on the model's device")
         with torch.cuda.device(self._device):
             _lib.check(self._lib.rz_upsample_maps_ex(self._h, _ptr(flat), stride, n_maps, g, hh, ww, int(sigmoid),
                                                      int(keep_aspect_ratio), _ptr(out), self._stream()), "rz_upsample_maps")
