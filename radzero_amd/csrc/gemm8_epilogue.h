@@ -119,26 +119,56 @@ __device__ __forceinline__ void v8_epilogue_resid_ln(const GemmArgs& g, const f3
     typedef typename Traits<T>::vec4 vec4_t;
     typedef typename Traits<T>::frag frag_t;
     const int l15 = lane & 15, lg = lane >> 4;
-    f32x4 b4[4], s4[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int n = nw + j * 16 + 4 * lg;
-        b4[j] = g.bias ? *reinterpret_cast<const f32x4*>(g.bias + n) : (f32x4){0.f, 0.f, 0.f, 0.f};
-        s4[j] = *reinterpret_cast<const f32x4*>(g.scale + n);
+    // The wave's 64 bias / LayerScale / next-LayerNorm-gain values live in the upper half of its 4 KB LDS region for the duration of the
+    // epilogue (lane l < 48 fetches one 16-byte piece): 48 VGPRs less than holding them in registers — what the second residual buffer
+    // below needs — and no ordinary global load is left inside the pipelined part.
+    float* vec = reinterpret_cast<float*>(wl + 2048);                 // [0,64) bias  [64,128) scale  [128,192) gamma
+    if (lane < 48) {
+        const int which = lane >> 4, c4 = (lane & 15) * 4;
+        const float* src = which == 0 ? g.bias : which == 1 ? g.scale : g.ln_gamma;
+        const f32x4 v = src ? *reinterpret_cast<const f32x4*>(src + nw + c4) : (f32x4){0.f, 0.f, 0.f, 0.f};
+        *reinterpret_cast<f32x4*>(vec + which * 64 + c4) = v;
     }
     const unsigned wr_off = (unsigned)(l15 * 128 + (lg & 1) * 8);
     const int slice = nw >> 6;                               // 0..11 for N = 768
-#pragma unroll
-    for (int grp = 0; grp < 4; ++grp) {                      // 32 rows per batch: 8 loads in flight, as in gemm_epilogue_rmw
+    // The residual rows arrive in four batches of 32 rows (8 x 16-byte loads + 2 centring constants per lane), and batch g+1 is
+    // REQUESTED BEFORE batch g is consumed and stored: the epilogue used to walk four dependent HBM round trips per tile (9.4-10 us
+    // per out-proj tile in the stamped build, a quarter of its K loop).  hipcc cannot be asked for that: with LDS-DMA pieces of the
+    // next tile in flight it puts vmcnt(0) in front of the first use of any ordinary load (cdna_hip_programming.md §5, trap (b)),
+    // which would also wait for the batch just requested.  So these loads are inline asm and the wait is counted by hand: when batch g
+    // is needed, the only younger vector-memory operations of this wave are the 10 loads of batch g+1 (more, if the compiler put
+    // something behind them, only makes the wait stricter).
+    f32x4 hvb[2][2][4];
+    float cmb[2][2];
+    auto request = [&](int grp, f32x4 (&hv)[2][4], float (&cm)[2]) {
         const int a = grp >> 1, ih = grp & 1;
-        f32x4 hv[2][4];
-        float* dst[2];
 #pragma unroll
         for (int ii = 0; ii < 2; ++ii) {
             const int m = mw + a * 64 + (ih * 2 + ii) * 16 + l15;
-            dst[ii] = g.resid + (int64_t)m * g.ldr + nw + 4 * lg;
+            const float* src = g.resid + (int64_t)m * g.ldr + nw + 4 * lg;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) hv[ii][j] = *reinterpret_cast<const f32x4*>(dst[ii] + j * 16);
+            for (int j = 0; j < 4; ++j) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(hv[ii][j]) : "v"(src + j * 16) : "memory");
+            asm volatile("global_load_dword %0, %1, off" : "=v"(cm[ii]) : "v"(g.ln_mu + m) : "memory");
+        }
+    };
+    request(0, hvb[0], cmb[0]);
+#pragma unroll
+    for (int grp = 0; grp < 4; ++grp) {
+        const int a = grp >> 1, ih = grp & 1;
+        f32x4 (&hv)[2][4] = hvb[grp & 1];
+        float (&cmv)[2] = cmb[grp & 1];
+        float* dst[2];
+#pragma unroll
+        for (int ii = 0; ii < 2; ++ii) dst[ii] = g.resid + (int64_t)(mw + a * 64 + (ih * 2 + ii) * 16 + l15) * g.ldr + nw + 4 * lg;
+        if (grp < 3) {
+            request(grp + 1, hvb[(grp + 1) & 1], cmb[(grp + 1) & 1]);
+            asm volatile("s_waitcnt vmcnt(10)"
+                         : "+v"(hv[0][0]), "+v"(hv[0][1]), "+v"(hv[0][2]), "+v"(hv[0][3]), "+v"(hv[1][0]), "+v"(hv[1][1]), "+v"(hv[1][2]), "+v"(hv[1][3]),
+                           "+v"(cmv[0]), "+v"(cmv[1]) :: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)"
+                         : "+v"(hv[0][0]), "+v"(hv[0][1]), "+v"(hv[0][2]), "+v"(hv[0][3]), "+v"(hv[1][0]), "+v"(hv[1][1]), "+v"(hv[1][2]), "+v"(hv[1][3]),
+                           "+v"(cmv[0]), "+v"(cmv[1]) :: "memory");
         }
 #pragma unroll
         for (int ii = 0; ii < 2; ++ii) {
@@ -147,7 +177,8 @@ __device__ __forceinline__ void v8_epilogue_resid_ln(const GemmArgs& g, const f3
             float sum = 0.f;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                hv[ii][j] = hv[ii][j] + s4[j] * (acc[a][i][j] + b4[j]);           // the new residual
+                const f32x4 b4 = *reinterpret_cast<const f32x4*>(vec + j * 16 + 4 * lg), s4 = *reinterpret_cast<const f32x4*>(vec + 64 + j * 16 + 4 * lg);
+                hv[ii][j] = hv[ii][j] + s4 * (acc[a][i][j] + b4);                 // the new residual
                 *reinterpret_cast<f32x4*>(dst[ii] + j * 16) = hv[ii][j];
                 sum += (hv[ii][j][0] + hv[ii][j][1]) + (hv[ii][j][2] + hv[ii][j][3]);
             }
@@ -165,13 +196,13 @@ __device__ __forceinline__ void v8_epilogue_resid_ln(const GemmArgs& g, const f3
             m2 += __shfl_xor(m2, 32, 64);
             if (lg == 0) *reinterpret_cast<f32x2*>(g.ln_part + ((int64_t)m * 12 + slice) * 2) = (f32x2){mean, m2};
             // T copy, centred with the row's previous mean and scaled by the consuming LayerNorm's gain BEFORE rounding:
-            // 16 rows x 64 columns through the wave's LDS image, whole 128-byte row pieces out
-            const float cm = g.ln_mu[m];
-            char* img = wl + (i & 1) * 2048;
+            // 16 rows x 64 columns through the wave's LDS image (ONE 2 KB image: same wave, in-order LDS queue), whole 128-byte row pieces out
+            const float cm = cmv[ii];
+            char* img = wl;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int c = j * 2 + (lg >> 1);
-                const f32x4 gv = (hv[ii][j] - cm) * *reinterpret_cast<const f32x4*>(g.ln_gamma + nw + j * 16 + 4 * lg);
+                const f32x4 gv = (hv[ii][j] - cm) * *reinterpret_cast<const f32x4*>(vec + 128 + j * 16 + 4 * lg);
                 *reinterpret_cast<vec4_t*>(img + wr_off + ((c ^ (l15 & 7)) << 4)) = pack4<T>(gv[0], gv[1], gv[2], gv[3]);
             }
             asm volatile("" ::: "memory");
