@@ -336,7 +336,7 @@ def main():
     ap.add_argument("--all-kernel-events", action="store_true", help="A/B: record HIP events for every kernel family inside the timed region (default: "
                     "the dominant kernel's family only; the other families are timed over two extra, un-timed steps)")
     ap.add_argument("--no-other-configs", action="store_true", help="skip the short runs of BASELINE configs[3], configs[4] per-GPU shape and the fp32 mode")
-    ap.add_argument("--attn-variant", type=int, default=None, help="A/B switch (rz_set_option): 1 = default (4 waves x 32 rows; bf16 without the running maximum), 417 = with it")
+    ap.add_argument("--attn-variant", type=int, default=None, help="A/B switch (rz_set_option): 0 = default (4 waves x 32 query rows; bf16 without the running maximum), 64 = 64 query rows per wave, 417 = running maximum tracked")
     ap.add_argument("--ln-fused", type=int, default=None, help="A/B switch: 1 fused LayerNorm (default, 16-bit modes), 0 stand-alone LayerNorm kernels")
     ap.add_argument("--vision-chunk", type=int, default=None, help="images per internal pass of the vision encoder (0 = whole batch)")
     ap.add_argument("--mlp-chunk", type=int, default=None, help="images per fc1->fc2 pass (-1 = auto, 0 = whole batch)")

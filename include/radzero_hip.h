@@ -215,7 +215,9 @@ int rz_patch_embed(int dtype, const float* pixel_values_dev, int batch, int chan
  *                      | 10 persistent, four waves x 128x128, accumulators in AGPRs, generated inline-asm K loop (gemm10.hip; bit-identical, 7 % slower)
  *   "gemm_v1_only"     (process-wide only) 1 = same as gemm_variant 1
  *   "attn_variant"     0 default (16x16x32 MFMA, 4 waves x 32 query rows, row sums on the matrix pipe; bf16 without the running
- *                      maximum in the hot loop) | 417 the same with it (what f16 always runs)
+ *                      maximum in the hot loop) | 64 = 64 query rows per wave where the padded token count is a multiple of 256 (half
+ *                      the LDS traffic per FLOP; faster back to back, slower inside the model's step) | 417 = the default shape with
+ *                      the running maximum tracked in every tile (what f16 always runs)
  *   "attn_f32_split"   1 (default) = fp32 mode runs attention as hi/lo-split f16 MFMAs; 0 = exact-fp32 MFMAs (16x16x4_f32)
  *   "gemm_f32_split"   1 (default) = fp32 mode runs the vision encoder's GEMMs as hi/lo-split f16 MFMAs; 0 = exact-fp32 MFMAs
  *   "f32_split_guard"  1 (default) = fp32 mode: a forward in which a value left the f16 range of the hi/lo planes (|x| > 65504) is

@@ -61,7 +61,7 @@ inline int pick(int own, int process_wide) { return own == RZ_OPT_INHERIT ? proc
 
 hipError_t flash_attn(int variant, int dt, const void* q, const void* k, const void* vt, void* ctx, int64_t bs, int B, int H, int nv, int np,
                       hipStream_t s) {
-    return launch_flash_attn(dt, q, k, vt, ctx, bs, B, H, nv, np, (variant == 16 || variant == 417) ? variant : 4, s);
+    return launch_flash_attn(dt, q, k, vt, ctx, bs, B, H, nv, np, variant, s);       // unknown values run the default shapes
 }
 
 int hip_fail(hipError_t e, const char* what) {

@@ -79,7 +79,12 @@ __device__ __forceinline__ typename Traits<T>::frag lds_frag_row(const char* til
 // the loop is done and, if any row of the workgroup overflowed, runs the whole loop again with the tracking path (16 v_max3 +
 // the vote per tile come out of the hot loop: the kernel is bound by vector ISSUE slots).  f16 operands keep the tracking path: P <= 65504 means the
 // second pass already triggers at s - m > 16, which random scores reach often enough to cost more than the maxima (927 against 997 TFLOP/s).
-template <typename T, int NW, int QT, bool LS = false, bool NOMAX = false>
+// ABL (only instantiated != 0 with -DRZ_EXPERIMENTS, attn_variant 1000 + ABL): TIMING ablations of the hot loop, results wrong by
+// construction (tools/attn_ablate.py): 1 no exponentials, 2 no P V / row-sum MFMAs, 4 no score MFMAs,
+// 8 no LDS fragment reads, 16 no K / V staging after tile 1, 32 no barriers.
+// NBUF = K / V^T tiles resident in LDS (2: tile t+1 is staged while tile t is consumed; 3: tile t+2 is — two tiles of time for the
+// LDS-DMA to land, waited for with a counted vmcnt).
+template <typename T, int NW, int QT, bool LS = false, bool NOMAX = false, int ABL = 0, int NBUF = 2>
 __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : ((QT == 4 || sizeof(T) == 4) ? 2 : RZ_FA_WAVES)) void flash_attn_kernel(const T* __restrict__ q, const T* __restrict__ k,
                                                             const T* __restrict__ vT, T* __restrict__ ctx,
                                                             int64_t qk_batch_stride, int B, int H, int n_valid, int n_pad) {
@@ -87,7 +92,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : ((QT == 4 || sizeof(T) == 4)
     constexpr int NPAN = FaCfg<T>::NPAN;
     constexpr int TILE = FaCfg<T>::TILE_BYTES;
     constexpr int ES = (int)sizeof(T);
-    __shared__ __attribute__((aligned(1024))) char lds[4 * TILE];   // K0 K1 V0 V1
+    __shared__ __attribute__((aligned(1024))) char lds[2 * NBUF * TILE];   // K0 .. K(NBUF-1) V0 .. V(NBUF-1)
     __shared__ int overflowed;                                      // NOMAX: some row of this workgroup left the float range
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -152,7 +157,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : ((QT == 4 || sizeof(T) == 4)
 
     auto stage = [&](int t, int buf) {
         char* sk = lds + buf * TILE;
-        char* sv = lds + (2 + buf) * TILE;
+        char* sv = lds + (NBUF + buf) * TILE;
         const int key0 = t * FA_KEYS;
 #pragma unroll
         for (int p = 0; p < NPAN; ++p) {
@@ -182,16 +187,18 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : ((QT == 4 || sizeof(T) == 4)
 #pragma unroll
     for (int a = 0; a < QT; ++a) { mrow[a] = 0.f; lrow[a] = 0.f; cinit[a] = (f32x4){0.f, 0.f, 0.f, 0.f}; lacc[a] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
 
+    const int ntiles = (n_valid + FA_KEYS - 1) / FA_KEYS;
     // one KV tile.  FIRST: tile 0 (establishes the reference point).  MASK: ragged last tile (keys >= n_valid dead).
     auto tile = [&](int t, auto first_c, auto mask_c, auto track_c) {
         constexpr bool FIRST = decltype(first_c)::value, MASK = decltype(mask_c)::value;
         constexpr bool TRACK = FIRST || decltype(track_c)::value;    // running maximum + re-centring in this tile
-        const int buf = t & 1;
+        const int buf = NBUF == 2 ? (t & 1) : t % NBUF;
         const char* sk = lds + buf * TILE;
-        const char* sv = lds + (2 + buf) * TILE;
+        const char* sv = lds + (NBUF + buf) * TILE;
         // ---- S' = K Q^T - mrow ----
         f32x4 sacc[QT][4];
         auto load_k = [&](int ks, int kt) -> frag_t {
+            if constexpr ((ABL & 8) != 0) { frag_t x; asm volatile("" : "=v"(x)); return x; }   // whatever the registers hold: no instruction, no CSE
             const int krb = (32 * (kt >> 1) + 4 * (kt & 1)) * 128;   // immediate
             if constexpr (ES == 4) {
                 const f32x4 lo = *reinterpret_cast<const f32x4*>(sk + koff[ks][0] + krb);
@@ -202,6 +209,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : ((QT == 4 || sizeof(T) == 4)
             }
         };
         auto load_v = [&](int kk, int dt) -> frag_t {
+            if constexpr ((ABL & 8) != 0) { frag_t x; asm volatile("" : "=v"(x)); return x; }
             if constexpr (ES == 4) {
                 const f32x4 lo = *reinterpret_cast<const f32x4*>(sv + voff[kk][0] + dt * 2048);
                 const f32x4 hi = *reinterpret_cast<const f32x4*>(sv + voff[kk][1] + dt * 2048);
@@ -219,12 +227,17 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : ((QT == 4 || sizeof(T) == 4)
 #pragma unroll
         for (int kt = 0; kt < 4; ++kt) {
 #pragma unroll
-            for (int a = 0; a < QT; ++a) sacc[a][kt] = mma(kf[0][kt], qf[a][0], cinit[a]);     // = K Q^T - m (cinit is 0 on tile 0)
+            for (int a = 0; a < QT; ++a) {
+                if constexpr ((ABL & 4) != 0) { asm volatile("" : "=v"(sacc[a][kt]) : "v"(kf[0][kt]), "v"(kf[1][kt])); }
+                else sacc[a][kt] = mma(kf[0][kt], qf[a][0], cinit[a]);     // = K Q^T - m (cinit is 0 on tile 0)
+            }
         }
+        if constexpr ((ABL & 4) == 0) {
 #pragma unroll
         for (int kt = 0; kt < 4; ++kt) {
 #pragma unroll
             for (int a = 0; a < QT; ++a) sacc[a][kt] = mma(kf[1][kt], qf[a][1], sacc[a][kt]);
+        }
         }
         // V^T fragments of the first 32-key step: requested now, consumed after the softmax
         frag_t vf0[4];
@@ -307,6 +320,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : ((QT == 4 || sizeof(T) == 4)
             for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
+                    if constexpr ((ABL & 1) != 0) pv[kt][r] = sacc[qt][kt][r]; else
                     pv[kt][r] = __builtin_amdgcn_exp2f(sacc[qt][kt][r]);
                     if constexpr (!LS) psum += pv[kt][r];
                 }
@@ -321,6 +335,13 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : ((QT == 4 || sizeof(T) == 4)
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) vf1[dt] = load_v(1, dt);
         asm volatile("" ::: "memory");
+        if constexpr ((ABL & 2) != 0) {
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) asm volatile("" :: "v"(vf0[dt]), "v"(vf1[dt]));
+#pragma unroll
+            for (int a = 0; a < QT; ++a) asm volatile("" :: "v"(pf[a][0]), "v"(pf[a][1]));
+            return;
+        }
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) {
 #pragma unroll
@@ -341,7 +362,6 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : ((QT == 4 || sizeof(T) == 4)
     using TrueT = std::integral_constant<bool, true>;
     using FalseT = std::integral_constant<bool, false>;
 
-    const int ntiles = (n_valid + FA_KEYS - 1) / FA_KEYS;
     const bool ragged = (n_valid % FA_KEYS) != 0;
     const int nplain = ragged ? ntiles - 1 : ntiles;     // tiles [0, nplain) need no masking
     auto run = [&](auto track_c) {
@@ -349,14 +369,36 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : ((QT == 4 || sizeof(T) == 4)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (ntiles > 1) stage(1, 1);
+        if constexpr (NBUF == 3) {
+            // three tiles resident: tile t+2 is requested at the top of tile t (its buffer was tile t-1's, which every wave left at the last
+            // barrier) and only tile t+1 has to be there at the bottom -> this wave's DMA_PER_STAGE pieces of tile t+2 may stay in flight
+            constexpr int DMA_PER_STAGE = NPAN * (8 / NW) * 2;
+            static_assert(DMA_PER_STAGE == 4 || DMA_PER_STAGE == 8, "counted vmcnt below");
+            auto bottom = [&](bool staged) {
+                if (staged) { if constexpr (DMA_PER_STAGE == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); }
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                if constexpr ((ABL & 32) == 0) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            };
+            if constexpr ((ABL & 16) == 0) { if (ntiles > 2) stage(2, 2); }
+            if (nplain >= 1) tile(0, TrueT{}, FalseT{}, track_c); else tile(0, TrueT{}, TrueT{}, track_c);
+            bottom(ntiles > 2);
+            for (int t = 1; t < nplain; ++t) {
+                const bool st = t + 2 < ntiles;
+                if constexpr ((ABL & 16) == 0) { if (st) stage(t + 2, (t + 2) % 3); }
+                tile(t, FalseT{}, FalseT{}, track_c);
+                bottom(st);
+            }
+            if (ragged && ntiles > 1) tile(ntiles - 1, FalseT{}, TrueT{}, track_c);
+            return;
+        }
         if (nplain >= 1) tile(0, TrueT{}, FalseT{}, track_c); else tile(0, TrueT{}, TrueT{}, track_c);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         for (int t = 1; t < nplain; ++t) {
-            if (t + 1 < ntiles) stage(t + 1, (t + 1) & 1);
+            if constexpr ((ABL & 16) == 0) { if (t + 1 < ntiles) stage(t + 1, (t + 1) & 1); }
             tile(t, FalseT{}, FalseT{}, track_c);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
+            if constexpr ((ABL & 32) == 0) __syncthreads();
         }
         if (ragged && ntiles > 1) tile(ntiles - 1, FalseT{}, TrueT{}, track_c);
     };
@@ -375,7 +417,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : ((QT == 4 || sizeof(T) == 4)
         }
         if (__any(bad) && lane == 0) overflowed = 1;
         __syncthreads();                                 // also: every wave is done with the K / V buffers
-        if (__builtin_expect(overflowed != 0, 0)) {      // workgroup-uniform: the waves share the staging and its barriers
+        if (ABL == 0 && __builtin_expect(overflowed != 0, 0)) {      // workgroup-uniform: the waves share the staging and its barriers
 #pragma unroll
             for (int a = 0; a < QT; ++a) {
                 mrow[a] = 0.f; lrow[a] = 0.f; cinit[a] = (f32x4){0.f, 0.f, 0.f, 0.f}; lacc[a] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -723,47 +765,71 @@ hipError_t launch_flash_attn_split_planes(const void* q_hi, const void* k_hi, co
 }
 
 hipError_t launch_flash_attn(int dtype, const void* q, const void* k, const void* vT, void* ctx,
-                             int64_t qk_batch_stride, int B, int H, int n_valid, int n_pad, int waves, hipStream_t s) {
+                             int64_t qk_batch_stride, int B, int H, int n_valid, int n_pad, int variant, hipStream_t s) {
     if (n_pad % FA_QROWS || n_valid <= 0 || n_valid > n_pad || B <= 0 || H <= 0) return hipErrorInvalidValue;
-    // `waves` = option attn_variant:  4 (default) 4 waves x 32 query rows, row sums on the matrix pipe, bf16 without the running maximum
-    // in the hot loop (NOMAX); 417 the same shape with the running maximum tracked in every tile (what f16 always runs; bf16's second
-    // pass).  fp32 operands: VALU row sums (the ones-row sums would cost 8 exact-f32 MFMAs per tile).
-    // Measured and retired (rounds 1-2; compiled only with -DRZ_EXPERIMENTS): 16 = VALU row sums for 16-bit operands,
-    // 8 = 8 waves x 32 rows, 64 = 4 waves x 64 rows.
-    int qt = 2;
+    // `variant` = option attn_variant.  Every 16-bit kernel: 4 waves per workgroup, row sums on the matrix pipe (LS); bf16 without the
+    // running maximum in the hot loop (NOMAX), f16 with it.
+    //   0 / 4 (default)  32 query rows per wave (128 per workgroup), 3 waves per SIMD
+    //   64               64 query rows per wave (256 per workgroup) where n_pad is a multiple of 256: every K / V^T fragment read from LDS
+    //                    feeds four MFMAs and every staged tile 256 query rows — half the LDS reads and LDS-DMA bytes per FLOP, which the
+    //                    round-3 timing ablations name as what the MFMA stream waits for.  4-6 % faster than the default when the kernel
+    //                    runs back to back (tools/attn_ab.py), 1.5-2 % SLOWER inside the model's step: not the default
+    //   417              the default shape with the running maximum tracked in every tile (bf16's second pass made the first)
+    // fp32 operands: 32 rows per wave, VALU row sums (the ones-row sums would cost 8 exact-f32 MFMAs per tile).
+    // Measured and retired (compiled only with -DRZ_EXPERIMENTS): 16 = VALU row sums for 16-bit operands, 8 = 8 waves x 32
+    // rows, 5 / 65 = three K / V^T tiles resident (LDS-DMA two tiles ahead), 1000 + m / 2000 + m = timing ablations of the hot loop.
+    int nw = 4, qt = (dtype != DT_F32 && n_pad % 256 == 0 && (variant == 64 || variant == 65)) ? 4 : 2;
+    bool ls = dtype != DT_F32, track = variant == 417 || dtype == DT_F16;
+    [[maybe_unused]] bool deep = false;
+#define RZ_FA(TT, NWV, QTV, LSV, NOMAXV, ABLV, NBUFV)                                                                                      \
+    hipLaunchKernelGGL((flash_attn_kernel<TT, NWV, QTV, LSV, NOMAXV, ABLV, NBUFV>), dim3(((B * H * (n_pad / (16 * QTV * NWV)) + 7) / 8) * 8), \
+                       dim3(64 * NWV), 0, s, (const TT*)q, (const TT*)k, (const TT*)vT, (TT*)ctx, qk_batch_stride, B, H, n_valid, n_pad)
 #ifdef RZ_EXPERIMENTS
-    const bool ls = (waves == 4 || waves == 417) && dtype != DT_F32;
-#else
-    if (waves != 4 && waves != 417) waves = 4;
-    const bool ls = dtype != DT_F32;
-#endif
-    const bool track = (waves == 417) || dtype == DT_F16;
-    if (waves == 417 || waves == 16) waves = 4;
-    if (waves == 64) { waves = 4; qt = 4; }
-    if ((waves == 8 || qt == 4) && (n_pad % 256 || dtype == DT_F32)) { waves = 4; qt = 2; }
-    if (waves != 4 && waves != 8) return hipErrorInvalidValue;
-    const int nq = n_pad / (16 * qt * waves);
-    const int pairs = B * H;
-    dim3 grid(((pairs * nq + 7) / 8) * 8), block(64 * waves);
-#define RZ_FA(TT, NWV, QTV, LSV, NOMAXV) hipLaunchKernelGGL((flash_attn_kernel<TT, NWV, QTV, LSV, NOMAXV>), grid, block, 0, s, (const TT*)q, \
-                                                            (const TT*)k, (const TT*)vT, (TT*)ctx, qk_batch_stride, B, H, n_valid, n_pad)
-#ifdef RZ_EXPERIMENTS
-#define RZ_FA16(TT)                                                   \
-    if (ls) RZ_FA(TT, 4, 2, true, false);                             \
-    else if (waves == 8) RZ_FA(TT, 8, 2, false, false);               \
-    else if (qt == 4) RZ_FA(TT, 4, 4, false, false);                  \
-    else RZ_FA(TT, 4, 2, false, false)
-#else
-#define RZ_FA16(TT) RZ_FA(TT, 4, 2, true, false)
+    if (variant >= 1000 && variant < 3000) {                 // timing ablations: results wrong by construction (tools/attn_ablate.py)
+        if (dtype != DT_BF16 || (variant >= 2000 && n_pad % 256)) return hipErrorInvalidValue;
+#define RZ_FA_ABL(A) case 1000 + A: RZ_FA(bf16_t, 4, 2, true, true, A, 2); break;
+#define RZ_FA_ABL4(A) case 2000 + A: RZ_FA(bf16_t, 4, 4, true, true, A, 2); break;
+        switch (variant) {
+            RZ_FA_ABL(0) RZ_FA_ABL(1) RZ_FA_ABL(2) RZ_FA_ABL(4) RZ_FA_ABL(8) RZ_FA_ABL(16) RZ_FA_ABL(32) RZ_FA_ABL(6) RZ_FA_ABL(7) RZ_FA_ABL(48)
+            RZ_FA_ABL(56) RZ_FA_ABL(57) RZ_FA_ABL(9) RZ_FA_ABL(24)
+            RZ_FA_ABL4(0) RZ_FA_ABL4(1) RZ_FA_ABL4(8) RZ_FA_ABL4(16) RZ_FA_ABL4(32) RZ_FA_ABL4(7) RZ_FA_ABL4(48) RZ_FA_ABL4(56) RZ_FA_ABL4(57) RZ_FA_ABL4(24)
+            default: return hipErrorInvalidValue;
+        }
+#undef RZ_FA_ABL
+#undef RZ_FA_ABL4
+        return hipGetLastError();
+    }
+    if (dtype != DT_F32) {
+        if (variant == 16) { ls = false; qt = 2; }
+        if (variant == 8 && n_pad % 256 == 0) { nw = 8; ls = false; qt = 2; }
+        if (variant == 5) { deep = true; qt = 2; }
+        if (variant == 65 && qt == 4) deep = true;
+    }
 #endif
     switch (dtype) {
-        case DT_F32: RZ_FA(float, 4, 2, false, false); break;
-        case DT_BF16: if (ls && !track) RZ_FA(bf16_t, 4, 2, true, true); else { RZ_FA16(bf16_t); } break;
-        case DT_F16: RZ_FA16(f16_t); break;
+        case DT_F32: RZ_FA(float, 4, 2, false, false, 0, 2); break;
+        case DT_BF16:
+#ifdef RZ_EXPERIMENTS
+            if (deep && qt == 4) { RZ_FA(bf16_t, 4, 4, true, true, 0, 3); break; }
+            if (deep) { RZ_FA(bf16_t, 4, 2, true, true, 0, 3); break; }
+            if (nw == 8) { RZ_FA(bf16_t, 8, 2, false, false, 0, 2); break; }
+            if (!ls) { RZ_FA(bf16_t, 4, 2, false, false, 0, 2); break; }
+#endif
+            if (qt == 4) { if (track) RZ_FA(bf16_t, 4, 4, true, false, 0, 2); else RZ_FA(bf16_t, 4, 4, true, true, 0, 2); }
+            else { if (track) RZ_FA(bf16_t, 4, 2, true, false, 0, 2); else RZ_FA(bf16_t, 4, 2, true, true, 0, 2); }
+            break;
+        case DT_F16:
+#ifdef RZ_EXPERIMENTS
+            if (deep && qt == 2) { RZ_FA(f16_t, 4, 2, true, false, 0, 3); break; }
+            if (nw == 8) { RZ_FA(f16_t, 8, 2, false, false, 0, 2); break; }
+            if (!ls) { RZ_FA(f16_t, 4, 2, false, false, 0, 2); break; }
+#endif
+            if (qt == 4) RZ_FA(f16_t, 4, 4, true, false, 0, 2); else RZ_FA(f16_t, 4, 2, true, false, 0, 2);
+            break;
         default: return hipErrorInvalidValue;
     }
-#undef RZ_FA16
 #undef RZ_FA
+    (void)nw; (void)ls;
     return hipGetLastError();
 }
 

@@ -84,11 +84,12 @@ def _attn_ref(q, k, v):
     return torch.einsum("bhqk,bhkd->bhqd", torch.softmax(s, -1), v)
 
 
-@pytest.fixture(params=[1, 417], ids=["mfma16", "mfma16trackedMax"])
+@pytest.fixture(params=[0, 64, 417], ids=["default", "rows64", "trackedMax"])
 def attn_variant(request, lib):
-    """Every selectable shape of the flash-attention kernel must pass every attention test (1 = the default: for bf16 no running
-    maximum in the hot loop + overflow check; 417 = the same shape with the running maximum tracked in every tile).  The retired
-    shapes of rounds 1-2 (VALU row sums, 8 waves, 64 rows per wave) live behind -DRZ_EXPERIMENTS and are no longer in the library."""
+    """Every selectable shape of the flash-attention kernel must pass every attention test: 0 = the default (32 query rows per wave; for
+    bf16 no running maximum in the hot loop + overflow check), 64 = 64 query rows per wave where n_pad is a multiple of 256, 417 = the
+    default shape with the running maximum tracked in every tile.  The retired shapes (VALU row sums, 8 waves, three resident tiles)
+    live behind -DRZ_EXPERIMENTS and are not in the library."""
     lib.rz_set_option(b"attn_variant", request.param)
     yield request.param
     lib.rz_set_option(b"attn_variant", 0)
@@ -96,9 +97,10 @@ def attn_variant(request, lib):
 
 @pytest.mark.parametrize("dt", ["f32", "bf16", "f16"])
 @pytest.mark.parametrize("case", [(1, 2, 257), (2, 12, 362), (1, 3, 64), (1, 1, 1), (1, 2, 1370), (1, 1, 128), (1, 2, 700), (1, 1, 192),
-                                  (1, 1, 130), (1, 1, 320)])
+                                  (1, 1, 130), (1, 1, 320), (1, 1, 256), (2, 3, 1000), (1, 1, 2300)])
 def test_flash_attention(lib, dt, case, attn_variant):
-    """n_valid not a multiple of any tile (257, 362, 1370), single key, exact tile multiples."""
+    """n_valid not a multiple of any tile (257, 362, 1370), single key, exact tile multiples; n_pad a multiple of 256 (the 64-rows-per-wave
+    shape: 700 -> 768, 192 / 130 / 256 -> 256, 1000 -> 1024, 2300 -> 2304) and not (384, 128, 1408)."""
     code, tdt = DT[dt]
     B, H, n = case
     npad = (n + 127) // 128 * 128
@@ -124,14 +126,14 @@ def test_flash_attention(lib, dt, case, attn_variant):
     assert err <= tol, (dt, case, err)
 
 
+@pytest.mark.parametrize("npad", [384, 512], ids=["rows32shape", "rows64shape"])
 @pytest.mark.parametrize("dt", ["f32", "bf16", "f16"])
-def test_flash_attention_rescale_branch(lib, attn_variant, dt):
+def test_flash_attention_rescale_branch(lib, attn_variant, dt, npad):
     """Force the row maximum to jump late (a spiked key in the last tile) — rule 26 of the HIP guide.  The spike is ~345 in
     log2 units above everything in tile 0: the tracking kernels must re-centre, the bf16 default (no running maximum in the hot
     loop) must notice the overflow of 2^(s - m) and run its tracking pass."""
     code, tdt = DT[dt]
     B, H, n = 1, 1, 300
-    npad = 384
     g = torch.Generator(device="cpu").manual_seed(5)
     q = torch.zeros(B, H, npad, 64); k = torch.zeros(B, H, npad, 64); v = torch.zeros(B, H, npad, 64)
     q[:, :, :n] = torch.randn(B, H, n, 64, generator=g) * 0.3
