@@ -81,7 +81,7 @@ __device__ __forceinline__ typename Traits<T>::frag lds_frag_row(const char* til
 // second pass already triggers at s - m > 16, which random scores reach often enough to cost more than the maxima (927 against 997 TFLOP/s).
 // ABL (only instantiated != 0 with -DRZ_EXPERIMENTS, attn_variant 1000 + ABL): TIMING ablations of the hot loop, results wrong by
 // construction (tools/attn_ablate.py): 1 no exponentials, 2 no P V / row-sum MFMAs, 4 no score MFMAs,
-// 8 no LDS fragment reads, 16 no K / V staging after tile 1, 32 no barriers.
+// 8 no LDS fragment reads, 16 no K / V staging after tile 1, 32 no barriers, 64 a quarter of the LDS fragment reads.
 // NBUF = K / V^T tiles resident in LDS (2: tile t+1 is staged while tile t is consumed; 3: tile t+2 is — two tiles of time for the
 // LDS-DMA to land, waited for with a counted vmcnt).
 template <typename T, int NW, int QT, bool LS = false, bool NOMAX = false, int ABL = 0, int NBUF = 2>
@@ -199,6 +199,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : ((QT == 4 || sizeof(T) == 4)
         f32x4 sacc[QT][4];
         auto load_k = [&](int ks, int kt) -> frag_t {
             if constexpr ((ABL & 8) != 0) { frag_t x; asm volatile("" : "=v"(x)); return x; }   // whatever the registers hold: no instruction, no CSE
+            if constexpr ((ABL & 64) != 0) { if (kt != 0) { frag_t x; asm volatile("" : "=v"(x)); return x; } }   // a quarter of the reads
             const int krb = (32 * (kt >> 1) + 4 * (kt & 1)) * 128;   // immediate
             if constexpr (ES == 4) {
                 const f32x4 lo = *reinterpret_cast<const f32x4*>(sk + koff[ks][0] + krb);
@@ -210,6 +211,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : ((QT == 4 || sizeof(T) == 4)
         };
         auto load_v = [&](int kk, int dt) -> frag_t {
             if constexpr ((ABL & 8) != 0) { frag_t x; asm volatile("" : "=v"(x)); return x; }
+            if constexpr ((ABL & 64) != 0) { if (dt != 0) { frag_t x; asm volatile("" : "=v"(x)); return x; } }
             if constexpr (ES == 4) {
                 const f32x4 lo = *reinterpret_cast<const f32x4*>(sv + voff[kk][0] + dt * 2048);
                 const f32x4 hi = *reinterpret_cast<const f32x4*>(sv + voff[kk][1] + dt * 2048);
@@ -791,7 +793,7 @@ hipError_t launch_flash_attn(int dtype, const void* q, const void* k, const void
 #define RZ_FA_ABL4(A) case 2000 + A: RZ_FA(bf16_t, 4, 4, true, true, A, 2); break;
         switch (variant) {
             RZ_FA_ABL(0) RZ_FA_ABL(1) RZ_FA_ABL(2) RZ_FA_ABL(4) RZ_FA_ABL(8) RZ_FA_ABL(16) RZ_FA_ABL(32) RZ_FA_ABL(6) RZ_FA_ABL(7) RZ_FA_ABL(48)
-            RZ_FA_ABL(56) RZ_FA_ABL(57) RZ_FA_ABL(9) RZ_FA_ABL(24)
+            RZ_FA_ABL(56) RZ_FA_ABL(57) RZ_FA_ABL(9) RZ_FA_ABL(24) RZ_FA_ABL(64) RZ_FA_ABL(80)
             RZ_FA_ABL4(0) RZ_FA_ABL4(1) RZ_FA_ABL4(8) RZ_FA_ABL4(16) RZ_FA_ABL4(32) RZ_FA_ABL4(7) RZ_FA_ABL4(48) RZ_FA_ABL4(56) RZ_FA_ABL4(57) RZ_FA_ABL4(24)
             default: return hipErrorInvalidValue;
         }

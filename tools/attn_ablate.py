@@ -18,7 +18,7 @@ vt = torch.randn(B, H, 64, npad, device="cuda").bfloat16()
 ctx = torch.empty(B, npad, H * 64, device="cuda", dtype=torch.bfloat16)
 st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 flops = 4.0 * B * H * nv * nv * 64
-names = {1: "noexp", 2: "noPV", 4: "noQK", 8: "nolds", 16: "nodma", 32: "nobar"}
+names = {1: "noexp", 2: "noPV", 4: "noQK", 8: "nolds", 16: "nodma", 32: "nobar", 64: "quarterlds"}
 for arg in sys.argv[1:] or ["0"]:
     if arg.startswith("v"):          # a plain attn_variant (v4 = product kernel, v64 = 64 query rows per wave, v417 = tracked maximum ...)
         mask = -1

@@ -14,7 +14,7 @@ for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
         key = (int(m.groups()[-1]), int(m.groups()[-4]) if len(m.groups()) == 5 else int(m.group(1)))
         rows[key][r["Counter_Name"]].append(float(r["Counter_Value"]))
         rows[key]["ns:" + r["Dispatch_Id"]] = [float(r["End_Timestamp"]) - float(r["Start_Timestamp"])]
-names = {1: "noexp", 2: "noPV", 4: "noQK", 8: "nolds", 16: "nodma", 32: "nobar"}
+names = {1: "noexp", 2: "noPV", 4: "noQK", 8: "nolds", 16: "nodma", 32: "nobar", 64: "quarterlds"}
 print(f"{'ABL':>4} {'QT':>2} {'what':28s} {'ms':>7} {'GHz':>5} {'mfma_busy':>9} {'busy*GHz':>8} {'valu/wave':>9} {'wait_any':>8} {'wait_inst':>9}")
 for (abl, qt), c in sorted(rows.items()):
     mean = lambda k: sum(c[k]) / max(len(c[k]), 1)
