@@ -24,8 +24,15 @@
 
 #include "rz_common.h"
 #include "rz_kernels.h"
+#ifdef RZ_EXPERIMENTS
+#include "attn_ks_loop.inc"
+#endif
 
 namespace rz {
+
+typedef float fa_f32x32 __attribute__((ext_vector_type(32)));
+typedef unsigned fa_u32x32 __attribute__((ext_vector_type(32)));
+typedef unsigned fa_u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int FA_QROWS = 128;   // query rows per 4-wave workgroup (the 8-wave variant covers 256)
 constexpr int FA_KEYS = 64;     // keys per KV tile
@@ -454,6 +461,371 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : ((QT == 4 || sizeof(T) == 4)
     }
 }
 
+#ifdef RZ_EXPERIMENTS
+// ---------------------------------------------------------------------------------------------
+// flash_attn_ks_kernel ("key split"): the LDS bytes a wave reads per FLOP depend only on the query rows it owns (it reads its whole share
+// of every K / V^T tile whatever the MFMA shape), and the timing ablations of flash_attn_kernel name those reads as what holds the
+// clock at 2.0 GHz.  Here a workgroup owns 256 query rows; wave (qg, kh) owns 128 of them (qg) and HALF of every 64-key tile (kh: the
+// 32 keys of 32-key step kk = kh): 8 fragment reads per 72 MFMAs instead of 16 per 36.  The two key halves of a query group run as
+// independent softmax streams with their own reference points and are merged once, through LDS, when the keys are exhausted
+// (O = O0 2^(m0 - M) + O1 2^(m1 - M), l likewise).  ~400 registers: one wave per SIMD, one workgroup per CU.
+// NOMAX as in flash_attn_kernel (reference point = the wave's maximum over ITS keys of tile 0; overflow -> tracked second pass).
+// ---------------------------------------------------------------------------------------------
+#ifndef RZ_ATTN_KS_LOOP_BF16_NOVALU        // the ablated texts exist only when the generator ran with RZ_KS_ABLATIONS=1
+#define RZ_ATTN_KS_LOOP_BF16_NOVALU RZ_ATTN_KS_LOOP_BF16
+#define RZ_ATTN_KS_LOOP_BF16_NODMA RZ_ATTN_KS_LOOP_BF16
+#define RZ_ATTN_KS_LOOP_BF16_NORDS RZ_ATTN_KS_LOOP_BF16
+#define RZ_ATTN_KS_LOOP_BF16_NOBAR RZ_ATTN_KS_LOOP_BF16
+#define RZ_ATTN_KS_LOOP_BF16_NOP1MFMA RZ_ATTN_KS_LOOP_BF16
+#define RZ_ATTN_KS_LOOP_BF16_NOPVMFMA RZ_ATTN_KS_LOOP_BF16
+#define RZ_ATTN_KS_LOOP_BF16_MFMAONLY RZ_ATTN_KS_LOOP_BF16
+#endif
+// The same decomposition in plain C++ with the running maximum tracked in every tile: what a workgroup of flash_attn_ks_kernel falls back
+// to when some 2^S left the float range (never seen on the model's data; forced by tests).  ~400 live values: hipcc spills, nobody cares.
+template <typename T>
+__device__ __noinline__ void flash_attn_ks_tracked(const T* __restrict__ q, const T* __restrict__ k, const T* __restrict__ vT, T* __restrict__ ctx,
+                                                   int64_t qk_batch_stride, int H, int n_valid, int n_pad, int b, int h, int pair, int qb, char* lds) {
+    typedef typename Traits<T>::frag frag_t;
+    static_assert(sizeof(T) == 2, "16-bit operands only");
+    constexpr int TILE = FaCfg<T>::TILE_BYTES;       // 8 KB
+    constexpr int QT = 8;                            // 16-row query tiles per wave
+    constexpr int XBUF = 36 * 1024;                  // hand-over per query group: 32 O fragments x 1 KB, then l and m (2 KB each)
+    constexpr int QROWS = 256;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int qg = wave >> 1, kh = wave & 1;
+    const int l15 = lane & 15, lg = lane >> 4;
+    const T* qbase = q + (int64_t)b * qk_batch_stride + ((int64_t)h * n_pad) * 64;
+    const char* kbase = reinterpret_cast<const char*>(k + (int64_t)b * qk_batch_stride + ((int64_t)h * n_pad) * 64);
+    const char* vbase = reinterpret_cast<const char*>(vT + ((int64_t)pair * 64) * n_pad);
+    const int64_t k_ld = 64 * 2, v_ld = (int64_t)n_pad * 2;
+
+    const int q0 = qb * QROWS + qg * 128;
+    frag_t qf[QT][2];
+#pragma unroll
+    for (int a = 0; a < QT; ++a)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+            qf[a][ks] = *reinterpret_cast<const frag_t*>(qbase + (int64_t)(q0 + a * 16 + l15) * 64 + ks * 32 + lg * 8);
+
+    // K fragment of the wave's 16-key tile kt (0, 1): row = 32 kh + 4 kt + [8 (l15 >> 2) + (l15 & 3)]; the XOR term depends on l15 only
+    const int krow = 8 * (l15 >> 2) + (l15 & 3);
+    const int ksw = swz_k(krow);
+    int koff[2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) koff[ks] = (32 * kh + krow) * 128 + (((ks * 4 + lg) ^ ksw) << 4);
+    // V^T fragment: row d = 16 dt + l15, the 8 contiguous keys 32 kh + 8 lg .. +7
+    const int voff = l15 * 128 + (((kh * 4 + lg) ^ ((l15 >> 1) & 7)) << 4);
+
+    auto stage = [&](int t, int buf) {
+        char* sk = lds + buf * TILE;
+        char* sv = lds + (2 + buf) * TILE;
+        const int key0 = t * FA_KEYS;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int row8 = (wave * 2 + i) * 8;
+            glds_rows8<1>(sk + row8 * 128, kbase + (int64_t)key0 * k_ld, k_ld, row8, lane);
+            glds_rows8(sv + row8 * 128, vbase + (int64_t)key0 * 2, v_ld, row8, lane);
+        }
+    };
+
+    f32x4 oacc[QT][4], lacc[QT], cinit[QT];
+    float mrow[QT];
+    const frag_t ones = pack8<T>(1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f);
+    auto reset = [&]() {
+#pragma unroll
+        for (int a = 0; a < QT; ++a) {
+            mrow[a] = 0.f; cinit[a] = (f32x4){0.f, 0.f, 0.f, 0.f}; lacc[a] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int c = 0; c < 4; ++c) oacc[a][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+    };
+    reset();
+    auto row_max = [&](float m0) {
+        m0 = fmaxf(m0, __shfl_xor(m0, 16, 64));
+        return fmaxf(m0, __shfl_xor(m0, 32, 64));
+    };
+
+    auto tile = [&](int t, auto first_c, auto mask_c, auto track_c) {
+        constexpr bool FIRST = decltype(first_c)::value, MASK = decltype(mask_c)::value;
+        constexpr bool TRACK = FIRST || decltype(track_c)::value;
+        const int buf = t & 1;
+        const char* sk = lds + buf * TILE;
+        const char* sv = lds + (2 + buf) * TILE;
+        frag_t kf[2][2];
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt) kf[ks][kt] = *reinterpret_cast<const frag_t*>(sk + koff[ks] + kt * (4 * 128));
+        f32x4 sacc[QT][2];
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int a = 0; a < QT; ++a) sacc[a][kt] = mma(kf[0][kt], qf[a][0], cinit[a]);
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int a = 0; a < QT; ++a) sacc[a][kt] = mma(kf[1][kt], qf[a][1], sacc[a][kt]);
+        frag_t vf[4];
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) vf[dt] = *reinterpret_cast<const frag_t*>(sv + voff + dt * 2048);
+        asm volatile("" ::: "memory");
+        if constexpr (MASK) {
+            const int key0 = t * FA_KEYS + 32 * kh + 8 * lg;
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    if (key0 + 4 * kt + r >= n_valid) {
+#pragma unroll
+                        for (int a = 0; a < QT; ++a) sacc[a][kt][r] = -INFINITY;
+                    }
+                }
+        }
+        float mx[QT];
+        if constexpr (TRACK) {
+#pragma unroll
+            for (int a = 0; a < QT; ++a) {
+                float m0 = fmaxf(fmaxf(sacc[a][0][0], sacc[a][0][1]), sacc[a][0][2]);
+                m0 = fmaxf(fmaxf(m0, sacc[a][0][3]), sacc[a][1][0]);
+                m0 = fmaxf(fmaxf(m0, sacc[a][1][1]), sacc[a][1][2]);
+                mx[a] = fmaxf(m0, sacc[a][1][3]);
+            }
+        }
+        if constexpr (FIRST) {
+#pragma unroll
+            for (int a = 0; a < QT; ++a) {
+                mx[a] = row_max(mx[a]);
+                if (mx[a] == -INFINITY) mx[a] = -1e30f;        // this half holds no live key at all (n_valid <= 32): P = 0, and the merge ignores it
+                mrow[a] = mx[a];
+                cinit[a] = (f32x4){-mx[a], -mx[a], -mx[a], -mx[a]};
+#pragma unroll
+                for (int kt = 0; kt < 2; ++kt) sacc[a][kt] -= mx[a];
+            }
+        } else if constexpr (TRACK) {
+            float any = fmaxf(fmaxf(fmaxf(mx[0], mx[1]), fmaxf(mx[2], mx[3])), fmaxf(fmaxf(mx[4], mx[5]), fmaxf(mx[6], mx[7])));
+            if (__builtin_expect(__any(any > FA_DEFER), 0)) {
+                asm volatile("" ::: "memory");
+#pragma unroll
+                for (int a = 0; a < QT; ++a) {
+                    const float delta = fmaxf(row_max(mx[a]), 0.f);
+                    const float alpha = __builtin_amdgcn_exp2f(-delta);
+                    mrow[a] += delta;
+                    cinit[a] -= delta;
+                    lacc[a] *= alpha;
+#pragma unroll
+                    for (int kt = 0; kt < 2; ++kt) sacc[a][kt] -= delta;
+#pragma unroll
+                    for (int dt = 0; dt < 4; ++dt) oacc[a][dt] *= alpha;
+                }
+                asm volatile("" ::: "memory");
+            }
+        }
+        frag_t pf[QT];
+#pragma unroll
+        for (int a = 0; a < QT; ++a) {
+            float pv[2][4];
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) pv[kt][r] = __builtin_amdgcn_exp2f(sacc[a][kt][r]);
+            pf[a] = pack8<T>(pv[0][0], pv[0][1], pv[0][2], pv[0][3], pv[1][0], pv[1][1], pv[1][2], pv[1][3]);
+        }
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+            for (int a = 0; a < QT; ++a) oacc[a][dt] = mma(vf[dt], pf[a], oacc[a][dt]);
+#pragma unroll
+        for (int a = 0; a < QT; ++a) lacc[a] = mma(ones, pf[a], lacc[a]);
+    };
+    using TrueT = std::integral_constant<bool, true>;
+    using FalseT = std::integral_constant<bool, false>;
+    const int ntiles = (n_valid + FA_KEYS - 1) / FA_KEYS;
+    const bool ragged = (n_valid % FA_KEYS) != 0;
+    const int nplain = ragged ? ntiles - 1 : ntiles;
+    auto run = [&](auto track_c) {
+        stage(0, 0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (ntiles > 1) stage(1, 1);
+        if (nplain >= 1) tile(0, TrueT{}, FalseT{}, track_c); else tile(0, TrueT{}, TrueT{}, track_c);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        for (int t = 1; t < nplain; ++t) {
+            if (t + 1 < ntiles) stage(t + 1, (t + 1) & 1);
+            tile(t, FalseT{}, FalseT{}, track_c);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+        }
+        if (ragged && ntiles > 1) tile(ntiles - 1, FalseT{}, TrueT{}, track_c);
+    };
+    run(TrueT{});
+
+    // ---- merge the two key halves of each query group (kh = 1 hands over, kh = 0 finishes), O = O^T / l ----
+    __syncthreads();                                   // every wave is done with the K / V buffers
+    char* xb = lds + qg * XBUF;
+    if (kh == 1) {
+#pragma unroll
+        for (int a = 0; a < QT; ++a) {
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) *reinterpret_cast<f32x4*>(xb + ((a * 4 + dt) * 64 + lane) * 16) = oacc[a][dt];
+            *reinterpret_cast<float*>(xb + 32768 + (a * 64 + lane) * 4) = lacc[a][0];
+            *reinterpret_cast<float*>(xb + 32768 + 2048 + (a * 64 + lane) * 4) = mrow[a];
+        }
+    }
+    __syncthreads();
+    if (kh == 0) {
+#pragma unroll
+        for (int a = 0; a < QT; ++a) {
+            const float l1 = *reinterpret_cast<const float*>(xb + 32768 + (a * 64 + lane) * 4);
+            const float m1 = *reinterpret_cast<const float*>(xb + 32768 + 2048 + (a * 64 + lane) * 4);
+            const float M = fmaxf(mrow[a], m1);
+            const float f0 = __builtin_amdgcn_exp2f(mrow[a] - M), f1 = __builtin_amdgcn_exp2f(m1 - M);
+            const float inv = 1.0f / (lacc[a][0] * f0 + l1 * f1);
+            const int qrow = q0 + a * 16 + l15;
+            T* o = ctx + ((int64_t)b * n_pad + qrow) * (H * 64) + h * 64 + lg * 4;
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                const f32x4 o1 = *reinterpret_cast<const f32x4*>(xb + ((a * 4 + dt) * 64 + lane) * 16);
+                const f32x4 v = (oacc[a][dt] * f0 + o1 * f1) * inv;
+                *reinterpret_cast<typename Traits<T>::vec4*>(o + dt * 16) = pack4<T>(v[0], v[1], v[2], v[3]);
+            }
+        }
+    }
+}
+
+
+// The kernel: everything between the workgroup's first and last instruction that touches a tile is the generated loop
+// (tools/gen_attn_ks_loop.py -> attn_ks_loop.inc; its header has the register map and the pipeline).  No reference point is subtracted
+// in the loop (P = 2^S, exact while it stays inside the float range); the two key halves are then plain sums.  A workgroup whose l or O
+// left the range — or whose l is 0 — recomputes its 256 rows with flash_attn_ks_tracked.
+// AV: 0 the kernel; 1..7 timing ablations of the generated text (results wrong by construction, no fallback).
+template <int AV>
+__global__ __launch_bounds__(256, 1) void flash_attn_ks_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, const bf16_t* __restrict__ vT,
+                                                               bf16_t* __restrict__ ctx, int64_t qk_batch_stride, int B, int H, int n_valid, int n_pad) {
+    __shared__ __attribute__((aligned(1024))) char lds[5 * 16384];   // the loop's five tile buffers; afterwards the key halves' hand-over (4 x 17 KB); the fallback's buffers
+    __shared__ int fallback;
+    const int tid = threadIdx.x, lane = tid & 63;
+    if (tid == 0) fallback = 0;                      // ordered before its readers by the loop's barriers
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int qg = wave >> 1, kh = wave & 1;
+    const int l15 = lane & 15, lg = lane >> 4;
+
+    constexpr int QROWS = 256;
+    const int nq = n_pad / QROWS;
+    const int pairs = B * H;
+    const int items = pairs * nq;
+    const int per_xcd = (items + 7) >> 3;
+    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+    const int item = xcd * per_xcd + j;
+    if (j >= per_xcd || item >= items) return;
+    const int pair = item / nq;
+    const int qb = item - pair * nq;
+    const int b = pair / H, h = pair % H;
+
+    const char* qbase = reinterpret_cast<const char*>(q + (int64_t)b * qk_batch_stride + ((int64_t)h * n_pad) * 64);
+    const char* kbase = reinterpret_cast<const char*>(k + (int64_t)b * qk_batch_stride + ((int64_t)h * n_pad) * 64);
+    const char* vbase = reinterpret_cast<const char*>(vT + ((int64_t)pair * 64) * n_pad);
+    const int v_ld = n_pad * 2;
+    const int q0 = qb * QROWS + qg * 128;
+    const int ntiles = (n_valid + FA_KEYS - 1) / FA_KEYS;
+    const bool ragged = (n_valid % FA_KEYS) != 0;
+
+    // lane constants of the loop: fragment read offsets inside a tile buffer (K at 0, V^T at 8 KB), LDS-DMA source offsets and
+    // destinations of the wave's two K and two V^T pieces per tile (rows 16 w + 8 i .. + 7; the XOR swizzles of rz_common.h)
+    const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)lds;
+    const int krow = 8 * (l15 >> 2) + (l15 & 3);
+    const int ksw = swz_k(krow);
+    const unsigned koff0 = lds0 + (unsigned)((32 * kh + krow) * 128 + (((0 * 4 + lg) ^ ksw) << 4));
+    const unsigned koff1 = lds0 + (unsigned)((32 * kh + krow) * 128 + (((1 * 4 + lg) ^ ksw) << 4));
+    const unsigned voffa = lds0 + 8192u + (unsigned)(l15 * 128 + (((kh * 4 + lg) ^ ((l15 >> 1) & 7)) << 4));
+    unsigned dk[2], dv[2], ldsk[2], ldsv[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int row8 = (wave * 2 + i) * 8, r = row8 + (lane >> 3);
+        dk[i] = (unsigned)(r * 128 + (((lane & 7) ^ swz_k(r)) << 4));
+        dv[i] = (unsigned)(r * v_ld + (((lane & 7) ^ swz_std(r)) << 4));
+        ldsk[i] = lds0 + (unsigned)(row8 * 128);
+        ldsv[i] = lds0 + 8192u + (unsigned)(row8 * 128);
+    }
+    const unsigned qoff = (unsigned)((q0 + l15) * 128 + lg * 16);
+    const int vg = (n_valid - (ntiles - 1) * FA_KEYS) - (32 * kh + 8 * lg);      // live keys of the lane's 8-key group in the last tile
+    const uint64_t qb64 = (uint64_t)qbase, kb64 = (uint64_t)kbase, vb64 = (uint64_t)vbase;
+    fa_f32x32 o0, o1, o2, o3, ls;
+#define RZ_KS_ASM(TEXT)                                                                                                                   \
+    asm volatile(TEXT                                                                                                                     \
+                 : "={a[0:31]}"(o0), "={a[32:63]}"(o1), "={a[64:95]}"(o2), "={a[96:127]}"(o3), "={a[128:159]}"(ls)                        \
+                 : [koff0] "v"(koff0), [koff1] "v"(koff1), [voff] "v"(voffa), [dk0] "v"(dk[0]), [dk1] "v"(dk[1]), [dv0] "v"(dv[0]),        \
+                   [dv1] "v"(dv[1]), [qoff] "v"(qoff), [vg] "v"(vg), [klo] "s"((unsigned)kb64), [khi] "s"((unsigned)(kb64 >> 32)),         \
+                   [vlo] "s"((unsigned)vb64), [vhi] "s"((unsigned)(vb64 >> 32)), [qlo] "s"((unsigned)qb64), [qhi] "s"((unsigned)(qb64 >> 32)), \
+                   [ntl] "s"((unsigned)ntiles), [n] "s"((unsigned)ntiles), [mk] "s"(ragged ? (unsigned)(ntiles - 1) : 0xffffffffu), [ldsk0] "s"(ldsk[0]),     \
+                   [ldsk1] "s"(ldsk[1]), [ldsv0] "s"(ldsv[0]), [ldsv1] "s"(ldsv[1])                                                       \
+                 : RZ_ATTN_KS_CLOBBERS)
+    if constexpr (AV == 0) RZ_KS_ASM(RZ_ATTN_KS_LOOP_BF16);
+    else if constexpr (AV == 1) RZ_KS_ASM(RZ_ATTN_KS_LOOP_BF16_NOVALU);
+    else if constexpr (AV == 2) RZ_KS_ASM(RZ_ATTN_KS_LOOP_BF16_NODMA);
+    else if constexpr (AV == 3) RZ_KS_ASM(RZ_ATTN_KS_LOOP_BF16_NORDS);
+    else if constexpr (AV == 4) RZ_KS_ASM(RZ_ATTN_KS_LOOP_BF16_NOBAR);
+    else if constexpr (AV == 5) RZ_KS_ASM(RZ_ATTN_KS_LOOP_BF16_NOP1MFMA);
+    else if constexpr (AV == 6) RZ_KS_ASM(RZ_ATTN_KS_LOOP_BF16_NOPVMFMA);
+    else if constexpr (AV == 8) RZ_KS_ASM(RZ_ATTN_KS_LOOP_BF16);          // the full text without the fallback (debugging)
+    else RZ_KS_ASM(RZ_ATTN_KS_LOOP_BF16_MFMAONLY);
+#undef RZ_KS_ASM
+
+    // ---- the key halves are plain sums.  Wave (qg, kh) finishes the query tiles 4 kh .. 4 kh + 3 of its group and hands the other four
+    // (16 O fragments + their l) to its partner through LDS ----
+    __syncthreads();                                   // every wave is done with the tile buffers
+    char* mine = lds + wave * 17408;
+    const char* theirs = lds + (wave ^ 1) * 17408;
+    auto frag_of = [&](auto a_c, int dt) -> f32x4 {    // O fragment (a, dt) out of the pinned 32-float rows: a is a compile-time constant
+        constexpr int a = decltype(a_c)::value;
+        const fa_f32x32& r = (a >> 1) == 0 ? o0 : (a >> 1) == 1 ? o1 : (a >> 1) == 2 ? o2 : o3;
+        const int e = (a & 1) * 16 + dt * 4;
+        return (f32x4){r[e], r[e + 1], r[e + 2], r[e + 3]};
+    };
+    auto give = [&](auto a0_c) {
+        constexpr int a0 = decltype(a0_c)::value;
+        auto one = [&](auto i_c) {
+            constexpr int i = decltype(i_c)::value;
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt)
+                *reinterpret_cast<f32x4*>(mine + ((i * 4 + dt) * 64 + lane) * 16) = frag_of(std::integral_constant<int, a0 + i>{}, dt);
+            *reinterpret_cast<float*>(mine + 16384 + (i * 64 + lane) * 4) = ls[4 * (a0 + i)];
+        };
+        one(std::integral_constant<int, 0>{}); one(std::integral_constant<int, 1>{}); one(std::integral_constant<int, 2>{}); one(std::integral_constant<int, 3>{});
+    };
+    bool bad = false;
+    auto left_range = [](float x) { return (__float_as_uint(x) & 0x7f800000u) == 0x7f800000u; };      // inf / nan (built with -fno-honor-nans)
+    auto keep = [&](auto a0_c) {
+        constexpr int a0 = decltype(a0_c)::value;
+        auto one = [&](auto i_c) {
+            constexpr int i = decltype(i_c)::value;
+            const float l = ls[4 * (a0 + i)] + *reinterpret_cast<const float*>(theirs + 16384 + (i * 64 + lane) * 4);
+            bad |= left_range(l) || l == 0.f;
+            const float inv = 1.0f / l;
+            bf16_t* o = ctx + ((int64_t)b * n_pad + q0 + (a0 + i) * 16 + l15) * (H * 64) + h * 64 + lg * 4;
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                const f32x4 s = frag_of(std::integral_constant<int, a0 + i>{}, dt) + *reinterpret_cast<const f32x4*>(theirs + ((i * 4 + dt) * 64 + lane) * 16);
+                bad |= left_range(s[0]) || left_range(s[1]) || left_range(s[2]) || left_range(s[3]);
+                const f32x4 v = s * inv;
+                *reinterpret_cast<Traits<bf16_t>::vec4*>(o + dt * 16) = pack4<bf16_t>(v[0], v[1], v[2], v[3]);
+            }
+        };
+        one(std::integral_constant<int, 0>{}); one(std::integral_constant<int, 1>{}); one(std::integral_constant<int, 2>{}); one(std::integral_constant<int, 3>{});
+    };
+    if (kh == 0) give(std::integral_constant<int, 4>{}); else give(std::integral_constant<int, 0>{});
+    __syncthreads();
+    if (kh == 0) keep(std::integral_constant<int, 0>{}); else keep(std::integral_constant<int, 4>{});
+    if (AV == 0) {
+        if (__any(bad) && lane == 0) fallback = 1;
+        __syncthreads();                               // also: the hand-over buffers have been read
+        if (__builtin_expect(fallback != 0, 0))
+            flash_attn_ks_tracked<bf16_t>(q, k, vT, ctx, qk_batch_stride, H, n_valid, n_pad, b, h, pair, qb, lds);
+    }
+}
+
+#endif
 // ---------------------------------------------------------------------------------------------
 // flash_attn_split_kernel: the fp32 mode's attention on the f16 matrix pipe.  Every fp32 operand x is carried as two f16 planes,
 // hi = f16(x) and lo = f16(x - hi) (x - hi is exact in fp32, so hi + lo holds 22 mantissa bits), and every product as three MFMAs with
@@ -799,6 +1171,13 @@ hipError_t launch_flash_attn(int dtype, const void* q, const void* k, const void
         }
 #undef RZ_FA_ABL
 #undef RZ_FA_ABL4
+        return hipGetLastError();
+    }
+    if (variant >= 128 && variant < 137 && dtype == DT_BF16 && n_pad % 256 == 0) {     // key-split kernel (and its timing ablations)
+        const dim3 grid(((B * H * (n_pad / 256) + 7) / 8) * 8), block(256);
+#define RZ_KS(AVV) case 128 + AVV: hipLaunchKernelGGL((flash_attn_ks_kernel<AVV>), grid, block, 0, s, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)vT, (bf16_t*)ctx, qk_batch_stride, B, H, n_valid, n_pad); break;
+        switch (variant) { RZ_KS(0) RZ_KS(1) RZ_KS(2) RZ_KS(3) RZ_KS(4) RZ_KS(5) RZ_KS(6) RZ_KS(7) RZ_KS(8) }
+#undef RZ_KS
         return hipGetLastError();
     }
     if (dtype != DT_F32) {
