@@ -341,7 +341,8 @@ def main():
     ap.add_argument("--vision-chunk", type=int, default=None, help="images per internal pass of the vision encoder (0 = whole batch)")
     ap.add_argument("--mlp-chunk", type=int, default=None, help="images per fc1->fc2 pass (-1 = auto, 0 = whole batch)")
     ap.add_argument("--vision-streams", type=int, default=None, help="2 = split the batch over two internal HIP streams")
-    ap.add_argument("--gemm-variant", type=int, default=None, help="A/B switch: 0 auto, 1 / 3 / 7 / 8 / 10 force that GEMM kernel (include/radzero_hip.h)")
+    ap.add_argument("--gemm-variant", type=int, default=None, help="A/B switch: 0 auto, 1 / 3 / 7 / 8 / 12 force that GEMM kernel (include/radzero_hip.h)")
+    ap.add_argument("--gemm-raster", type=int, default=None, help="A/B switch (gemm12.hip): tile order inside an XCD, 0 = 4 x tiles_n groups, S > 0 = slab walk with <= S n tiles per slab")
     args = ap.parse_args()
 
     # HSA reads its environment at hsa_init, i.e. at the first torch.cuda call below: set these before anything touches the GPU
@@ -376,6 +377,8 @@ def main():
         _lib.check(_lib.load().rz_set_option(b"vision_streams", args.vision_streams), "rz_set_option")
     if args.gemm_variant is not None:
         _lib.check(_lib.load().rz_set_option(b"gemm_variant", args.gemm_variant), "rz_set_option")
+    if args.gemm_raster is not None:
+        _lib.check(_lib.load().rz_set_option(b"gemm_raster", args.gemm_raster), "rz_set_option")
 
     cfg = RadZeroConfig()
     sd = node_shared_state_dict(cfg, 20260103, local_rank, use_dist and world > 1)

@@ -16,7 +16,9 @@ CSRC = os.path.join(PKG_DIR, "csrc")
 # its own library and object directory; the product and every test use the plain build.
 EXPERIMENTS = os.environ.get("RZ_EXPERIMENTS") == "1"
 LIB_PATH = os.environ.get("RZ_LIB_PATH") or os.path.join(PKG_DIR, "libradzero_hip_experiments.so" if EXPERIMENTS else "libradzero_hip.so")   # RZ_LIB_PATH: A/B of two builds in one gpurun call
-SOURCES = ["gemm.hip", "gemm7.hip", "gemm8.hip", "gemm10.hip", "gemm11.hip", "attention.hip", "rowops.hip", "vlcabs.hip", "preprocess.hip", "api.hip"]
+SOURCES = ["gemm.hip", "gemm7.hip", "gemm8.hip", "gemm12.hip", "attention.hip", "rowops.hip", "vlcabs.hip", "preprocess.hip", "api.hip"]
+if EXPERIMENTS:
+    SOURCES += ["gemm10.hip", "gemm11.hip"]      # retired K-loop experiments (round 3): never faster than gemm8 inside the step
 # attention.hip: fmaxf chains on MFMA outputs fuse into v_max3_f32 without a canonicalising v_max each
 EXTRA_FLAGS = {"attention.hip": ["-fno-honor-nans"]}
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")

@@ -39,10 +39,11 @@ struct Options {
     int sim_op;           // VL-CABS similarity: 0 = "cos" (released config), 1 = "dot" (losses.py:214-215)
     int pad_rows;         // token rows per image: 0 = multiple of 128, of 256 when that costs < 2 % more rows | 128 | 256 = always that multiple
     int f32_split_guard;  // fp32 mode: 1 = a forward whose f16 planes overflowed is repeated on the exact-fp32 kernels (default)
+    int gemm_raster;      // gemm12.hip: tile order inside an XCD (GemmArgs::raster): 0 = 4 x tiles_n groups | S > 0 = slab walk, <= S n tiles per slab
 };
-Options g_opt = {0, 1, 0, 0, 0, 1, 1, 1, 0, 0, 1};
+Options g_opt = {0, 1, 0, 0, 0, 1, 1, 1, 0, 0, 1, 0};
 const Options kInherit = {RZ_OPT_INHERIT, RZ_OPT_INHERIT, RZ_OPT_INHERIT, RZ_OPT_INHERIT, RZ_OPT_INHERIT, RZ_OPT_INHERIT, RZ_OPT_INHERIT,
-                          RZ_OPT_INHERIT, RZ_OPT_INHERIT, RZ_OPT_INHERIT, RZ_OPT_INHERIT};
+                          RZ_OPT_INHERIT, RZ_OPT_INHERIT, RZ_OPT_INHERIT, RZ_OPT_INHERIT, RZ_OPT_INHERIT};
 int* option_field(Options& o, const char* name) {
     if (!strcmp(name, "vision_chunk")) return &o.vision_chunk;
     if (!strcmp(name, "vision_streams")) return &o.vision_streams;
@@ -55,6 +56,7 @@ int* option_field(Options& o, const char* name) {
     if (!strcmp(name, "sim_op")) return &o.sim_op;
     if (!strcmp(name, "pad_rows")) return &o.pad_rows;
     if (!strcmp(name, "f32_split_guard")) return &o.f32_split_guard;
+    if (!strcmp(name, "gemm_raster")) return &o.gemm_raster;
     return nullptr;
 }
 inline int pick(int own, int process_wide) { return own == RZ_OPT_INHERIT ? process_wide : own; }
@@ -146,6 +148,7 @@ struct rz_model {
     int o_mlp_chunk() const { return pick(opt.mlp_chunk, g_opt.mlp_chunk); }
     int o_attn_variant() const { return pick(opt.attn_variant, g_opt.attn_variant); }
     int o_gemm_variant() const { return pick(opt.gemm_variant, g_opt.gemm_variant); }
+    int o_gemm_raster() const { return pick(opt.gemm_raster, g_opt.gemm_raster); }
     bool o_gemm_f32_split() const { return pick(opt.gemm_f32_split, g_opt.gemm_f32_split) != 0 && !force_exact; }
     bool o_attn_f32_split() const { return pick(opt.attn_f32_split, g_opt.attn_f32_split) != 0 && !force_exact; }
     bool o_ln_fused() const { return pick(opt.ln_fused, g_opt.ln_fused) != 0; }
@@ -432,7 +435,7 @@ int gemm(rz_model* m, int epi, const void* A, int64_t lda, const void* W, int64_
     GemmArgs g;
     g.A = A; g.lda = lda; g.W = W; g.ldw = ldw; g.M = M; g.N = N; g.K = K; g.bias = bias; g.out = out; g.ldo = ldo;
     g.scale = scale; g.resid = resid; g.ldr = ldr; g.rows_per_image = rpi; g.heads_total = heads; g.plane_off = plane_off;
-    g.variant = m->o_gemm_variant(); g.ovf_flag = (unsigned*)m->ovf.p;
+    g.variant = m->o_gemm_variant(); g.raster = m->o_gemm_raster(); g.ovf_flag = (unsigned*)m->ovf.p;
     ProfScope ps(m, RZ_PROF_GEMM, s);
     if (m->dt == RZ_F32 && m->o_gemm_f32_split()) {
         bool done = false;
@@ -490,7 +493,7 @@ int gemm_ln(rz_model* m, int epi, const void* hb, const Tensor& wf, const Tensor
     GemmArgs g;
     g.A = hb; g.lda = m->D; g.W = wf.p; g.ldw = m->D; g.M = M; g.N = N; g.K = m->D; g.bias = (const float*)c2.p; g.out = out; g.ldo = ldo;
     g.scale = (const float*)c1.p; g.resid = nullptr; g.ldr = 0; g.rows_per_image = np; g.heads_total = heads;
-    g.out2 = out2; g.heads_total2 = heads2; g.split_n = split_n; g.ln_stat = stat; g.variant = m->o_gemm_variant();
+    g.out2 = out2; g.heads_total2 = heads2; g.split_n = split_n; g.ln_stat = stat; g.variant = m->o_gemm_variant(); g.raster = m->o_gemm_raster();
     ProfScope ps(m, RZ_PROF_GEMM, s);
     RZ_HIP(launch_gemm(m->dt, epi, g, s));
     return 0;
@@ -503,7 +506,7 @@ int gemm_resid_ln(rz_model* m, const void* A, int64_t lda, const Tensor& W, cons
     GemmArgs g;
     g.A = A; g.lda = lda; g.W = W.p; g.ldw = K; g.M = M; g.N = m->D; g.K = K; g.bias = (const float*)bias.p; g.out = nullptr; g.ldo = 0;
     g.scale = (const float*)ls.p; g.resid = h; g.ldr = m->D; g.rows_per_image = np; g.heads_total = 0; g.ln_part = part; g.ln_hb = hb; g.ln_gamma = (const float*)next_gamma.p; g.ln_mu = mu;
-    g.variant = m->o_gemm_variant();
+    g.variant = m->o_gemm_variant(); g.raster = m->o_gemm_raster();
     {
         ProfScope ps(m, RZ_PROF_GEMM, s);
         RZ_HIP(launch_gemm(m->dt, EPI_RESID_SCALE_LN, g, s));
@@ -518,7 +521,7 @@ int gemm_qkv(rz_model* m, const void* xn, const DinoBlock& b, int M, int np, voi
     GemmArgs g;
     g.A = xn; g.lda = D; g.W = b.wqkv.p; g.ldw = D; g.M = M; g.N = 3 * D; g.K = D; g.bias = (const float*)b.bqkv.p;
     g.out = qk; g.ldo = 0; g.scale = nullptr; g.resid = nullptr; g.ldr = 0; g.rows_per_image = np; g.heads_total = 2 * H;
-    g.out2 = vt; g.heads_total2 = H; g.split_n = 2 * D; g.variant = m->o_gemm_variant();
+    g.out2 = vt; g.heads_total2 = H; g.split_n = 2 * D; g.variant = m->o_gemm_variant(); g.raster = m->o_gemm_raster();
     if (gemm_qkv_fused_ok(m->dt, g)) {
         ProfScope ps(m, RZ_PROF_GEMM, s);
         RZ_HIP(launch_gemm(m->dt, EPI_QKV, g, s));
@@ -887,7 +890,7 @@ static int vision_forward_once(rz_handle_t m, const float* px, int B, int C, int
                 if ((rc = gemm_qkv(m, xn, b, M, np, qkb, vtb, s))) return rc;
             } else {
                 GemmArgs probe;
-                probe.A = xn; probe.lda = D; probe.W = b.wqkv.p; probe.ldw = D; probe.M = M; probe.N = 3 * D; probe.K = D; probe.out2 = vtb; probe.split_n = 2 * D; probe.variant = m->o_gemm_variant();
+                probe.A = xn; probe.lda = D; probe.W = b.wqkv.p; probe.ldw = D; probe.M = M; probe.N = 3 * D; probe.K = D; probe.out2 = vtb; probe.split_n = 2 * D; probe.variant = m->o_gemm_variant(); probe.raster = m->o_gemm_raster();
                 if (gemm_qkv_fused_ok(m->dt, probe)) {
                     if ((rc = gemm_ln(m, EPI_QKV_LN, xn, b.wqkv, b.c1qkv, b.c2qkv, stat, M, 3 * D, np, qkb, 0, 2 * H, vtb, H, 2 * D, s))) return rc;
                 } else {        // small batches: the same projection as q|k and v launches of the 128x128 kernel
@@ -1177,7 +1180,7 @@ int rz_gemm(int dtype, int epilogue, const void* a, const void* w, const float* 
     memset(&g, 0, sizeof g);
     g.A = a; g.lda = K; g.W = w; g.ldw = K; g.M = M; g.N = N; g.K = K; g.bias = bias; g.out = out; g.ldo = N;
     g.rows_per_image = M;
-    g.variant = g_opt.gemm_variant;
+    g.variant = g_opt.gemm_variant; g.raster = g_opt.gemm_raster;
     RZ_HIP(launch_gemm(dtype, epilogue, g, (hipStream_t)stream));
     return 0;
 }
@@ -1195,7 +1198,7 @@ int rz_gemm_ex(int dtype, int epilogue, const void* a, int64_t lda, const void* 
     GemmArgs g;
     g.A = a; g.lda = lda; g.W = w; g.ldw = ldw; g.M = M; g.N = N; g.K = K; g.bias = bias; g.out = out; g.ldo = ldo;
     g.scale = scale; g.resid = resid; g.ldr = ldr; g.rows_per_image = rows_per_image > 0 ? rows_per_image : M; g.heads_total = heads_total;
-    g.variant = g_opt.gemm_variant;
+    g.variant = g_opt.gemm_variant; g.raster = g_opt.gemm_raster;
     RZ_HIP(launch_gemm(dtype, epilogue, g, (hipStream_t)stream));
     return 0;
 }
@@ -1209,7 +1212,7 @@ int rz_gemm_qkv(int dtype, const void* x, const void* w, const float* bias, void
     GemmArgs g;
     g.A = x; g.lda = D; g.W = w; g.ldw = D; g.M = M; g.N = 3 * D; g.K = D; g.bias = bias; g.out = qk; g.ldo = 0;
     g.scale = nullptr; g.resid = nullptr; g.ldr = 0; g.rows_per_image = rows_per_image; g.heads_total = 2 * heads;
-    g.out2 = vt; g.heads_total2 = heads; g.split_n = 2 * D; g.variant = g_opt.gemm_variant;
+    g.out2 = vt; g.heads_total2 = heads; g.split_n = 2 * D; g.variant = g_opt.gemm_variant; g.raster = g_opt.gemm_raster;
     const bool fused = gemm_qkv_fused_ok(dtype, g);
     if (fused_out) *fused_out = fused ? 1 : 0;
     if (fused) {
@@ -1282,7 +1285,7 @@ int rz_patch_embed(int dtype, const float* px, int B, int C, int Himg, int Wimg,
     RZ_HIP(launch_im2col(dtype, px, ws, B, C, Himg, Wimg, P, gh, gw, n_pad, k_pad, s));
     GemmArgs g;
     g.A = ws; g.lda = k_pad; g.W = weight; g.ldw = k_pad; g.M = B * n_pad; g.N = 768; g.K = k_pad; g.bias = nullptr; g.out = out; g.ldo = 768;
-    g.scale = table; g.resid = nullptr; g.ldr = 0; g.rows_per_image = n_pad; g.heads_total = 0; g.variant = g_opt.gemm_variant;
+    g.scale = table; g.resid = nullptr; g.ldr = 0; g.rows_per_image = n_pad; g.heads_total = 0; g.variant = g_opt.gemm_variant; g.raster = g_opt.gemm_raster;
     RZ_HIP(launch_gemm(dtype, EPI_PATCH, g, s));
     return 0;
 }

@@ -43,6 +43,7 @@ struct GemmArgs {
     const float* ln_mu = nullptr;    // EPI_RESID_SCALE_LN: [M] centring constant of each row (its mean before this update): ln_hb = T((x - ln_mu[m]) * ln_gamma[n])
     int64_t plane_off = 0;        // hi/lo-split outputs (fp32 mode, EPI_HEADS / EPI_VT): elements from the hi plane to the lo plane
     unsigned* ovf_flag = nullptr; // hi/lo-split outputs: word that receives 1 when a value leaves the f16 range (rz_common.h flag_f16_range)
+    int raster = 0;               // gemm12.hip tile order inside an XCD: 0 = gemm8's (4 x tiles_n groups) | S > 0 = slab walk, slabs of <= S n tiles
     int variant = 0;              // kernel choice: 0 auto | 1 128x128 two-stage | 3 256x256 two-stage | 7 staggered 8-phase (gemm7.hip) | 8 persistent (gemm8.hip) | 10 persistent, 4 waves x 128x128, asm K loop (gemm10.hip) | 11 persistent, 8 waves, one phase per K tile (gemm11.hip)
 };
 
@@ -62,6 +63,8 @@ bool gemm_v10_ok(int dtype, int epi, const GemmArgs& g);
 bool gemm_v11_ok(int dtype, int epi, const GemmArgs& g);
 hipError_t launch_gemm_v11(int dtype, int epi, const GemmArgs& g, hipStream_t s);  // persistent, 8 waves, ONE LOAD / MFMA phase per K tile (gemm11.hip)
 hipError_t launch_gemm_v10(int dtype, int epi, const GemmArgs& g, hipStream_t s);  // persistent, 4 waves x 128x128, asm K loop (gemm10.hip)
+bool gemm_v12_ok(int dtype, int epi, const GemmArgs& g);
+hipError_t launch_gemm_v12(int dtype, int epi, const GemmArgs& g, hipStream_t s);  // persistent, two 256x128 workgroups per CU (gemm12.hip)
 hipError_t launch_gemm_v7(int variant, int dtype, int epi, const GemmArgs& g, hipStream_t s);
 hipError_t launch_gemm_v7_f16_out(int epi, const GemmArgs& g, bool split_out, hipStream_t s);   // f16 operands, fp32 / hi-lo-split outputs
 

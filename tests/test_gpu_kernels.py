@@ -196,7 +196,7 @@ def test_upsample(lib, g, size):
     assert (out_s.cpu() - torch.sigmoid(ref)).abs().max().item() <= 1e-5
 
 
-@pytest.mark.parametrize("variant", [1, 3, 7, 8, 10, 11])
+@pytest.mark.parametrize("variant", [1, 3, 7, 8, 12])
 @pytest.mark.parametrize("dt", ["f32", "bf16", "f16"])
 def test_gemm_variants_agree(lib, variant, dt):
     """All tile variants (128x128 two-stage, 256x256 two-stage, 256x256 staggered 8-phase) against the fp32 reference,
@@ -224,14 +224,15 @@ def test_gemm_variants_agree(lib, variant, dt):
     assert (resid - (resid0 + scale * ref)).abs().max().item() <= 2e-4 * math.sqrt(K / 64)
 
 
-@pytest.mark.parametrize("variant", [7, 8, 10, 11])
+@pytest.mark.parametrize("variant", [7, 8, 12])
 @pytest.mark.parametrize("K", [128, 192, 256, 640, 768, 3072])
 @pytest.mark.parametrize("dt", ["bf16", "f16"])
 @pytest.mark.parametrize("M", [4096, 33792])
 def test_gemm_pipelined_variants_bitwise(lib, variant, K, dt, M):
     """The deep-pipelined 256x256 kernels (gemm7.hip: counted vmcnt, raw barriers, staggered wave groups; gemm8.hip: the
-    same loop run persistently, operand stream continuous across output tiles, wave-private epilogues; gemm10.hip: four waves
-    x 128x128, accumulators in AGPRs, K loop in generated inline asm, one barrier per K tile) accumulate
+    same loop run persistently, operand stream continuous across output tiles, wave-private epilogues; gemm12.hip: two independent
+    256x128 workgroups per CU, each with an 8-slot operand ring addressed by a run-time position, K = 640 gives 10 K tiles = a ring
+    phase that differs from tile to tile) accumulate
     every output element over K in the same order with the same MFMA as the 256x256 two-stage kernel, so the results
     must be IDENTICAL bit for bit: any LDS-DMA race (a fragment read before its piece landed, a stage overwritten
     before it was read) shows up as a difference.  K = 128 / 192 exercise the tail-only and one-iteration loops;
@@ -280,7 +281,7 @@ def test_gemm_staggered_race_screen_full_size(lib, shape):
     try:
         check(lib, lib.rz_gemm_ex(1, 0, P(a), K, P(w), K, P(bias), P(ref), N, None, None, 0, M, N // 64, M, N, K, stream()))
         outs = []
-        for variant in (7, 8, 10, 11):
+        for variant in (7, 8, 12):
             check(lib, lib.rz_set_option(b"gemm_variant", variant))
             these = [torch.zeros_like(ref) for _ in range(10)]
             for o in these:
@@ -364,11 +365,38 @@ def test_fused_layernorm_model_path_matches_standalone(lib, dt, rows, images):
         m.close()
 
 
+@pytest.mark.parametrize("raster", [0, 4, 8, 9])
+@pytest.mark.parametrize("shape", [(8192, 3072, 768), (5376, 2304, 768), (33792, 768, 3072), (2304, 384, 640)])
+def test_gemm_v12_tile_walks_bitwise(lib, shape, raster):
+    """gemm12.hip's tile orders (option gemm_raster: 0 = gemm8's 4 x tiles_n groups over an id range per XCD; S > 0 = every XCD walks its
+    band of m tiles once per slab of <= S n tiles): every output tile must be produced exactly once whatever the order, bit-identical to
+    the two-stage kernel.  Shapes: 24 / 18 / 6 / 3 n tiles (slabs of 8+8+8, 9+9, one slab; 3 tiles with S = 4 > tiles_n), 32 / 21 / 132 / 9
+    m tiles (bands of 4 / 3 / 17 / 2 m tiles: the last XCDs get short or empty bands)."""
+    M, N, K = shape
+    g = torch.Generator(device="cpu").manual_seed(N + K + raster)
+    a = (torch.randn(M, K, generator=g) * 0.7).bfloat16().cuda()
+    w = (torch.randn(N, K, generator=g) / math.sqrt(K)).bfloat16().cuda()
+    bias = torch.randn(N, generator=g).cuda()
+    ref = torch.empty(M, N, dtype=torch.bfloat16, device="cuda")
+    out = torch.zeros_like(ref)
+    try:
+        check(lib, lib.rz_set_option(b"gemm_variant", 3))
+        check(lib, lib.rz_gemm_ex(1, 1, P(a), K, P(w), K, P(bias), P(ref), N, None, None, 0, M, N // 64, M, N, K, stream()))
+        check(lib, lib.rz_set_option(b"gemm_variant", 12))
+        check(lib, lib.rz_set_option(b"gemm_raster", raster))
+        check(lib, lib.rz_gemm_ex(1, 1, P(a), K, P(w), K, P(bias), P(out), N, None, None, 0, M, N // 64, M, N, K, stream()))
+        torch.cuda.synchronize()
+    finally:
+        lib.rz_set_option(b"gemm_variant", 0)
+        lib.rz_set_option(b"gemm_raster", 0)
+    assert torch.equal(out, ref)
+
+
 @pytest.mark.parametrize("dt", ["bf16", "f16"])
-def test_gemm_v10_v11_whole_model_bit_identical_to_v8(dt):
-    """gemm10.hip inside the model (merged q|k|v with both operand orders, fused-LayerNorm producer / consumer epilogues, GELU, patch
+def test_gemm_v12_whole_model_bit_identical_to_v8(dt):
+    """gemm12.hip inside the model (merged q|k|v with both operand orders, fused-LayerNorm producer / consumer epilogues, GELU, patch
     table, residual epilogues at every tile seam) against gemm8.hip: the K order per accumulator and the epilogue arithmetic are the
-    same, so the vision tokens and the scores must not differ by a bit — 2 images of 1024^2 (42 x 3 ... 42 x 12 tiles per GEMM)."""
+    same, so the vision tokens must not differ by a bit — 4 images of 1024^2 (84 x 6 ... 84 x 24 tiles per GEMM), both tile walks."""
     from radzero_amd.config import RadZeroConfig
     from radzero_amd.modeling import RadZeroModel
     from radzero_amd.weights import make_state_dict
@@ -378,17 +406,18 @@ def test_gemm_v10_v11_whole_model_bit_identical_to_v8(dt):
     g = torch.Generator(device="cuda").manual_seed(5)
     px = torch.randn((4, 3, 1024, 1024), generator=g, device="cuda")
     outs = {}
-    for variant in (8, 10, 11):
+    for variant, raster in ((8, 0), (12, 0), (12, 8)):
         m = RadZeroModel.from_state_dict(sd, cfg, torch_dtype=tdt, device="cuda:0").eval()
         try:
             m.set_model_option("gemm_variant", variant)
+            m.set_model_option("gemm_raster", raster)
             toks = [m.forward_vision_model(px)["vision_tokens"].clone() for _ in range(3)]
             torch.cuda.synchronize()
             assert torch.equal(toks[0], toks[1]) and torch.equal(toks[0], toks[2])
-            outs[variant] = toks[0]
+            outs[(variant, raster)] = toks[0]
         finally:
             m.close()
-    assert torch.isfinite(outs[10]).all() and torch.equal(outs[8], outs[10]) and torch.equal(outs[8], outs[11])
+    assert torch.isfinite(outs[(12, 0)]).all() and torch.equal(outs[(8, 0)], outs[(12, 0)]) and torch.equal(outs[(8, 0)], outs[(12, 8)])
 
 
 # ---- the text side and the patch embedding, kernel by kernel (SURVEY.md §8(b) list) ------------------------------
