@@ -336,13 +336,13 @@ def main():
     ap.add_argument("--all-kernel-events", action="store_true", help="A/B: record HIP events for every kernel family inside the timed region (default: "
                     "the dominant kernel's family only; the other families are timed over two extra, un-timed steps)")
     ap.add_argument("--no-other-configs", action="store_true", help="skip the short runs of BASELINE configs[3], configs[4] per-GPU shape and the fp32 mode")
-    ap.add_argument("--attn-variant", type=int, default=None, help="A/B switch (rz_set_option): 0 = default (4 waves x 32 query rows; bf16 without the running maximum), 64 = 64 query rows per wave, 417 = running maximum tracked")
+    ap.add_argument("--attn-variant", type=int, default=None, help="A/B switch (rz_set_option): 0 = default (4 waves x 32 query rows; bf16 without the running maximum), 417 = running maximum tracked; RZ_EXPERIMENTS=1 library: 64 / 128 / ...")
     ap.add_argument("--ln-fused", type=int, default=None, help="A/B switch: 1 fused LayerNorm (default, 16-bit modes), 0 stand-alone LayerNorm kernels")
-    ap.add_argument("--vision-chunk", type=int, default=None, help="images per internal pass of the vision encoder (0 = whole batch)")
-    ap.add_argument("--mlp-chunk", type=int, default=None, help="images per fc1->fc2 pass (-1 = auto, 0 = whole batch)")
-    ap.add_argument("--vision-streams", type=int, default=None, help="2 = split the batch over two internal HIP streams")
-    ap.add_argument("--gemm-variant", type=int, default=None, help="A/B switch: 0 auto, 1 / 3 / 7 / 8 / 12 force that GEMM kernel (include/radzero_hip.h)")
-    ap.add_argument("--gemm-raster", type=int, default=None, help="A/B switch (gemm12.hip): tile order inside an XCD, 0 = 4 x tiles_n groups, S > 0 = slab walk with <= S n tiles per slab")
+    ap.add_argument("--vision-chunk", type=int, default=None, help="RZ_EXPERIMENTS=1 library only: images per internal pass of the vision encoder (0 = whole batch)")
+    ap.add_argument("--mlp-chunk", type=int, default=None, help="RZ_EXPERIMENTS=1 library only: images per fc1->fc2 pass (-1 = auto, 0 = whole batch)")
+    ap.add_argument("--vision-streams", type=int, default=None, help="RZ_EXPERIMENTS=1 library only: 2 = split the batch over two internal HIP streams")
+    ap.add_argument("--gemm-variant", type=int, default=None, help="A/B switch: 0 auto, 1 / 3 / 7 / 8 force that GEMM kernel (include/radzero_hip.h); RZ_EXPERIMENTS=1 library: 10 / 11 / 12")
+    ap.add_argument("--gemm-raster", type=int, default=None, help="RZ_EXPERIMENTS=1 library only (gemm12.hip): tile order inside an XCD, 0 = 4 x tiles_n groups, S > 0 = slab walk with <= S n tiles per slab")
     args = ap.parse_args()
 
     # HSA reads its environment at hsa_init, i.e. at the first torch.cuda call below: set these before anything touches the GPU

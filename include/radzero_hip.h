@@ -211,13 +211,13 @@ int rz_patch_embed(int dtype, const float* pixel_values_dev, int batch, int chan
  * handle's own value, which then overrides the process-wide one for that handle only (INT32_MIN = follow the process-wide value again):
  * two handles of one process can differ.  Defaults are the measured-fastest choices.
  *   "gemm_variant"     0 auto | 1 128x128 two-stage | 3 256x256 two-stage | 7 256x256 staggered 8-phase (16-bit, gemm7.hip)
- *                      | 8 the same K loop as a persistent kernel, one workgroup per CU (16-bit, gemm8.hip; default for big shapes)
- *                      | 10 persistent, four waves x 128x128, accumulators in AGPRs, generated inline-asm K loop (gemm10.hip; bit-identical, 7 % slower)
+ *                      | 8 the same K loop as a persistent kernel, one workgroup per CU (16-bit, gemm8.hip; default for big shapes).
+ *                      10 / 11 / 12 (other K loops; two 256x128 workgroups per CU) are retired experiments: bit-identical, never faster
+ *                      inside the step, compiled into the RZ_EXPERIMENTS tools library only — the product library runs 8 for them
  *   "gemm_v1_only"     (process-wide only) 1 = same as gemm_variant 1
  *   "attn_variant"     0 default (16x16x32 MFMA, 4 waves x 32 query rows, row sums on the matrix pipe; bf16 without the running
- *                      maximum in the hot loop) | 64 = 64 query rows per wave where the padded token count is a multiple of 256 (half
- *                      the LDS traffic per FLOP; faster back to back, slower inside the model's step) | 417 = the default shape with
- *                      the running maximum tracked in every tile (what f16 always runs)
+ *                      maximum in the hot loop) | 417 = the default shape with the running maximum tracked in every tile (what f16
+ *                      always runs).  Other values run the default (the retired shapes live in the RZ_EXPERIMENTS tools library)
  *   "attn_f32_split"   1 (default) = fp32 mode runs attention as hi/lo-split f16 MFMAs; 0 = exact-fp32 MFMAs (16x16x4_f32)
  *   "gemm_f32_split"   1 (default) = fp32 mode runs the vision encoder's GEMMs as hi/lo-split f16 MFMAs; 0 = exact-fp32 MFMAs
  *   "f32_split_guard"  1 (default) = fp32 mode: a forward in which a value left the f16 range of the hi/lo planes (|x| > 65504) is
@@ -231,9 +231,8 @@ int rz_patch_embed(int dtype, const float* pixel_values_dev, int batch, int chan
  *   "pad_rows"         token rows per image are padded to: 0 (default) a multiple of 128, of 256 where that costs < 2 % more rows
  *                      | 128 | 256 always that multiple.  Setting it on a handle drops its position tables and workspace sizes
  *                      (call rz_set_position_table / rz_reserve again).
- *   "vision_chunk"     images per internal pass of rz_vision_forward (0 = whole batch)
- *   "vision_streams"   2 = two halves of the batch on two internal streams
- *   "mlp_chunk"        images per fc1->fc2 pass (0 = whole batch, -1 = ~126 MiB of hidden activations) */
+ * (The batch-chunking / two-stream / tile-walk switches of rounds 1-4 — vision_chunk, vision_streams, mlp_chunk, gemm_raster — measured
+ * no gain and are known to the RZ_EXPERIMENTS tools library only.) */
 int rz_set_option(const char* name, int value);
 int rz_set_model_option(rz_handle_t h, const char* name, int value);
 /* the value in force for this handle (its own, else the process-wide one); also "f32_split_guard_reruns" */

@@ -16,9 +16,11 @@ CSRC = os.path.join(PKG_DIR, "csrc")
 # its own library and object directory; the product and every test use the plain build.
 EXPERIMENTS = os.environ.get("RZ_EXPERIMENTS") == "1"
 LIB_PATH = os.environ.get("RZ_LIB_PATH") or os.path.join(PKG_DIR, "libradzero_hip_experiments.so" if EXPERIMENTS else "libradzero_hip.so")   # RZ_LIB_PATH: A/B of two builds in one gpurun call
-SOURCES = ["gemm.hip", "gemm7.hip", "gemm8.hip", "gemm12.hip", "attention.hip", "rowops.hip", "vlcabs.hip", "preprocess.hip", "api.hip"]
+SOURCES = ["gemm.hip", "gemm7.hip", "gemm8.hip", "attention.hip", "rowops.hip", "vlcabs.hip", "preprocess.hip", "api.hip"]
 if EXPERIMENTS:
-    SOURCES += ["gemm10.hip", "gemm11.hip"]      # retired K-loop experiments (round 3): never faster than gemm8 inside the step
+    # retired GEMM experiments, never faster than gemm8 inside the step: gemm10 / gemm11 (round 3: other K loops), gemm12 (round 4: two
+    # 256x128 workgroups per CU so that epilogues overlap K loops; profiles/r04/gemm12_*.log)
+    SOURCES += ["gemm10.hip", "gemm11.hip", "gemm12.hip"]
 # attention.hip: fmaxf chains on MFMA outputs fuse into v_max3_f32 without a canonicalising v_max each
 EXTRA_FLAGS = {"attention.hip": ["-fno-honor-nans"]}
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")

@@ -45,9 +45,12 @@ Options g_opt = {0, 1, 0, 0, 0, 1, 1, 1, 0, 0, 1, 0};
 const Options kInherit = {RZ_OPT_INHERIT, RZ_OPT_INHERIT, RZ_OPT_INHERIT, RZ_OPT_INHERIT, RZ_OPT_INHERIT, RZ_OPT_INHERIT, RZ_OPT_INHERIT,
                           RZ_OPT_INHERIT, RZ_OPT_INHERIT, RZ_OPT_INHERIT, RZ_OPT_INHERIT, RZ_OPT_INHERIT};
 int* option_field(Options& o, const char* name) {
+#ifdef RZ_EXPERIMENTS      // measured, never a gain (profiles/NOTEBOOK.md): known to the tools build only; the product runs one pass, one stream
     if (!strcmp(name, "vision_chunk")) return &o.vision_chunk;
     if (!strcmp(name, "vision_streams")) return &o.vision_streams;
     if (!strcmp(name, "mlp_chunk")) return &o.mlp_chunk;
+    if (!strcmp(name, "gemm_raster")) return &o.gemm_raster;
+#endif
     if (!strcmp(name, "attn_variant")) return &o.attn_variant;
     if (!strcmp(name, "gemm_variant")) return &o.gemm_variant;
     if (!strcmp(name, "gemm_f32_split")) return &o.gemm_f32_split;
@@ -56,7 +59,6 @@ int* option_field(Options& o, const char* name) {
     if (!strcmp(name, "sim_op")) return &o.sim_op;
     if (!strcmp(name, "pad_rows")) return &o.pad_rows;
     if (!strcmp(name, "f32_split_guard")) return &o.f32_split_guard;
-    if (!strcmp(name, "gemm_raster")) return &o.gemm_raster;
     return nullptr;
 }
 inline int pick(int own, int process_wide) { return own == RZ_OPT_INHERIT ? process_wide : own; }
@@ -143,9 +145,15 @@ struct TextLayer {       // TF:mpnet/modeling_mpnet.py:234-261
 struct rz_model {
     rz_config cfg;
     Options opt = kInherit;
+#ifdef RZ_EXPERIMENTS
     int o_vision_chunk() const { return pick(opt.vision_chunk, g_opt.vision_chunk); }
     int o_vision_streams() const { return pick(opt.vision_streams, g_opt.vision_streams); }
     int o_mlp_chunk() const { return pick(opt.mlp_chunk, g_opt.mlp_chunk); }
+#else
+    int o_vision_chunk() const { return 0; }
+    int o_vision_streams() const { return 1; }
+    int o_mlp_chunk() const { return 0; }
+#endif
     int o_attn_variant() const { return pick(opt.attn_variant, g_opt.attn_variant); }
     int o_gemm_variant() const { return pick(opt.gemm_variant, g_opt.gemm_variant); }
     int o_gemm_raster() const { return pick(opt.gemm_raster, g_opt.gemm_raster); }

@@ -1144,15 +1144,16 @@ hipError_t launch_flash_attn(int dtype, const void* q, const void* k, const void
     // `variant` = option attn_variant.  Every 16-bit kernel: 4 waves per workgroup, row sums on the matrix pipe (LS); bf16 without the
     // running maximum in the hot loop (NOMAX), f16 with it.
     //   0 / 4 (default)  32 query rows per wave (128 per workgroup), 3 waves per SIMD
-    //   64               64 query rows per wave (256 per workgroup) where n_pad is a multiple of 256: every K / V^T fragment read from LDS
-    //                    feeds four MFMAs and every staged tile 256 query rows — half the LDS reads and LDS-DMA bytes per FLOP, which the
-    //                    round-3 timing ablations name as what the MFMA stream waits for.  4-6 % faster than the default when the kernel
-    //                    runs back to back (tools/attn_ab.py), 1.5-2 % SLOWER inside the model's step: not the default
     //   417              the default shape with the running maximum tracked in every tile (bf16's second pass made the first)
     // fp32 operands: 32 rows per wave, VALU row sums (the ones-row sums would cost 8 exact-f32 MFMAs per tile).
-    // Measured and retired (compiled only with -DRZ_EXPERIMENTS): 16 = VALU row sums for 16-bit operands, 8 = 8 waves x 32
-    // rows, 5 / 65 = three K / V^T tiles resident (LDS-DMA two tiles ahead), 1000 + m / 2000 + m = timing ablations of the hot loop.
-    int nw = 4, qt = (dtype != DT_F32 && n_pad % 256 == 0 && (variant == 64 || variant == 65)) ? 4 : 2;
+    // Measured and retired (profiles/NOTEBOOK.md; compiled only with -DRZ_EXPERIMENTS): 64 = 64 query rows per wave where n_pad is a
+    // multiple of 256 (half the LDS reads and LDS-DMA bytes per FLOP: 4-6 % faster back to back, 1.5-2 % SLOWER inside the model's step),
+    // 16 = VALU row sums for 16-bit operands, 8 = 8 waves x 32 rows, 5 / 65 = three K / V^T tiles resident (LDS-DMA two tiles ahead),
+    // 128 = key-split asm kernel, 1000 + m / 2000 + m = timing ablations of the hot loop.
+    int nw = 4, qt = 2;
+#ifdef RZ_EXPERIMENTS
+    if (dtype != DT_F32 && n_pad % 256 == 0 && (variant == 64 || variant == 65)) qt = 4;
+#endif
     bool ls = dtype != DT_F32, track = variant == 417 || dtype == DT_F16;
     [[maybe_unused]] bool deep = false;
 #define RZ_FA(TT, NWV, QTV, LSV, NOMAXV, ABLV, NBUFV)                                                                                      \
@@ -1195,22 +1196,23 @@ hipError_t launch_flash_attn(int dtype, const void* q, const void* k, const void
             if (deep) { RZ_FA(bf16_t, 4, 2, true, true, 0, 3); break; }
             if (nw == 8) { RZ_FA(bf16_t, 8, 2, false, false, 0, 2); break; }
             if (!ls) { RZ_FA(bf16_t, 4, 2, false, false, 0, 2); break; }
+            if (qt == 4) { if (track) RZ_FA(bf16_t, 4, 4, true, false, 0, 2); else RZ_FA(bf16_t, 4, 4, true, true, 0, 2); break; }
 #endif
-            if (qt == 4) { if (track) RZ_FA(bf16_t, 4, 4, true, false, 0, 2); else RZ_FA(bf16_t, 4, 4, true, true, 0, 2); }
-            else { if (track) RZ_FA(bf16_t, 4, 2, true, false, 0, 2); else RZ_FA(bf16_t, 4, 2, true, true, 0, 2); }
+            if (track) RZ_FA(bf16_t, 4, 2, true, false, 0, 2); else RZ_FA(bf16_t, 4, 2, true, true, 0, 2);
             break;
         case DT_F16:
 #ifdef RZ_EXPERIMENTS
             if (deep && qt == 2) { RZ_FA(f16_t, 4, 2, true, false, 0, 3); break; }
             if (nw == 8) { RZ_FA(f16_t, 8, 2, false, false, 0, 2); break; }
             if (!ls) { RZ_FA(f16_t, 4, 2, false, false, 0, 2); break; }
+            if (qt == 4) { RZ_FA(f16_t, 4, 4, true, false, 0, 2); break; }
 #endif
-            if (qt == 4) RZ_FA(f16_t, 4, 4, true, false, 0, 2); else RZ_FA(f16_t, 4, 2, true, false, 0, 2);
+            RZ_FA(f16_t, 4, 2, true, false, 0, 2);
             break;
         default: return hipErrorInvalidValue;
     }
 #undef RZ_FA
-    (void)nw; (void)ls;
+    (void)nw; (void)ls; (void)qt;
     return hipGetLastError();
 }
 

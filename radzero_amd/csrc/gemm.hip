@@ -213,14 +213,16 @@ static bool big_tiles_pay(const GemmArgs& g) {
     return t256 >= 128 && (double)t256 / (double)(((t256 + 255) / 256) * 256) >= 0.55;
 }
 
-// the persistent kernels (the only ones with the merged q|k|v projection and the whole-batch fused-LayerNorm epilogues); 10 and 11 are
-// retired experiments, compiled with -DRZ_EXPERIMENTS only (they fall back to 8 in the product library)
+// the persistent kernels (the only ones with the merged q|k|v projection and the whole-batch fused-LayerNorm epilogues); 10, 11 and 12
+// are retired experiments, compiled with -DRZ_EXPERIMENTS only (they fall back to 8 in the product library)
 static bool persistent_variant(int v) { return v == 8 || v == 10 || v == 11 || v == 12; }
 
 // The merged q|k|v projection (EPI_QKV) exists only in the persistent kernel: callers ask first and fall back to the
 // separate EPI_HEADS + EPI_VT launches (fp32 mode, small batches, forced variants).
 bool gemm_qkv_fused_ok(int dtype, const GemmArgs& g) {
+#ifdef RZ_EXPERIMENTS
     if (g.variant == 12) return gemm_v12_ok(dtype, EPI_QKV, g);
+#endif
     return (g.variant == 0 || persistent_variant(g.variant)) && gemm_v8_ok(dtype, EPI_QKV, g) && (g.variant != 0 || big_tiles_pay(g));
 }
 
@@ -245,11 +247,11 @@ static hipError_t launch_gemm_t(int epi, const GemmArgs& g, hipStream_t s) {
     if ((epi == EPI_QKV || epi == EPI_QKV_LN) && !persistent_variant(variant)) return hipErrorInvalidValue;     // merged projection: persistent kernels only
     if ((epi == EPI_HEADS_LN || epi == EPI_VT_LN) && persistent_variant(variant)) variant = 1;  // its two halves: 128x128 kernel only
     if (epi > EPI_QKV && !persistent_variant(variant)) variant = 1;                              // fused-LayerNorm epilogues: those kernels
+#ifdef RZ_EXPERIMENTS
     if (variant == 12) {
         if (gemm_v12_ok(Traits<T>::kDType, epi, g)) return launch_gemm_v12(Traits<T>::kDType, epi, g, s);
         variant = 8;
     }
-#ifdef RZ_EXPERIMENTS
     if (variant == 11) {
         if (gemm_v11_ok(Traits<T>::kDType, epi, g)) return launch_gemm_v11(Traits<T>::kDType, epi, g, s);
         variant = 8;
@@ -259,7 +261,7 @@ static hipError_t launch_gemm_t(int epi, const GemmArgs& g, hipStream_t s) {
         variant = 8;
     }
 #else
-    if (variant == 10 || variant == 11) variant = 8;
+    if (variant == 10 || variant == 11 || variant == 12) variant = 8;
 #endif
     if (variant == 8) {
         if (gemm_v8_ok(Traits<T>::kDType, epi, g)) return launch_gemm_v8(Traits<T>::kDType, epi, g, s);

@@ -15,21 +15,23 @@
 //   c0 = A rows of (wr 0, mi 0)   c1 = A (wr 1, mi 0)   c2 = W rows of ni 0 (32 rows of wc 0, then 32 of wc 1)   c3 = W (ni 1)
 //   c4 = A (wr 0, mi 1)           c5 = A (wr 1, mi 1)
 // Chunk q of the stream (q = 6 t + c) lives in ring slot q mod 8 (`pos` = slot of c0 of the current K tile, advanced by 6 per K
-// tile: a run-time scalar, so K / 64 may be any number >= 2).  Each wave moves 2 of a chunk's 8 one-KB pieces (LDS-DMA, swizzle on
-// the source address).  Phase p of K tile t:
-//   reads(p):  p0: fa <- c0|c1 (own wr), fb0 <- c2     p1: fb1 <- c3     p2: fa <- c4|c5     p3: nothing
-//   wait:      vmcnt so that this wave's pieces of what reads(p+1) will touch have landed, lgkmcnt(0) for reads(p)
-//   s_barrier  => (i) every wave's pieces have landed: reads(p+1) are safe (they come one phase AFTER the wait that retires them),
-//                 (ii) every wave's reads(p) have returned: the slots they read may be overwritten
-//   issue:     p0: c2, c3, c4 of K tile t+1 (into the slots of c0, c1, c2 of t)   p1: c5 of t+1 (slot of c3)
-//              p2: c0, c1 of t+2 (slots of c4, c5)
-//   16 MFMAs
-// vmcnt accounting (per wave, issue order ... [c0 c1](t+1) | [c2 c3 c4](t+1) | [c5](t+1) | [c0 c1](t+2) | [c2 c3 c4](t+2) ..., two
-// instructions per chunk): before b3(t) c2(t+1) must have landed: 10 younger instructions; before b0(t+1) c3(t+1): 8 younger;
-// before b1(t+1) c4, c5(t+1): 10 younger (4 + the 6 issued after b0(t+1)); b2 needs nothing new.  Every chunk is issued >= 3 phases
-// before its first read.  As in gemm8.hip the epilogue's stores count in vmcnt too: they are younger than every operand piece issued
-// before the epilogue, so the first K tile after an epilogue allows EXTRA (half the epilogue's trailing stores) more in b0 and b1.
-// Behind a workgroup's last output tile the stream re-fetches that tile's first chunks into slots nobody reads; drained at the end.
+// tile: a run-time scalar, so K / 64 may be any number >= 4).  Each wave moves 2 of a chunk's 8 one-KB pieces (LDS-DMA, swizzle on
+// the source address).  Fragments are read ONE PHASE BEFORE the MFMAs that consume them (96 fragment registers: fa0, fa1, fb0, fb1),
+// so an LDS round trip hides under the running quadrant.  K tile t:
+//   phase 0: read fb0 <- c2, fb1 <- c3          MFMA (0,0) = fa0 x fb0     wait, barrier     issue c4, c5 of t+1 (slots of c2, c3)
+//   phase 1: read fa1 <- c4|c5 (own wr)         MFMA (0,1) = fa0 x fb1     wait, barrier     issue c0, c1 of t+2 (slots of c4, c5)
+//   phase 2:                                    MFMA (1,1) = fa1 x fb1
+//   phase 3: read fa0 <- c0|c1 of K tile t+1    MFMA (1,0) = fa1 x fb0     wait, barrier     issue c2, c3 of t+2 (slots of c0, c1 of t+1)
+// Each "wait, barrier" = s_waitcnt vmcnt(8) + lgkmcnt(0) + s_barrier: (i) this wave's pieces of everything the NEXT reads touch have
+// landed — the two chunk pairs issued after the previous two barriers (8 instructions) may stay in flight — and after the barrier so
+// have every other wave's; (ii) every wave's reads of this phase have returned, so the chunks they touched may be overwritten.  A chunk
+// is issued a whole K tile or more before its first read.
+// Tile seams.  The last K tile of an output tile does not read ahead (the epilogue needs the registers) and leaves c0 | c1 of the next
+// tile's first K tile unread, so it issues nothing after its last barrier; the first K tile reads fa0 itself in phase 0 and issues the
+// postponed pair together with its own after that phase's barrier (wait: vmcnt(4) there).  As in gemm8.hip the epilogue's stores count
+// in vmcnt too: they are younger than every operand piece issued before the epilogue, so the first K tile's first two waits allow EXTRA
+// (half the epilogue's trailing stores) more.  Behind a workgroup's last output tile the stream re-fetches that tile's first chunks
+// into slots nobody reads; drained at the end.
 #include <type_traits>
 
 #include "gemm_common.h"
@@ -61,80 +63,84 @@ template <int N> __device__ __forceinline__ void p12_wait_vm() {
 
 __device__ __forceinline__ char* p12_slot(char* ring, int pos, int c) { return ring + (((pos + c) & 7) * P12_CHUNK); }
 
-// One K tile (header).  a1 / w1: this wave's source bases at the K offset of K tile t+1, a2: of t+2 (either may belong to the next
-// output tile).  ONE copy of this body per call site, as in gemm8.hip.
+// One K tile (header).  w1 / a1: this wave's source bases at the K offset of K tile t+1, a2 / w2: of t+2 (any may belong to the next
+// output tile).  fa0 (the A fragments of mi 0) is loaded one phase early, by the previous call.  first: first K tile of an output tile
+// (fa0 is read here, and the refill of c0 / c1's slots happens one barrier later); last: last K tile (no read-ahead across the
+// epilogue: its 32 registers are the epilogue's); extra: an epilogue's stores are in the queue (first only).
 template <typename T, bool SWAP, int EXTRA>
-__device__ __forceinline__ void p12_tile(f32x4 (&acc)[2][4][4], char* ring, int pos, int wr, unsigned a_rd, unsigned b_rd,
-                                         const char* a1, const char* w1, const char* a2, const unsigned (&a_off)[2],
-                                         const unsigned (&w_off)[2], int64_t a64, int64_t w32, unsigned dst_w, bool extra) {
+__device__ __forceinline__ void p12_tile(f32x4 (&acc)[2][4][4], typename Traits<T>::frag (&fa0)[2][4], char* ring, int pos, int wr,
+                                         unsigned a_rd, unsigned b_rd, const char* a1, const char* w1, const char* a2, const char* w2,
+                                         const unsigned (&a_off)[2], const unsigned (&w_off)[2], int64_t a64, int64_t w32, unsigned dst_w,
+                                         bool first, bool last, bool extra, bool flip) {
     typedef typename Traits<T>::frag frag_t;
-    frag_t fa[2][4], fb0[2][2], fb1[2][2];
+    frag_t fa1[2][4], fb0[2][2], fb1[2][2];
+    auto read_a = [&](frag_t (&fa)[2][4], int c) {
+        const char* ca = p12_slot(ring, pos, c + wr);
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-        // ---- reads(u)
-        if (u == 0 || u == 2) {
-            const char* ca = p12_slot(ring, pos, (u == 0 ? 0 : 4) + wr);
+        for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks)
+            for (int i = 0; i < 4; ++i) fa[ks][i] = *reinterpret_cast<const frag_t*>(ca + ((a_rd ^ (ks * 64)) + i * 2048));
+    };
+    auto read_b = [&](frag_t (&fb)[2][2], int c) {
+        const char* cw = p12_slot(ring, pos, c);
 #pragma unroll
-                for (int i = 0; i < 4; ++i) fa[ks][i] = *reinterpret_cast<const frag_t*>(ca + ((a_rd ^ (ks * 64)) + i * 2048));
-        }
-        if (u == 0) {
-            const char* cw = p12_slot(ring, pos, 2);
+        for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-                for (int j = 0; j < 2; ++j) fb0[ks][j] = *reinterpret_cast<const frag_t*>(cw + ((b_rd ^ (ks * 64)) + j * 2048));
-        }
-        if (u == 1) {
-            const char* cw = p12_slot(ring, pos, 3);
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-                for (int j = 0; j < 2; ++j) fb1[ks][j] = *reinterpret_cast<const frag_t*>(cw + ((b_rd ^ (ks * 64)) + j * 2048));
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        // ---- landed: what reads(u+1) need; returned: reads(u)
-        if (u == 0) { if (extra) p12_wait_vm<8 + EXTRA>(); else p12_wait_vm<8>(); }
-        if (u == 1) { if (extra) p12_wait_vm<10 + EXTRA>(); else p12_wait_vm<10>(); }
-        if (u == 3) p12_wait_vm<10>();
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_barrier();
-        __builtin_amdgcn_sched_barrier(0);
-        // ---- refill the slots reads(u) released
-        if (u == 0) {
-#pragma unroll
-            for (int e = 0; e < 2; ++e) p12_glds(w1, w_off[e], p12_slot(ring, pos, 8) + dst_w + e * 1024);              // c2(t+1)
-#pragma unroll
-            for (int e = 0; e < 2; ++e) p12_glds(w1 + w32, w_off[e], p12_slot(ring, pos, 9) + dst_w + e * 1024);        // c3(t+1)
-#pragma unroll
-            for (int e = 0; e < 2; ++e) p12_glds(a1 + a64, a_off[e], p12_slot(ring, pos, 10) + dst_w + e * 1024);       // c4(t+1)
-        }
-        if (u == 1) {
-#pragma unroll
-            for (int e = 0; e < 2; ++e) p12_glds(a1 + 3 * a64, a_off[e], p12_slot(ring, pos, 11) + dst_w + e * 1024);   // c5(t+1)
-        }
-        if (u == 2) {
-#pragma unroll
-            for (int e = 0; e < 2; ++e) p12_glds(a2, a_off[e], p12_slot(ring, pos, 12) + dst_w + e * 1024);             // c0(t+2)
-#pragma unroll
-            for (int e = 0; e < 2; ++e) p12_glds(a2 + 2 * a64, a_off[e], p12_slot(ring, pos, 13) + dst_w + e * 1024);   // c1(t+2)
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        // ---- MFMA quadrant (mi, ni) = (0,0) (0,1) (1,1) (1,0)
-        const int mi = u >> 1, ni = (u == 1 || u == 2) ? 1 : 0;
-        __builtin_amdgcn_s_setprio(1);
+            for (int j = 0; j < 2; ++j) fb[ks][j] = *reinterpret_cast<const frag_t*>(cw + ((b_rd ^ (ks * 64)) + j * 2048));
+    };
+    auto quadrant = [&](int mi, int ni, const frag_t (&fa)[2][4], const frag_t (&fb)[2][2]) {
+        if (flip) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
-                for (int j = 0; j < 2; ++j)
-                    p12_mma<T, SWAP>(acc[mi][i][ni * 2 + j], fa[ks][i], ni ? fb1[ks][j] : fb0[ks][j]);
-        __builtin_amdgcn_s_setprio(0);
+                for (int j = 0; j < 2; ++j) p12_mma<T, SWAP>(acc[mi][i][ni * 2 + j], fa[ks][i], fb[ks][j]);
+        if (flip) __builtin_amdgcn_s_setprio(0);
+    };
+    auto issue2 = [&](const char* s0, const char* s1, const unsigned (&off)[2], int c) {      // two chunks -> slots pos+c, pos+c+1
+#pragma unroll
+        for (int e = 0; e < 2; ++e) p12_glds(s0, off[e], p12_slot(ring, pos, c) + dst_w + e * 1024);
+#pragma unroll
+        for (int e = 0; e < 2; ++e) p12_glds(s1, off[e], p12_slot(ring, pos, c + 1) + dst_w + e * 1024);
+    };
+    auto sync = [&]() {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
-    }
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    // ---- phase 0: quadrant (0, 0)
+    if (first) read_a(fa0, 0);
+    read_b(fb0, 2);
+    read_b(fb1, 3);
+    quadrant(0, 0, fa0, fb0);
+    __builtin_amdgcn_sched_barrier(0);
+    if (first) { if (extra) p12_wait_vm<4 + EXTRA>(); else p12_wait_vm<4>(); }
+    else p12_wait_vm<8>();
+    sync();
+    if (first) issue2(w1, w1 + w32, w_off, 8);                  // c2, c3 of t+1 -> slots of c0, c1 (read just now instead of one phase early)
+    issue2(a1 + a64, a1 + 3 * a64, a_off, 10);                  // c4, c5 of t+1 -> slots of c2, c3
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- phase 1: quadrant (0, 1)
+    read_a(fa1, 4);
+    quadrant(0, 1, fa0, fb1);
+    __builtin_amdgcn_sched_barrier(0);
+    if (first && extra) p12_wait_vm<8 + EXTRA>(); else p12_wait_vm<8>();
+    sync();
+    issue2(a2, a2 + 2 * a64, a_off, 12);                        // c0, c1 of t+2 -> slots of c4, c5
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- phase 2: quadrant (1, 1)
+    quadrant(1, 1, fa1, fb1);
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- phase 3: quadrant (1, 0)
+    if (!last) read_a(fa0, 6);                                  // c0 | c1 of t+1
+    quadrant(1, 0, fa1, fb0);
+    __builtin_amdgcn_sched_barrier(0);
+    p12_wait_vm<8>();
+    sync();
+    if (!last) issue2(w2, w2 + w32, w_off, 14);                 // c2, c3 of t+2 -> slots of c0, c1 of t+1
+    __builtin_amdgcn_sched_barrier(0);
 }
 
 // Tile order inside an XCD (g.raster):
@@ -176,7 +182,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel_v12(GemmArgs g) {
 
     // ---- this workgroup's tile list
     P12Walk walk;
-    walk.tiles_n = g.N / P12_BN; walk.tiles_m = g.M / P12_BM; walk.raster = g.raster;
+    walk.tiles_n = g.N / P12_BN; walk.tiles_m = g.M / P12_BM; walk.raster = g.raster & 0xff;
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, stride = gridDim.x >> 3;
     if (walk.raster == 0) {
         const int ntiles = walk.tiles_m * walk.tiles_n;
@@ -194,6 +200,14 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel_v12(GemmArgs g) {
     }
     const int cnt = walk.cnt;
     if (slot >= cnt) return;
+    // EXPERIMENT (g.raster bits 8-9): static issue priority by role, so that the two waves of a SIMD alternate instead of running
+    // their MFMA clusters side by side: 1 = role by the wave's slot on its SIMD, 2 = by the workgroup's slot on its CU (HW_REG_HW_ID)
+    const int prio_mode = (g.raster >> 8) & 3;
+    if (prio_mode) {
+        const int role = (prio_mode == 1 ? __builtin_amdgcn_s_getreg(4 | (0 << 6) | (3 << 11)) : __builtin_amdgcn_s_getreg(4 | (16 << 6) | (3 << 11))) & 1;
+        if (role) __builtin_amdgcn_s_setprio(2); else __builtin_amdgcn_s_setprio(0);
+    }
+    const bool flip = prio_mode == 0;
 
     const int64_t lda_b = g.lda * 2, ldw_b = g.ldw * 2;
     const int nk = g.K / 64;
@@ -224,6 +238,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel_v12(GemmArgs g) {
         for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int j = 0; j < 4; ++j) acc[a][i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    typename Traits<T>::frag fa0[2][4];          // A fragments of (own wr, mi 0): read one phase ahead, alive across K tiles
 
     int idx = slot, m0, n0;
     walk.origin(idx, m0, n0);
@@ -250,7 +265,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel_v12(GemmArgs g) {
     for (int e = 0; e < 2; ++e) p12_glds(Ab + 128, a_off[e], lds + 6 * P12_CHUNK + dst_w + e * 1024);
 #pragma unroll
     for (int e = 0; e < 2; ++e) p12_glds(Ab + 128 + 2 * a64, a_off[e], lds + 7 * P12_CHUNK + dst_w + e * 1024);
-    p12_wait_vm<10>();                                  // c0, c1, c2 of K tile 0
+    p12_wait_vm<8>();                                   // c0 .. c3 of K tile 0
     __builtin_amdgcn_s_barrier();
 
     bool after_epilogue = false;
@@ -266,7 +281,8 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel_v12(GemmArgs g) {
             constexpr bool SWAP = decltype(swap_c)::value;
             constexpr bool PEEL = !(EPI == EPI_QKV || EPI == EPI_QKV_LN);      // see gemm8.hip: the merged kernels hold two copies already
             if constexpr (PEEL) {
-                p12_tile<T, SWAP, EXTRA>(acc, lds, pos, wr, a_rd, b_rd, Ab + 128, Wb + 128, Ab + 256, a_off, w_off, a64, w32, dst_w, after_epilogue);
+                p12_tile<T, SWAP, EXTRA>(acc, fa0, lds, pos, wr, a_rd, b_rd, Ab + 128, Wb + 128, Ab + 256, Wb + 256, a_off, w_off, a64, w32, dst_w,
+                                         true, false, after_epilogue, flip);
                 pos = (pos + 6) & 7;
             }
             for (int kt = PEEL ? 1 : 0; kt < nk; ++kt) {
@@ -274,8 +290,9 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel_v12(GemmArgs g) {
                 const char* a1 = in1 ? Ab + (int64_t)(kt + 1) * 128 : An + (int64_t)(kt + 1 - nk) * 128;
                 const char* w1 = in1 ? Wb + (int64_t)(kt + 1) * 128 : Wn + (int64_t)(kt + 1 - nk) * 128;
                 const char* a2 = in2 ? Ab + (int64_t)(kt + 2) * 128 : An + (int64_t)(kt + 2 - nk) * 128;
-                p12_tile<T, SWAP, EXTRA>(acc, lds, pos, wr, a_rd, b_rd, a1, w1, a2, a_off, w_off, a64, w32, dst_w,
-                                         PEEL ? false : (kt == 0 && after_epilogue));
+                const char* w2 = in2 ? Wb + (int64_t)(kt + 2) * 128 : Wn + (int64_t)(kt + 2 - nk) * 128;
+                p12_tile<T, SWAP, EXTRA>(acc, fa0, lds, pos, wr, a_rd, b_rd, a1, w1, a2, w2, a_off, w_off, a64, w32, dst_w,
+                                         PEEL ? false : kt == 0, kt == nk - 1, PEEL ? false : (kt == 0 && after_epilogue), flip);
                 pos = (pos + 6) & 7;
             }
         };
@@ -350,7 +367,7 @@ static hipError_t launch_v12_t(int epi, const GemmArgs& g, hipStream_t s) {
 // shape contract: M % 256 == 0, N % 128 == 0, K % 64 == 0, K >= 256, 16-bit dtype, per-lane operand offsets < 4 GB;
 // EPI_QKV additionally split_n % 128 == 0.
 bool gemm_v12_ok(int dtype, int epi, const GemmArgs& g) {
-    if (dtype == DT_F32 || g.M % P12_BM || g.N % P12_BN || g.K % 64 || g.K < 256 || g.raster < 0) return false;
+    if (dtype == DT_F32 || g.M % P12_BM || g.N % P12_BN || g.K % 64 || g.K < 256 || g.raster < 0 || (g.raster & 0xff) > 64) return false;
     if ((int64_t)16 * g.lda * 2 >= ((int64_t)1 << 32) || (int64_t)16 * g.ldw * 2 >= ((int64_t)1 << 32)) return false;
     if ((epi == EPI_QKV || epi == EPI_QKV_LN) && (g.split_n % P12_BN || g.split_n <= 0 || g.split_n >= g.N || !g.out2)) return false;
     if ((epi == EPI_QKV_LN || epi == EPI_GELU_LN) && (!g.ln_stat || !g.scale || !g.bias)) return false;
