@@ -140,7 +140,8 @@ int rz_preprocess_image(const void* image_dev, int src_dtype, int height, int wi
  * fill 0 -> BlipImageProcessor) when pad_left / pad_top / padded_* describe the padded square:
  *   pad_left = (max(w, h) - w) / 2, pad_top = (max(w, h) - h) / 2, padded_height = padded_width = max(w, h);
  * for the plain BlipImageProcessor pad_* = 0 and padded_* = height / width.  The resampling tables are those of
- * padded_width -> out_side (horizontal) and padded_height -> out_side (vertical).  descs_host: host array, copied before the call returns. */
+ * padded_width -> out_side (horizontal) and padded_height -> out_side (vertical).  descs_host: host array, copied before the call returns (as kernel
+ * arguments: the host never waits for the stream, and the call may be captured into a hipGraph). */
 typedef struct rz_image_desc {
     const void* image_dev;            /* (height, width, channels) of src_dtype: 0 uint8, 1 uint16, 2 float32 */
     int32_t src_dtype, height, width, channels;

@@ -6,6 +6,9 @@
 //   resample_h/v    : Pillow's 8-bit separable resampling (ImagingResample): coefficient tables in 22-bit fixed point are
 //                     built on the host exactly as Pillow builds them; horizontal pass first, uint8 intermediate
 //   normalize_kernel: out[c][y][x] = (v8 / 255 - mean[c]) / std[c], grey replicated to 3 channels
+#include <algorithm>
+#include <cstring>
+
 #include "rz_common.h"
 #include "rz_kernels.h"
 
@@ -241,6 +244,16 @@ __global__ __launch_bounds__(256) void normalize_batch_kernel(const PreDesc* __r
     }
 }
 
+// The descriptors travel to the device as KERNEL ARGUMENTS, 16 at a time (1792 bytes per launch): the runtime copies kernel arguments
+// when the launch is enqueued, so the caller's array may be freed as soon as the call returns, the host never waits for the stream (an
+// hipMemcpyAsync from pageable memory does: it is staged synchronously, i.e. only once the stream has reached it), and the launches
+// can be captured into a hipGraph.
+struct PreDescChunk { PreDesc d[16]; };
+__global__ void put_descs_kernel(PreDescChunk c, PreDesc* __restrict__ dst, int first, int n) {
+    const int i = threadIdx.x;
+    if (i < 16 && first + i < n) dst[first + i] = c.d[i];
+}
+
 size_t preprocess_batch_desc_bytes(int n) { return ((size_t)n * sizeof(PreDesc) + 8 * (size_t)n + 255) / 256 * 256; }
 
 // descs_host: n descriptors with a8 / b8 / c8 already laid out BEHIND the descriptor block (preprocess_batch_desc_bytes(n)); ws: the
@@ -248,8 +261,12 @@ size_t preprocess_batch_desc_bytes(int n) { return ((size_t)n * sizeof(PreDesc) 
 hipError_t launch_preprocess_batch(const void* descs_host, int n, int max_ph, int S, const float* mean, const float* stdv, float rescale,
                                    unsigned char* ws, float* out, int minmax_normalize, hipStream_t s) {
     if (!descs_host || !ws || !out || n <= 0 || S <= 0 || max_ph <= 0) return hipErrorInvalidValue;
-    hipError_t e = hipMemcpyAsync(ws, descs_host, (size_t)n * sizeof(PreDesc), hipMemcpyHostToDevice, s);
-    if (e != hipSuccess) return e;
+    for (int first = 0; first < n; first += 16) {
+        PreDescChunk c;
+        memset(&c, 0, sizeof c);
+        memcpy(c.d, reinterpret_cast<const PreDesc*>(descs_host) + first, (size_t)std::min(16, n - first) * sizeof(PreDesc));
+        hipLaunchKernelGGL(put_descs_kernel, dim3(1), dim3(64), 0, s, c, reinterpret_cast<PreDesc*>(ws), first, n);
+    }
     const PreDesc* dd = reinterpret_cast<const PreDesc*>(ws);
     unsigned* mm = reinterpret_cast<unsigned*>(ws + (size_t)n * sizeof(PreDesc));
     if (minmax_normalize) {

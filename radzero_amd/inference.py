@@ -5,8 +5,10 @@ Differences from the reference, all deliberate:
   * prompt embeddings are encoded ONCE per prompt set and cached (the reference re-encodes every prompt for
     every image batch, modeling.py:290-307) — same numbers, T x fewer text forwards per batch;
   * the unused negative-prompt tokenisation (utils.py:57-62) is kept only for signature compatibility;
-  * under torch.distributed the batches are dealt round-robin to the ranks and logits are gathered to rank 0
-    in the original order.
+  * under torch.distributed the SOURCE is sharded — batches are dealt round-robin to the ranks by a strided batch
+    sampler, a rank never reads an image it does not compute — and logits are gathered to rank 0 in the original order;
+  * raw detector images are preprocessed on the device (the raw bytes cross PCIe, not fp32 pixels), overlapped with the
+    previous batch's forward.
 """
 from __future__ import annotations
 
@@ -15,7 +17,7 @@ from typing import Callable, Dict, Iterable, List, Optional
 import torch
 import torch.distributed as dist
 
-from .parallel import gather_row_shards, sharded_text_features
+from .parallel import StridedBatchSampler, gather_row_shards, interleave_row_shards, sharded_text_features
 
 
 def process_class_prompts(text_prompt: Dict[str, List[str]], tokenizer, model):
@@ -26,42 +28,103 @@ def process_class_prompts(text_prompt: Dict[str, List[str]], tokenizer, model):
     return {"encoded_key_phrases": enc, "encoded_negative_phrases": neg}
 
 
-@torch.no_grad()
-def calculate_similarities(batches: Iterable[torch.Tensor], text_batch, model, distributed: bool = False):
-    """`batches` yields pixel_values tensors (B, 3, S, S) (the reference builds them with its DataLoader +
-    collate_fn, inference/dataset.py:31-51).  Returns class logits (n_images, T) as float32 numpy
-    (utils.py:103-104) in the order of `batches`.
+def _is_dataset(source) -> bool:
+    return hasattr(source, "__getitem__") and hasattr(source, "__len__") and not torch.is_tensor(source) and not isinstance(source, (list, tuple))
 
-    distributed=True (one process per GPU, torch.distributed initialised): EVERY rank passes the same `batches`
-    sequence; rank r computes the batches with index i % world == r (round-robin, so a streaming loader needs no
-    length), the prompt set is encoded once, sharded over ranks + one all_gather (parallel.sharded_text_features), and
-    the per-rank logits — unequal row counts are fine, a rank may get nothing — are gathered to rank 0 and put back
-    into `batches` order there.  Ranks other than 0 return None."""
+
+def _collate_default(items, model, preprocessor):
+    """A batch of dataset items -> pixel_values on the model's device.  Raw detector images (2-D / HWC integer or float arrays, sizes may
+    differ) go through the DEVICE preprocessing (radzero_amd.preprocess.DevicePreprocessor: cv2 min-max, Pillow-exact bicubic, rescale,
+    normalise) — 7.2 MB per 2048 x 1760 uint16 image over PCIe instead of 12.6 MB of fp32 pixels at 1024^2; items that already are
+    (3, S, S) float tensors are stacked and copied."""
+    import numpy as np
+    first = items[0]
+    if torch.is_tensor(first) and first.dim() == 3 and first.shape[0] == 3 and first.is_floating_point():
+        return torch.stack([t.float() for t in items]).to(model.device, non_blocking=True)
+    if preprocessor is None:
+        raise ValueError("calculate_similarities: raw images need preprocessor=DevicePreprocessor(size, ...) (or pass collate_fn=)")
+    raws = []
+    for it in items:
+        a = it if torch.is_tensor(it) else torch.from_numpy(np.ascontiguousarray(np.asarray(it)))
+        raws.append(a.pin_memory() if (a.device.type == "cpu" and model.device.type == "cuda") else a)
+    return preprocessor(raws)
+
+
+@torch.no_grad()
+def calculate_similarities(source, text_batch, model, distributed: bool = False, *, batch_size: Optional[int] = None,
+                           collate_fn: Optional[Callable] = None, preprocessor=None, overlap: bool = True):
+    """Class logits (n_images, T) as float32 numpy (exp/cxr_pt/inference/utils.py:70-106, :103-104), in the order of the source.
+
+    `source` is either
+      * a map-style dataset (`__len__` + `__getitem__`, e.g. the reference's InferDataset, inference/dataset.py:14-28) together with
+        `batch_size`: the driver forms the batches itself — items [i * batch_size, (i + 1) * batch_size) — and, under
+        torch.distributed, rank r takes batches r, r + world, ... through a StridedBatchSampler, so that a rank NEVER reads or decodes
+        an image it will not compute (the host-side share of an 8-GPU run is 1/8 per rank, not 8/8).  A batch of items becomes
+        pixel_values through `collate_fn(items)` if given, else: (3, S, S) float tensors are stacked; raw images (2-D / HWC uint8 /
+        uint16 / float arrays, sizes may differ) run the device preprocessing `preprocessor` (DevicePreprocessor) — the raw bytes
+        cross PCIe, not fp32 pixels.  With a CUDA model and `overlap`, batch k + 1 is fetched, copied and preprocessed on a side
+        stream while batch k computes;
+      * or an iterable of pixel_values tensors (B, 3, S, S) — under torch.distributed THIS RANK'S batches only (global batch i = the
+        (i // world)-th batch of rank i % world: shard the source with StridedBatchSampler, not the results).
+
+    distributed=True (one process per GPU, torch.distributed initialised): the prompt set is encoded once, sharded over ranks + one
+    all_gather (parallel.sharded_text_features); per-rank logits — unequal row counts are fine, a rank may get nothing — are gathered to
+    rank 0 and interleaved back into the source order there.  Ranks other than 0 return None."""
     enc = text_batch["encoded_key_phrases"]
     dist_on = distributed and dist.is_available() and dist.is_initialized()
     world, rank = (dist.get_world_size(), dist.get_rank()) if dist_on else (1, 0)
     encode = lambda e: model.forward_text_model(e)["text_features_wo_l2_norm"]
     feats = sharded_text_features(encode, enc, feature_dim=model.config.hidden_size) if dist_on else model.encode_prompts(enc)
     n_prompts = int(feats.shape[0])
-    out, rows_per_batch = [], []
-    for i, pixel_values in enumerate(batches):
-        rows_per_batch.append(int(pixel_values.shape[0]))
-        if i % world != rank:
-            continue
-        out.append(model.compute_logits(pixel_values=pixel_values.to(model.device), encoded_key_phrases=[enc],
-                                        text_features=feats)["logits"].reshape(pixel_values.shape[0], -1))
+    cuda = model.device.type == "cuda"
+
+    if _is_dataset(source):
+        if not batch_size or batch_size <= 0:
+            raise ValueError("calculate_similarities: a dataset source needs batch_size")
+        make = collate_fn if collate_fn is not None else (lambda items: _collate_default(items, model, preprocessor))
+        batches = (make([source[j] for j in idxs]) for idxs in StridedBatchSampler(len(source), batch_size, rank, world))
+    else:
+        batches = iter(source)
+
+    out, rows = [], []
+    if cuda and overlap:
+        # produce batch k + 1 (dataset reads, H2D, device preprocessing) on a side stream while batch k computes on the current one
+        main = torch.cuda.current_stream(model.device)
+        side = torch.cuda.Stream(device=model.device)
+
+        def produce():
+            with torch.cuda.stream(side):
+                try:
+                    px = next(batches)
+                except StopIteration:
+                    return None
+                px = px.to(model.device, non_blocking=True)
+                ev = torch.cuda.Event()
+                ev.record(side)
+            return px, ev
+
+        nxt = produce()
+        while nxt is not None:
+            px, ev = nxt
+            main.wait_event(ev)
+            px.record_stream(main)
+            logits = model.compute_logits(pixel_values=px, encoded_key_phrases=[enc], text_features=feats)["logits"]
+            out.append(logits.reshape(px.shape[0], -1).clone())
+            rows.append(int(px.shape[0]))
+            nxt = produce()
+    else:
+        for px in batches:
+            logits = model.compute_logits(pixel_values=px.to(model.device), encoded_key_phrases=[enc], text_features=feats)["logits"]
+            out.append(logits.reshape(px.shape[0], -1))
+            rows.append(int(px.shape[0]))
     logits = torch.cat(out, dim=0) if out else torch.zeros((0, n_prompts), dtype=torch.float32, device=feats.device)
     if dist_on:
+        all_rows = [None] * world
+        dist.all_gather_object(all_rows, rows)
         shards = gather_row_shards(logits.float())
         if shards is None:
             return None
-        # undo the round-robin: batch i is the (i // world)-th batch of rank i % world
-        offsets = [0] * world
-        ordered = []
-        for i, b in enumerate(rows_per_batch):
-            r = i % world
-            ordered.append(shards[r][offsets[r]: offsets[r] + b])
-            offsets[r] += b
+        ordered = interleave_row_shards(shards, all_rows)
         logits = torch.cat(ordered, dim=0) if ordered else shards[0]
     return logits.float().cpu().numpy()
 

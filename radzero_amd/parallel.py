@@ -22,6 +22,41 @@ def shard_range(n_items: int, rank: int, world: int) -> Tuple[int, int]:
     return lo, min(lo + per, n_items)
 
 
+class StridedBatchSampler:
+    """Index lists of the batches THIS rank computes: the global sequence of batches (items [i * batch_size, (i + 1) * batch_size) of a
+    map-style dataset, in order, last one short) is dealt round-robin — rank r takes batches r, r + world, r + 2 world, ... — so a rank
+    never touches (reads, decodes, collates) an item it will not compute.  Usable as `batch_sampler=` of a torch DataLoader (the
+    reference builds its loader in inference/utils.py:81-90) or directly (inference.calculate_similarities does)."""
+
+    def __init__(self, n_items: int, batch_size: int, rank: int = 0, world: int = 1):
+        if batch_size <= 0 or world <= 0 or not 0 <= rank < world:
+            raise ValueError("StridedBatchSampler: batch_size > 0 and 0 <= rank < world")
+        self.n_items, self.batch_size, self.rank, self.world = int(n_items), int(batch_size), int(rank), int(world)
+        self.n_batches = (self.n_items + self.batch_size - 1) // self.batch_size
+
+    def __iter__(self):
+        for i in range(self.rank, self.n_batches, self.world):
+            yield list(range(i * self.batch_size, min((i + 1) * self.batch_size, self.n_items)))
+
+    def __len__(self):
+        return len(range(self.rank, self.n_batches, self.world))
+
+
+def interleave_row_shards(shards, rows_per_batch):
+    """Undo the round-robin deal: shards[r] = rank r's rows (its batches concatenated in its own order), rows_per_batch[r] = the row
+    count of each of its batches; global batch i is the (i // world)-th batch of rank i % world."""
+    world = len(shards)
+    offsets = [0] * world
+    ordered = []
+    for k in range(max((len(c) for c in rows_per_batch), default=0)):
+        for r in range(world):
+            if k < len(rows_per_batch[r]):
+                b = rows_per_batch[r][k]
+                ordered.append(shards[r][offsets[r]: offsets[r] + b])
+                offsets[r] += b
+    return ordered
+
+
 def sharded_text_features(encode_fn: Callable[[Dict[str, torch.Tensor]], torch.Tensor],
                           encoded: Dict[str, torch.Tensor], group=None, feature_dim: int | None = None) -> torch.Tensor:
     """Encode this rank's share of the prompts with `encode_fn` ((t,L) ids/mask -> (t, D) fp32) and

@@ -95,40 +95,80 @@ def _batches(n_images, batch):
     return [px[i:i + batch] for i in range(0, n_images, batch)]
 
 
-def _driver_worker(rank, world, port, n_images, batch, q):
+class _LoggingDataset:
+    """Map-style dataset of (3, 4, 4) float images that records which items were read (the stand-in for decoding a file)."""
+
+    def __init__(self, n_images):
+        g = torch.Generator().manual_seed(5)
+        self.px = torch.randn(n_images, 3, 4, 4, generator=g)
+        self.read = []
+
+    def __len__(self):
+        return self.px.shape[0]
+
+    def __getitem__(self, i):
+        self.read.append(int(i))
+        return self.px[i]
+
+
+def _driver_worker(rank, world, port, n_images, batch, mode, q):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         from radzero_amd.inference import calculate_similarities
+        from radzero_amd.parallel import StridedBatchSampler
         g = torch.Generator().manual_seed(1)
         enc = {"input_ids": torch.randint(4, 30000, (5, 7), generator=g), "attention_mask": torch.ones(5, 7, dtype=torch.long)}
-        got = calculate_similarities(_batches(n_images, batch), {"encoded_key_phrases": enc}, _FakeModel(), distributed=True)
-        q.put((rank, None if got is None else got.tolist()))
+        ds = _LoggingDataset(n_images)
+        if mode == "dataset":
+            got = calculate_similarities(ds, {"encoded_key_phrases": enc}, _FakeModel(), distributed=True, batch_size=batch)
+        else:           # this rank's own batches, built with the same sampler (what a torch DataLoader(batch_sampler=...) would yield)
+            mine = (torch.stack([ds[j] for j in idxs]) for idxs in StridedBatchSampler(n_images, batch, rank, world))
+            got = calculate_similarities(mine, {"encoded_key_phrases": enc}, _FakeModel(), distributed=True)
+        q.put((rank, None if got is None else got.tolist(), sorted(ds.read)))
     finally:
         dist.destroy_process_group()
 
 
+@pytest.mark.parametrize("mode", ["dataset", "iterable"])
 @pytest.mark.parametrize("world,n_images,batch", [(2, 7, 2), (3, 7, 2), (3, 2, 2), (2, 5, 8), (4, 9, 1)])
-def test_batch_driver_shards_images_and_restores_order(world, n_images, batch):
-    """every rank passes the same batches; ranks compute disjoint shares (uneven, some empty) and rank 0
-    gets exactly the single-process result, in the original image order."""
+def test_batch_driver_shards_the_source_and_restores_order(world, n_images, batch, mode):
+    """the SOURCE is sharded, not the results — every rank reads exactly the items of its own batches (batch i
+    belongs to rank i % world; uneven shares, some ranks empty), no item is read twice, and rank 0 gets exactly the single-process
+    result in the original image order."""
     from radzero_amd.inference import calculate_similarities
     g = torch.Generator().manual_seed(1)
     enc = {"input_ids": torch.randint(4, 30000, (5, 7), generator=g), "attention_mask": torch.ones(5, 7, dtype=torch.long)}
     want = calculate_similarities(_batches(n_images, batch), {"encoded_key_phrases": enc}, _FakeModel())
     assert want.shape == (n_images, 5)
+    assert np.array_equal(calculate_similarities(_LoggingDataset(n_images), {"encoded_key_phrases": enc}, _FakeModel(), batch_size=batch), want)
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_driver_worker, args=(r, world, port, n_images, batch, q)) for r in range(world)]
+    procs = [ctx.Process(target=_driver_worker, args=(r, world, port, n_images, batch, mode, q)) for r in range(world)]
     for p in procs:
         p.start()
-    res = dict(q.get(timeout=120) for _ in range(world))
+    res = {r: (got, read) for r, got, read in (q.get(timeout=120) for _ in range(world))}
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    assert all(res[r] is None for r in range(1, world))
-    assert np.array_equal(np.asarray(res[0], np.float32), want)
+    assert all(res[r][0] is None for r in range(1, world))
+    assert np.array_equal(np.asarray(res[0][0], np.float32), want)
+    for r in range(world):
+        share = [j for i in range(r, (n_images + batch - 1) // batch, world) for j in range(i * batch, min((i + 1) * batch, n_images))]
+        assert res[r][1] == share, (r, res[r][1], share)          # its own items, each exactly once, nothing else
+
+
+def test_strided_batch_sampler_partitions_the_batches():
+    from radzero_amd.parallel import StridedBatchSampler
+    for n, bs, w in ((7, 2, 2), (64, 8, 8), (5, 8, 2), (0, 4, 3), (9, 1, 4)):
+        per_rank = [list(StridedBatchSampler(n, bs, r, w)) for r in range(w)]
+        assert [len(StridedBatchSampler(n, bs, r, w)) for r in range(w)] == [len(p) for p in per_rank]
+        nb = (n + bs - 1) // bs
+        merged = [per_rank[i % w][i // w] for i in range(nb)]
+        assert [j for b in merged for j in b] == list(range(n))
+    with pytest.raises(ValueError):
+        StridedBatchSampler(4, 0)
 
 
 def test_shard_range_covers_everything():

@@ -183,3 +183,50 @@ def test_device_batch_feeds_the_model_and_rejects_bad_batches(cfg, state_dict):
     assert lib.rz_preprocess_batch_workspace(d, 1, 224) == 0                      # null image / zero shape
     mean = (ctypes.c_float * 3)(0, 0, 0)
     assert lib.rz_preprocess_batch(d, 1, 224, mean, mean, 1.0, 1, ctypes.c_void_p(batch.data_ptr()), 16, ctypes.c_void_p(batch.data_ptr()), None) == 10001
+
+
+@pytest.mark.gpu
+def test_batch_driver_from_raw_images_on_a_side_stream(cfg, state_dict):
+    """The data-parallel driver's default input path: a map-style dataset of RAW uint16 detector images of different
+    sizes -> calculate_similarities(dataset, batch_size=, preprocessor=): 37 items in batches of 16 (> 16 descriptors per launch group, a
+    short last batch), dataset reads + H2D + device preprocessing on a side stream while the previous batch computes.  Must equal, bit for
+    bit, preprocessing and computing the same batches one after the other on the current stream, and the un-overlapped driver."""
+    from radzero_amd.config import RadZeroConfig
+    from radzero_amd.inference import calculate_similarities
+    from radzero_amd.modeling import RadZeroModel
+    from radzero_amd.preprocess import DevicePreprocessor
+    from radzero_amd.synthetic import synthetic_prompts
+    from radzero_amd.weights import make_state_dict
+
+    class Raws:
+        def __init__(self):
+            self.items = [synthetic_cxr_raw("uint16", (260 + 7 * (i % 5), 300 - 11 * (i % 3)), 300 + i) for i in range(37)]
+            self.read = []
+
+        def __len__(self):
+            return len(self.items)
+
+        def __getitem__(self, i):
+            self.read.append(i)
+            return self.items[i]
+
+    small = RadZeroConfig(vit_layers=1, align_layers=1, text_layers=1)
+    m = RadZeroModel.from_state_dict(make_state_dict(small, 3), small, torch_dtype=torch.float32, device="cuda:0").eval()
+    try:
+        ids, mask = synthetic_prompts(4, 5, 9, 12)
+        tb = {"encoded_key_phrases": {"input_ids": torch.from_numpy(ids).cuda(), "attention_mask": torch.from_numpy(mask).cuda()}}
+        pre = DevicePreprocessor(224)
+        ds = Raws()
+        got = calculate_similarities(ds, tb, m, batch_size=16, preprocessor=pre)
+        assert got.shape == (37, 4) and ds.read == list(range(37))
+        plain = calculate_similarities(Raws(), tb, m, batch_size=16, preprocessor=pre, overlap=False)
+        want = []
+        for lo in range(0, 37, 16):
+            px = pre([torch.from_numpy(r) for r in ds.items[lo:lo + 16]])
+            want.append(m.compute_logits(px, [tb["encoded_key_phrases"]])["logits"].reshape(px.shape[0], -1).cpu().numpy())
+        want = np.concatenate(want)
+        assert np.array_equal(got, want) and np.array_equal(plain, want)
+        with pytest.raises(ValueError):
+            calculate_similarities(Raws(), tb, m, batch_size=16)          # raw items need a preprocessor (or a collate_fn)
+    finally:
+        m.close()
