@@ -514,7 +514,8 @@ def main():
             # north_star's tolerance (1e-3 on logits and maps) is met by the fp32 mode only: its throughput on the SAME shape,
             # stated next to `value` (which is BASELINE configs[1]'s own dtype, bf16)
             res["value_1e3_mode"] = {"images_per_s": res["other_configs"][3]["images_per_s"], "dtype": "f32 (hi/lo-split f16 MFMAs, fp32 accumulate)",
-                                     "max_abs_error_vs_reference": "2.1e-5 on scores, 4.7e-6 on logits (tests/test_gpu_model.py goldens)"}
+                                     "error_vs_reference": "not measured by this run: tests/test_gpu_model.py gates this mode at <= 1e-3 on every reference golden "
+                                                           "(FP32_TOL); last recorded maxima in profiles/r02/fp32_split_accuracy.log"}
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(cfg, sd, S, T, ids, mask)
         print(json.dumps(res), flush=True)

@@ -129,8 +129,9 @@ struct Tensor {          // one packed checkpoint tensor on the device
 struct DinoBlock {       // TF:dinov2/modeling_dinov2.py:342-380
     Tensor ln1_g, ln1_b, wqkv, bqkv, wo, bo, ls1, ln2_g, ln2_b, w1, b1, w2, b2, ls2;   // wqkv: [3D][D] rows q | k | v
     int qkv_parts = 0;   // bit mask of loaded q/k/v weight (1,2,4) and bias (8,16,32) pieces
-    // fused LayerNorm (gemm8.hip): c1[n] = sum_k gamma[k] W[n][k] over the ROUNDED weights, c2 = W beta + b; built once from the
-    // host copies below (16-bit modes only), which are released afterwards
+    // fused LayerNorm (gemm8.hip): c1[n] = sum_k gamma[k] W[n][k] over the ROUNDED weights, c2 = W beta + b; built from the host
+    // copies below (16-bit modes only), which STAY for the life of the handle (16.5 MB of host memory per block, ~200 MB for 12 + 2
+    // blocks) so that a partial reload — one rz_load_weight of a gain, say — re-folds from complete fp32 data (load_block)
     Tensor c1qkv, c2qkv, c1_1, c2_1;
     std::vector<float> h_wqkv, h_bqkv, h_w1, h_b1, h_g1, h_be1, h_g2, h_be2;
     bool folded = false;
@@ -179,6 +180,7 @@ struct rz_model {
     Tensor patch_w, vit_ln_g, vit_ln_b, word_emb, pos_emb, temb_ln_g, temb_ln_b, shared_ln_g, shared_ln_b;
     std::vector<float> cls_host, patch_bias_host;
     bool cls_loaded = false, patch_bias_loaded = false, tau_loaded = false, attn_tau_loaded = false;
+    bool tau_session = false, attn_tau_session = false;      // loaded since the last rz_weights_ready (a checkpoint WITHOUT attn_temperature resets it)
     float tau = 0.07f, attn_tau = 0.07f;      // exp(loss_temperature); exp(attn_temperature) when the checkpoint carries one (losses.py:57-63)
     // position tables per grid: [n_pad][D] fp32 = pos (+cls | +conv bias), zero on pad rows
     struct PosTable { DevBuf buf; int n_valid, n_pad; };
@@ -645,12 +647,14 @@ int rz_load_weight(rz_handle_t m, const char* name, const float* data, int64_t n
         if (numel != 1) return fail(RZ_ERR_INVALID, "bad numel for loss_temperature");
         m->tau = expf(data[0]);       // stored as log(tau) (losses.py:54-56); tau = exp(param) (losses.py:177-181)
         m->tau_loaded = true;
+        m->tau_session = true;
         return 0;
     }
     if (!strcmp(name, "loss_fns.RadZeroLoss.attn_temperature")) {      // only present when the config sets one (losses.py:57-63)
         if (numel != 1) return fail(RZ_ERR_INVALID, "bad numel for attn_temperature");
         m->attn_tau = expf(data[0]);
         m->attn_tau_loaded = true;
+        m->attn_tau_session = true;
         return 0;
     }
     // tensors the path never reads: position_embeddings (interpolated on the host and passed through
@@ -682,6 +686,10 @@ int rz_weights_ready(rz_handle_t m) {
         if ((rc = need(ok, "MPNetLayer " + std::to_string(i)))) return rc;
     }
     if ((rc = need(m->shared_ln_g.loaded && m->shared_ln_b.loaded && m->tau_loaded, "loss_fns.RadZeroLoss"))) return rc;
+    // a checkpoint that brought loss_temperature but no attn_temperature uses tau for the scores (losses.py:175-181): an attn_temperature
+    // left over from an earlier checkpoint on this handle must not survive it
+    if (m->tau_session && !m->attn_tau_session) m->attn_tau_loaded = false;
+    m->tau_session = m->attn_tau_session = false;
     if (m->dt != RZ_F32)        // one-time packing of the fused-LayerNorm vectors (c1, c2): here, so that no forward call allocates
         for (auto& b : m->blocks)
             if ((rc = fold_block(m, b))) return rc;

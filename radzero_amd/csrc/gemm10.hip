@@ -48,7 +48,7 @@ template <typename T, bool SWAP> struct V10Text;
       [wnlo] "s"(wnlo), [wnhi] "s"(wnhi), [sa8] "s"(sa8), [sw8] "s"(sw8), [ldsa] "s"(ldsa), [ldsw] "s"(ldsw), [nk] "s"(nk),           \
       [after] "s"(after), [extra] "n"(EXTRA)
 #define RZ_V10_CLOBBERS                                                                                                             \
-    : "memory", "scc", "s64", "s65", "s66", "s67", "s68", "s69", "s70", "s71", "s72", "s73", "s74", "s75", "s76", "s77", "s78",  \
+    : "memory", "scc", "m0", "s64", "s65", "s66", "s67", "s68", "s69", "s70", "s71", "s72", "s73", "s74", "s75", "s76", "s77", "s78",  \
       "s79", "s80", "s81", "s82", "s83", "s84",                                                                                     \
       "v120", "v121", "v122", "v123", "v124", "v125", "v126", "v127", "v128", "v129", "v130", "v131", "v132", "v133", "v134", "v135", \
       "v136", "v137", "v138", "v139", "v140", "v141", "v142", "v143", "v144", "v145", "v146", "v147", "v148", "v149", "v150", "v151", \

@@ -126,6 +126,7 @@ class RadZeroModel:
         self._text_ident_cache: Dict[tuple, tuple] = {}
         self.text_cache_enabled = True
         self._reserved = (0, 0, 0, 0)
+        self._options: Dict[str, int] = {}        # set through set_model_option: replayed when to() / float() re-creates the handle
         self.training = False
         self._create()
 
@@ -142,6 +143,8 @@ class RadZeroModel:
         with torch.cuda.device(self._device):
             _lib.check(self._lib.rz_create(ctypes.byref(rc), ctypes.byref(self._h)), "rz_create")
             _lib.check(self._lib.rz_set_model_option(self._h, b"sim_op", 1 if c.sim_op == "dot" else 0), "rz_set_model_option(sim_op)")
+            for name, v in self._options.items():      # the handle's own switches survive a dtype / device move
+                _lib.check(self._lib.rz_set_model_option(self._h, name.encode(), v), f"rz_set_model_option({name})")
 
     def close(self):
         if getattr(self, "_h", None) is not None and self._h.value:
@@ -466,6 +469,10 @@ class RadZeroModel:
         v = -(2 ** 31) if value is None else int(value)
         with torch.cuda.device(self._device):
             _lib.check(self._lib.rz_set_model_option(self._h, name.encode(), v), "rz_set_model_option")
+        if value is None:
+            self._options.pop(name, None)
+        else:
+            self._options[name] = v
         if name == "pad_rows":                       # the library dropped its tables / workspace sizes
             self._grids.clear()
             self._reserved = (0, 0, 0, 0)

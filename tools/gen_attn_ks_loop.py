@@ -321,7 +321,7 @@ def main():
             n_mfma = sum(1 for l in lines if l.startswith("v_mfma"))
             parts.append(f"// RZ_ATTN_KS_LOOP_{mn.upper()}{suffix}: {len(lines)} lines, {n_mfma} MFMAs in the text\n#define RZ_ATTN_KS_LOOP_{mn.upper()}{suffix} \\\n" +
                          " \\\n".join(c_string(lines).split("\n")) + "\n")
-    clob = ['"memory"', '"scc"', '"vcc"'] + [f'"s{i}"' for i in range(64, 81)] + [f'"v{i}"' for i in range(0, 216)] + [f'"a{i}"' for i in range(160, 224)]
+    clob = ['"memory"', '"scc"', '"vcc"', '"m0"'] + [f'"s{i}"' for i in range(64, 81)] + [f'"v{i}"' for i in range(0, 216)] + [f'"a{i}"' for i in range(160, 224)]
     parts.append("// registers the loop owns besides its pinned operands\n#define RZ_ATTN_KS_CLOBBERS " + ", ".join(clob) + "\n")
     open(OUT, "w").write("\n".join(parts))
     print("wrote", OUT, sum(len(p) for p in parts), "bytes")
