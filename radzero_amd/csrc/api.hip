@@ -303,16 +303,18 @@ int load_dino_block(rz_model* m, DinoBlock& b, const char* rest, const float* da
     // partial reload (load_state_dict(strict=False), one rz_load_weight) re-folds from complete data; only the tensors that enter
     // c1 / c2 (norm1 / norm2, q|k|v, fc1) invalidate the fold
     const bool keep = m->dt != RZ_F32;
-    if (!strcmp(rest, "norm1.weight")) { if (keep) { b.h_g1.assign(data, data + numel); b.folded = false; } return vec(b.ln1_g, D); }
-    if (!strcmp(rest, "norm1.bias")) { if (keep) { b.h_be1.assign(data, data + numel); b.folded = false; } return vec(b.ln1_b, D); }
-    if (!strcmp(rest, "norm2.weight")) { if (keep) { b.h_g2.assign(data, data + numel); b.folded = false; } return vec(b.ln2_g, D); }
-    if (!strcmp(rest, "norm2.bias")) { if (keep) { b.h_be2.assign(data, data + numel); b.folded = false; } return vec(b.ln2_b, D); }
+    // the host copy follows a SUCCESSFUL upload only: a refused tensor (wrong numel) must not truncate it (found by tools/host_asan.sh)
+    auto kept = [&](std::vector<float>& hv, int rc) { if (rc == 0 && keep) { hv.assign(data, data + numel); b.folded = false; } return rc; };
+    if (!strcmp(rest, "norm1.weight")) return kept(b.h_g1, vec(b.ln1_g, D));
+    if (!strcmp(rest, "norm1.bias")) return kept(b.h_be1, vec(b.ln1_b, D));
+    if (!strcmp(rest, "norm2.weight")) return kept(b.h_g2, vec(b.ln2_g, D));
+    if (!strcmp(rest, "norm2.bias")) return kept(b.h_be2, vec(b.ln2_b, D));
     if (!strcmp(rest, "layer_scale1.lambda1")) return vec(b.ls1, D);
     if (!strcmp(rest, "layer_scale2.lambda1")) return vec(b.ls2, D);
     if (!strcmp(rest, "attention.output.dense.weight")) return mat(b.wo, D, D);
     if (!strcmp(rest, "attention.output.dense.bias")) return vec(b.bo, D);
-    if (!strcmp(rest, "mlp.fc1.weight")) { if (keep) { b.h_w1.assign(data, data + numel); b.folded = false; } return mat(b.w1, F, D); }
-    if (!strcmp(rest, "mlp.fc1.bias")) { if (keep) { b.h_b1.assign(data, data + numel); b.folded = false; } return vec(b.b1, F); }
+    if (!strcmp(rest, "mlp.fc1.weight")) return kept(b.h_w1, mat(b.w1, F, D));
+    if (!strcmp(rest, "mlp.fc1.bias")) return kept(b.h_b1, vec(b.b1, F));
     if (!strcmp(rest, "mlp.fc2.weight")) return mat(b.w2, D, F);
     if (!strcmp(rest, "mlp.fc2.bias")) return vec(b.b2, D);
     const char* names[3] = {"query", "key", "value"};
@@ -467,7 +469,9 @@ float t_to_f32(int dt, uint16_t v) {
 int fold_matrix(rz_model* m, const std::vector<float>& W, const std::vector<float>& bias, const std::vector<float>& gamma,
                 const std::vector<float>& beta, size_t N, size_t K, Tensor& c1, Tensor& c2) {
     if (W.size() != N * K || bias.size() != N || gamma.size() != K || beta.size() != K)
-        return fail(RZ_ERR_STATE, "fused LayerNorm packing: host copies of the block's weights are incomplete");
+        return fail(RZ_ERR_STATE, "fused LayerNorm packing: host copies of the block's weights are incomplete (W " + std::to_string(W.size()) + " of " +
+                                      std::to_string(N * K) + ", bias " + std::to_string(bias.size()) + " of " + std::to_string(N) + ", gamma " +
+                                      std::to_string(gamma.size()) + ", beta " + std::to_string(beta.size()) + " of " + std::to_string(K) + ")");
     std::vector<float> v1(N), v2(N);
     for (size_t n = 0; n < N; ++n) {
         double s1 = 0.0, s2 = 0.0;
