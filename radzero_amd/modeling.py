@@ -126,6 +126,7 @@ class RadZeroModel:
         self._text_ident_cache: Dict[tuple, tuple] = {}
         self.text_cache_enabled = True
         self._reserved = (0, 0, 0, 0)
+        self._side_stream = None
         self._options: Dict[str, int] = {}        # set through set_model_option: replayed when to() / float() re-creates the handle
         self.training = False
         self._create()
@@ -296,15 +297,13 @@ class RadZeroModel:
                 "image_features": image_features}
 
     # ---- CxrAlignModel.forward_text_model, MPNet branch (modeling.py:125-211) ------------------
-    @torch.no_grad()
-    def forward_text_model(self, encoded_input):
-        ids = encoded_input["input_ids"].to(device=self._device, dtype=torch.int64).contiguous()
-        mask = encoded_input["attention_mask"].to(device=self._device, dtype=torch.int64).contiguous()
-        if ids.dim() != 2 or ids.shape != mask.shape:
-            raise ValueError("input_ids / attention_mask must be (n_prompts, len) and agree")
-        t, l = ids.shape
-        if int(ids.min()) < 0 or int(ids.max()) >= self.config.vocab_size:
+    def _check_ids(self, lo: int, hi: int):
+        if lo < 0 or hi >= self.config.vocab_size:
             raise IndexError("index out of range in self")          # nn.Embedding's error for bad token ids
+
+    def _text_forward_raw(self, ids: torch.Tensor, mask: torch.Tensor) -> torch.Tensor:
+        """rz_text_forward on the CURRENT stream for validated int64 device tensors (n_prompts, len); no cache, no host sync."""
+        t, l = ids.shape
         with torch.cuda.device(self._device):
             if l not in self._rel_bias_cache:
                 self._rel_bias_cache[l] = relative_position_bias(self._rel_weight, l).to(self._device)
@@ -312,7 +311,38 @@ class RadZeroModel:
             feat = torch.empty((t, self.config.hidden_size), dtype=torch.float32, device=self._device)
             _lib.check(self._lib.rz_text_forward(self._h, _ptr(ids), _ptr(mask), t, l, _ptr(self._rel_bias_cache[l]),
                                                  _ptr(feat), self._stream()), "rz_text_forward")
+        return feat
+
+    @torch.no_grad()
+    def forward_text_model(self, encoded_input):
+        ids = encoded_input["input_ids"].to(device=self._device, dtype=torch.int64).contiguous()
+        mask = encoded_input["attention_mask"].to(device=self._device, dtype=torch.int64).contiguous()
+        if ids.dim() != 2 or ids.shape != mask.shape:
+            raise ValueError("input_ids / attention_mask must be (n_prompts, len) and agree")
+        if not torch.cuda.is_current_stream_capturing():
+            lo, hi = torch.stack([ids.min(), ids.max()]).tolist()      # ONE device->host copy for both bounds
+            self._check_ids(int(lo), int(hi))
+        feat = self._text_forward_raw(ids, mask)
         return {"text_features_wo_l2_norm": feat, "text_features": F.normalize(feat, p=2, dim=1)}
+
+    def _cache_put(self, key: bytes, feat: torch.Tensor):
+        self._text_cache[key] = feat
+        while len(self._text_cache) > 512:                           # bounded: a service that sees a new text per request must not grow
+            self._text_cache.pop(next(iter(self._text_cache)))
+
+    def _ident(self, ids, mask):
+        # inference tensors (created under torch.inference_mode()) keep no version counter — reading `_version` raises — so an
+        # in-place write to them could not be noticed: they take the content key
+        if torch.is_tensor(ids) and torch.is_tensor(mask) and not ids.is_inference() and not mask.is_inference():
+            return (ids.data_ptr(), mask.data_ptr(), tuple(ids.shape), tuple(mask.shape), ids.dtype, mask.dtype,
+                    str(ids.device), ids._version, mask._version)
+        return None
+
+    def _ident_put(self, ident, ids, mask, feat):
+        if ident is not None:
+            if len(self._text_ident_cache) >= 64:                   # bounded: drop the oldest identity entry
+                self._text_ident_cache.pop(next(iter(self._text_ident_cache)))
+            self._text_ident_cache[ident] = (ids, mask, feat)
 
     def encode_prompts(self, encoded) -> torch.Tensor:
         """text_features_wo_l2_norm for a prompt set, cached: the reference re-encodes every prompt for every
@@ -322,29 +352,60 @@ class RadZeroModel:
         work, no host sync; this is what every reference caller hits, because they tokenise once and pass the same
         tensors for every image batch (inference/utils.py:92-100, grounding_utils.py:50-62).  The entry keeps the two
         tensors alive, so their storage cannot be recycled under the key, and an in-place write bumps `_version`.
-        (2) content: the token bytes, for callers that re-tokenise per call (one D2H copy of a few hundred bytes)."""
+        (2) content: the token bytes, for callers that re-tokenise per call (one D2H copy of a few hundred bytes, which also
+        carries the token-id range check); at most 512 prompt sets are kept."""
         ids = encoded["input_ids"]
         mask = encoded["attention_mask"]
         if not self.text_cache_enabled:
             return self.forward_text_model({"input_ids": ids, "attention_mask": mask})["text_features_wo_l2_norm"]
-        ident = None
-        # inference tensors (created under torch.inference_mode()) keep no version counter — reading `_version` raises — so an
-        # in-place write to them could not be noticed: they take the content key below
-        if torch.is_tensor(ids) and torch.is_tensor(mask) and not ids.is_inference() and not mask.is_inference():
-            ident = (ids.data_ptr(), mask.data_ptr(), tuple(ids.shape), tuple(mask.shape), ids.dtype, mask.dtype,
-                     str(ids.device), ids._version, mask._version)
+        ident = self._ident(ids, mask)
+        if ident is not None:
             hit = self._text_ident_cache.get(ident)
             if hit is not None:
                 return hit[2]
-        key = ids.detach().cpu().numpy().tobytes() + b"|" + mask.detach().cpu().numpy().tobytes() + str(tuple(ids.shape)).encode()
+        feat = self._encode_by_content(ids, mask)
+        self._ident_put(ident, ids, mask, feat)
+        return feat
+
+    def _encode_by_content(self, ids, mask) -> torch.Tensor:
+        """Content-keyed lookup / encode on the CURRENT stream: one host copy of the tokens serves the key and the id range check."""
+        if ids.dim() != 2 or ids.shape != mask.shape:
+            raise ValueError("input_ids / attention_mask must be (n_prompts, len) and agree")
+        hi_, hm_ = ids.detach().to("cpu", torch.int64), mask.detach().to("cpu", torch.int64)
+        key = hi_.numpy().tobytes() + b"|" + hm_.numpy().tobytes() + str(tuple(ids.shape)).encode()
         feat = self._text_cache.get(key)
         if feat is None:
-            feat = self.forward_text_model({"input_ids": ids, "attention_mask": mask})["text_features_wo_l2_norm"]
-            self._text_cache[key] = feat
-        if ident is not None:
-            if len(self._text_ident_cache) >= 64:                   # bounded: drop the oldest identity entry
-                self._text_ident_cache.pop(next(iter(self._text_ident_cache)))
-            self._text_ident_cache[ident] = (ids, mask, feat)
+            self._check_ids(int(hi_.min()), int(hi_.max()))
+            feat = self._text_forward_raw(ids.to(device=self._device, dtype=torch.int64).contiguous(),
+                                          mask.to(device=self._device, dtype=torch.int64).contiguous())
+            self._cache_put(key, feat)
+        return feat
+
+    def _encode_beside_vision(self, encoded, ids_ready: "torch.cuda.Event") -> torch.Tensor:
+        """The per-request path (a NEW text with every image: eval_refer_grounding, grounding_utils.py:283-326; extract_similarity_map,
+        attention_map_base.py:12-42): the text encoder runs on a side stream BESIDE the vision forward that the caller has already
+        enqueued on the current stream (disjoint workspaces inside the handle; the two only meet in rz_vlcabs), and the host's one
+        blocking copy of the tokens waits for `ids_ready` on that side stream, not for the vision forward.  The current stream is
+        made to wait for the embeddings before this returns.  Under stream capture the same fork / join is recorded (no cache)."""
+        ids, mask = encoded["input_ids"], encoded["attention_mask"]
+        main = torch.cuda.current_stream(self._device)
+        if self._side_stream is None:
+            self._side_stream = torch.cuda.Stream(device=self._device)
+        side = self._side_stream
+        capturing = torch.cuda.is_current_stream_capturing()
+        with torch.cuda.stream(side):
+            side.wait_event(ids_ready)
+            if capturing or not self.text_cache_enabled:
+                feat = self._text_forward_raw(ids.to(device=self._device, dtype=torch.int64).contiguous(),
+                                              mask.to(device=self._device, dtype=torch.int64).contiguous())
+            else:
+                ident = self._ident(ids, mask)
+                feat = self._encode_by_content(ids, mask)
+                self._ident_put(ident, ids, mask, feat)
+            done = torch.cuda.Event()
+            done.record(side)
+        main.wait_event(done)
+        feat.record_stream(main)
         return feat
 
     # ---- CxrAlignModel.compute_logits, compute_logits_type == "radzero" (modeling.py:278-328) ---
@@ -352,11 +413,23 @@ class RadZeroModel:
     def compute_logits(self, pixel_values, encoded_key_phrases, text_features: Optional[torch.Tensor] = None, **kwargs):
         """kwargs (encoded_negative_phrases, use_negative_logits, ...) are accepted and ignored, as in the
         reference (modeling.py:282).  `text_features` lets a data-parallel driver pass all-gathered embeddings."""
+        pending = None
         if text_features is None:
-            text_features = self.encode_prompts(encoded_key_phrases[0])
+            enc = encoded_key_phrases[0]
+            ident = self._ident(enc["input_ids"], enc["attention_mask"]) if self.text_cache_enabled else None
+            hit = self._text_ident_cache.get(ident) if ident is not None else None
+            if hit is not None:
+                text_features = hit[2]          # the same tokenised tensors as in an earlier call: every batch loop of the reference
+            else:
+                # a text this model has not been handed before: encode it BESIDE the vision forward (see _encode_beside_vision)
+                with torch.cuda.device(self._device):
+                    pending = torch.cuda.Event()
+                    pending.record(torch.cuda.current_stream(self._device))
+        _, (b, n) = self._vision(pixel_values, want_tokens=False)
+        if pending is not None:
+            text_features = self._encode_beside_vision(enc, pending)
         text_features = text_features.to(device=self._device, dtype=torch.float32).contiguous()
         t = text_features.shape[0]
-        _, (b, n) = self._vision(pixel_values, want_tokens=False)
         with torch.cuda.device(self._device):
             self._ensure(batch=b, tokens=n, prompts=t)
             scores = torch.empty((b, t, n), dtype=torch.float32, device=self._device)
@@ -448,6 +521,48 @@ class RadZeroModel:
 
         def run(pixel_values: torch.Tensor):
             static_px.copy_(pixel_values.to(device=self._device, dtype=torch.float32), non_blocking=True)
+            graph.replay()
+            return out
+
+        run.graph = graph
+        return run
+
+    def make_graphed_request(self, pixel_shape, prompt_shape, points: bool = True):
+        """The per-request path (one image + one NEW text per call: eval_refer_grounding, grounding_utils.py:283-326) as ONE HIP graph:
+        text encoder (on a forked branch) + vision forward + VL-CABS [+ fused grounding point].  Returns
+        run(pixel_values, input_ids, attention_mask) -> outputs (the graph's static buffers, overwritten by the next run).  Token ids are
+        NOT range-checked here (no host round trip inside a replay): validate them where they are produced."""
+        t, l = int(prompt_shape[0]), int(prompt_shape[1])
+        static_px = torch.zeros(tuple(pixel_shape), dtype=torch.float32, device=self._device)
+        static_ids = torch.full((t, l), self.config.pad_token_id, dtype=torch.int64, device=self._device)
+        static_ids[:, 0] = 0
+        static_mask = torch.ones((t, l), dtype=torch.int64, device=self._device)
+        enc = {"input_ids": static_ids, "attention_mask": static_mask}
+        cache_was = self.text_cache_enabled
+        self.text_cache_enabled = False
+        try:
+            with torch.cuda.device(self._device):
+                warm = torch.cuda.Stream(device=self._device)
+                warm.wait_stream(torch.cuda.current_stream(self._device))
+                with torch.cuda.stream(warm):                   # warm-up off the capture path: workspaces, tables, the side stream
+                    for _ in range(2):
+                        o = self.compute_logits(static_px, [enc])
+                        if points:
+                            self.grounding_points(o["similarity_scores"], pixel_shape[-2:])
+                torch.cuda.current_stream(self._device).wait_stream(warm)
+                torch.cuda.synchronize(self._device)
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph):
+                    out = self.compute_logits(static_px, [enc])
+                    if points:
+                        out["grounding_points"] = self.grounding_points(out["similarity_scores"], pixel_shape[-2:])
+        finally:
+            self.text_cache_enabled = cache_was
+
+        def run(pixel_values: torch.Tensor, input_ids: torch.Tensor, attention_mask: torch.Tensor):
+            static_px.copy_(pixel_values.to(device=self._device, dtype=torch.float32), non_blocking=True)
+            static_ids.copy_(input_ids.to(device=self._device, dtype=torch.int64), non_blocking=True)
+            static_mask.copy_(attention_mask.to(device=self._device, dtype=torch.int64), non_blocking=True)
             graph.replay()
             return out
 
