@@ -64,7 +64,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
 
 def _build_locked(obj_dir: str, verbose: bool, force: bool = False) -> str:
     flags = [f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "-Werror=uninitialized",
-             "-Werror=return-type"] + (["-DRZ_EXPERIMENTS"] if EXPERIMENTS else [])
+             "-Werror=return-type"] + (["-DRZ_EXPERIMENTS"] if EXPERIMENTS else []) + os.environ.get("RZ_CXXFLAGS", "").split()   # RZ_CXXFLAGS: A/B builds of a tunable (with RZ_LIB_PATH)
     tag = f".{os.getpid()}.tmp"
 
     def cc(src):

@@ -216,10 +216,40 @@ hipError_t launch_vlcabs(const float* tokens, const float* ln_gamma, const float
 }
 
 // ---- bilinear upsample, align_corners=False (F.interpolate semantics), optional sigmoid ----
-// One thread produces 4 consecutive pixels of a row (16-byte store); the two source rows of an output row are the
-// same for the whole row, so their addresses/weights are computed once per thread.  HBM-write bound:
-// n_maps*H*W*4 bytes (4.29 GB at BASELINE cfg 4).
-constexpr int UP_ROWS = 8;      // output rows per thread: the four x interpolation set-ups are amortised over them
+// segmentation_utils.py:62-70 (+ torch.sigmoid, attention_map_base.py:57).  HBM-WRITE bound: n_maps*H*W*4 bytes (4.29 GB at BASELINE cfg 4)
+// against a source of g*g floats per map that lives in L1 / L2.  One thread produces 4 consecutive pixels (one 16-byte store) of UP_ROWS
+// output rows.  Round 4: when the output is >= ~UP_ROWS x larger than the grid (every real use: 1024 / 73 = 14), the 4 x UP_ROWS outputs of a
+// thread depend on at most 3 source columns x 3 source rows: those 9 values are loaded ONCE into registers and every output row is a
+// register blend — 9 gather loads per 32 outputs instead of 128 (the round-3 kernel issued four dependent gathers per pixel and ran at
+// 4.4 TB/s = the texture-address path, not HBM) — and the stores are non-temporal (a 4 GB write-once stream should not sweep L2 / the
+// Infinity Cache).  Arithmetic per output is unchanged (same products, same order): bit-identical to the generic path, which stays as the
+// per-thread fall-back for small magnifications.
+#ifndef RZ_UP_ROWS
+#define RZ_UP_ROWS 16
+#endif
+#ifndef RZ_UP_NT
+#define RZ_UP_NT 1
+#endif
+constexpr int UP_ROWS = RZ_UP_ROWS;
+// One pixel of the bilinear map with a FIXED operation order (explicit fma / mul: nothing left to the compiler's contraction choices):
+// the map kernel's two paths and the fused argmax kernel must produce the same bits, or the argmax of a plateau (the clamped half-pixel
+// border rows are constant) lands on a different pixel than the first maximum of the written map.
+__device__ __forceinline__ float bilerp(float hy, float ly, float hx, float lx, float v00, float v01, float v10, float v11) {
+    const float top = __fmaf_rn(lx, v01, __fmul_rn(hx, v00));
+    const float bot = __fmaf_rn(lx, v11, __fmul_rn(hx, v10));
+    return __fmaf_rn(ly, bot, __fmul_rn(hy, top));
+}
+// source coordinate of output index i (F.interpolate, align_corners=False: scale * (i + 0.5) - 0.5, clamped at 0), same bits everywhere
+__device__ __forceinline__ float src_coord(float scale, int i, int off) {
+    const float f = __fmaf_rn(scale, (float)(i + off) + 0.5f, -0.5f);
+    return f < 0.f ? 0.f : f;
+}
+// torch.sigmoid of a map value (attention_map_base.py:57) on the transcendental pipe: 1 / (1 + 2^(-t log2 e)), v_exp_f32 + v_rcp_f32 (each
+// ~1 ulp: |error| < 3e-7 absolute on a value in (0, 1)); expf() + an IEEE division made the sigmoid maps VALU-bound at 3.6 TB/s
+__device__ __forceinline__ float up_sigmoid(float t) {
+    return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * t));
+}
+__device__ __forceinline__ float up_sel3(int k, float a, float b, float c) { return k == 0 ? a : (k == 1 ? b : c); }
 __global__ __launch_bounds__(256) void upsample_bilinear_kernel(const float* __restrict__ maps, int64_t map_stride,
                                                                 float* __restrict__ out, int g, int Hout, int Wout,
                                                                 float sy, float sx, int apply_sigmoid, int off_y, int off_x) {
@@ -234,7 +264,7 @@ __global__ __launch_bounds__(256) void upsample_bilinear_kernel(const float* __r
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int x = x4 + i;
-        float fx = sx * (x + off_x + 0.5f) - 0.5f; fx = fx < 0.f ? 0.f : fx;
+        const float fx = src_coord(sx, x, off_x);
         int xa = (int)fx;
         xa = xa > g - 1 ? g - 1 : xa;                         // only reachable for x >= Wout (masked below)
         x0[i] = xa;
@@ -242,33 +272,89 @@ __global__ __launch_bounds__(256) void upsample_bilinear_kernel(const float* __r
         lx[i] = fx - xa;
     }
     const bool full = x4 + 3 < Wout;
+    const int ylast = min(ybase + UP_ROWS, Hout) - 1;
+    auto ysrc = [&](int y, int& y0, int& y1, float& ly) {
+        const float fy = src_coord(sy, y, off_y);
+        y0 = (int)fy;
+        y0 = y0 > g - 1 ? g - 1 : y0;
+        y1 = y0 + (y0 < g - 1 ? 1 : 0);
+        ly = fy - y0;
+    };
+    int ys, ys1, ye, ye1; float lt;
+    ysrc(ybase, ys, ys1, lt);
+    ysrc(ylast, ye, ye1, lt);
+    const int xs = x0[0];
+    const bool fast = (x1[3] - xs <= 2) && (ye1 - ys <= 2);
+    float c[3][3];
+    if (fast) {
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+            for (int b = 0; b < 3; ++b) c[a][b] = src[min(ys + a, g - 1) * g + min(xs + b, g - 1)];
+    }
+    auto store = [&](int y, const float (&v)[4]) {
+        const int64_t base = ((int64_t)m * Hout + y) * Wout + x4;
+        float* o = out + base;
+        if (full && (base & 3) == 0) {
+#if RZ_UP_NT
+            __builtin_nontemporal_store((f32x4){v[0], v[1], v[2], v[3]}, reinterpret_cast<f32x4*>(o));
+#else
+            *reinterpret_cast<f32x4*>(o) = (f32x4){v[0], v[1], v[2], v[3]};
+#endif
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                if (x4 + i < Wout) o[i] = v[i];
+        }
+    };
+    if (fast) {
+        // the horizontal half of bilerp() — top / bot of the three candidate source rows — does not depend on the output row: once
+        float hb[3][4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float hx = 1.f - lx[i];
+            const int e0 = x0[i] - xs, e1 = x1[i] - xs;
+#pragma unroll
+            for (int k = 0; k < 3; ++k)
+                hb[k][i] = __fmaf_rn(lx[i], up_sel3(e1, c[k][0], c[k][1], c[k][2]), __fmul_rn(hx, up_sel3(e0, c[k][0], c[k][1], c[k][2])));
+        }
+#pragma unroll 4
+        for (int r = 0; r < UP_ROWS; ++r) {
+            const int y = ybase + r;
+            if (y >= Hout) break;
+            int y0, y1; float ly;
+            ysrc(y, y0, y1, ly);
+            const float hy = 1.f - ly;
+            const int d0 = y0 - ys, d1 = y1 - ys;             // wave-uniform
+            float v[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                float t = __fmaf_rn(ly, up_sel3(d1, hb[0][i], hb[1][i], hb[2][i]), __fmul_rn(hy, up_sel3(d0, hb[0][i], hb[1][i], hb[2][i])));
+                if (apply_sigmoid) t = up_sigmoid(t);
+                v[i] = t;
+            }
+            store(y, v);
+        }
+        return;
+    }
 #pragma unroll 2
     for (int r = 0; r < UP_ROWS; ++r) {
         const int y = ybase + r;
         if (y >= Hout) break;
-        float fy = sy * (y + off_y + 0.5f) - 0.5f; fy = fy < 0.f ? 0.f : fy;
-        const int y0 = (int)fy;
-        const int y1 = y0 + (y0 < g - 1 ? 1 : 0);
-        const float ly = fy - y0, hy = 1.f - ly;
+        int y0, y1; float ly;
+        ysrc(y, y0, y1, ly);
+        const float hy = 1.f - ly;
         const float* r0 = src + y0 * g;
         const float* r1 = src + y1 * g;
         float v[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const float hx = 1.f - lx[i];
-            float t = hy * (hx * r0[x0[i]] + lx[i] * r0[x1[i]]) + ly * (hx * r1[x0[i]] + lx[i] * r1[x1[i]]);
-            if (apply_sigmoid) t = 1.0f / (1.0f + expf(-t));
+            float t = bilerp(hy, ly, hx, lx[i], r0[x0[i]], r0[x1[i]], r1[x0[i]], r1[x1[i]]);
+            if (apply_sigmoid) t = up_sigmoid(t);
             v[i] = t;
         }
-        const int64_t base = ((int64_t)m * Hout + y) * Wout + x4;
-        float* o = out + base;
-        if (full && (base & 3) == 0) {
-            *reinterpret_cast<f32x4*>(o) = (f32x4){v[0], v[1], v[2], v[3]};
-        } else {
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-                if (x4 + i < Wout) o[i] = v[i];
-        }
+        store(y, v);
     }
 }
 
@@ -292,14 +378,13 @@ __global__ __launch_bounds__(256) void grounding_argmax_kernel(const float* __re
     unsigned long long best = 0ull;
     for (unsigned idx = blockIdx.x * 256u + threadIdx.x; idx < total; idx += gridDim.x * 256u) {
         const int y = idx / Wout, x = idx - y * Wout;
-        float fy = sy * (y + off_y + 0.5f) - 0.5f; fy = fy < 0.f ? 0.f : fy;
-        float fx = sx * (x + off_x + 0.5f) - 0.5f; fx = fx < 0.f ? 0.f : fx;
+        const float fy = src_coord(sy, y, off_y), fx = src_coord(sx, x, off_x);
         int y0 = (int)fy, x0 = (int)fx;
         y0 = y0 > g - 1 ? g - 1 : y0; x0 = x0 > g - 1 ? g - 1 : x0;
         const int y1 = y0 + (y0 < g - 1 ? 1 : 0), x1 = x0 + (x0 < g - 1 ? 1 : 0);
         const float ly = fy - y0, lx = fx - x0;
         const float hy = 1.f - ly, hx = 1.f - lx;
-        const float v = hy * (hx * src[y0 * g + x0] + lx * src[y0 * g + x1]) + ly * (hx * src[y1 * g + x0] + lx * src[y1 * g + x1]);
+        const float v = bilerp(hy, ly, hx, lx, src[y0 * g + x0], src[y0 * g + x1], src[y1 * g + x0], src[y1 * g + x1]);
         const unsigned long long k = pack_key(v, idx);
         best = k > best ? k : best;
     }
