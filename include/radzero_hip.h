@@ -208,6 +208,14 @@ int rz_masked_meanpool(const float* h_dev, const int64_t* attention_mask_dev, fl
 int rz_patch_embed(int dtype, const float* pixel_values_dev, int batch, int channels, int height, int width, int patch, const void* weight_dev,
                    int k_pad, const float* table_dev, int n_pad, void* im2col_ws_dev, float* out_dev, void* stream);
 
+/* fp32 GEMM on the f16 / fp8 matrix pipes, kernel level — the two operand forms of the fp32 (1e-3) mode's vision encoder
+ * (TF:dinov2/modeling_dinov2.py:199-213, :246-251, :281-297 computed with fp32 inputs): out_dev[m][n] += a[m][:] . w[n][:] + bias[n], fp32 `out_dev`
+ * read-modify-write.  form 0 = every product as three f16 MFMAs over hi/lo planes; form 1 = "MX": a_hi b_hi on the f16 pipe + the two correction
+ * terms as one block-scaled e4m3 MFMA.  a_dev (M, K), w_dev (N, K), bias_dev (N), ones_dev (N floats of 1.0), ws_a_dev / ws_w_dev: scratch of
+ * 6 (form 0) or 4 (form 1) bytes per element of a / w.  M, N multiples of 256, K a multiple of 64, >= 128. */
+int rz_gemm_f32_split(int form, const float* a_dev, const float* w_dev, const float* bias_dev, const float* ones_dev, float* out_dev,
+                      void* ws_a_dev, void* ws_w_dev, int M, int N, int K, void* stream);
+
 /* Tuning / A-B switches.  rz_set_option sets the PROCESS-WIDE value (what the measurement tools flip); rz_set_model_option sets one
  * handle's own value, which then overrides the process-wide one for that handle only (INT32_MIN = follow the process-wide value again):
  * two handles of one process can differ.  Defaults are the measured-fastest choices.
@@ -221,6 +229,10 @@ int rz_patch_embed(int dtype, const float* pixel_values_dev, int batch, int chan
  *                      always runs).  Other values run the default (the retired shapes live in the RZ_EXPERIMENTS tools library)
  *   "attn_f32_split"   1 (default) = fp32 mode runs attention as hi/lo-split f16 MFMAs; 0 = exact-fp32 MFMAs (16x16x4_f32)
  *   "gemm_f32_split"   1 (default) = fp32 mode runs the vision encoder's GEMMs as hi/lo-split f16 MFMAs; 0 = exact-fp32 MFMAs
+ *   "gemm_f32_mx"      fp32 mode, hi/lo-split GEMMs: 1 (default) = for large batches (>= 64 row tiles of 256) the two correction terms
+ *                      a_lo b_hi + a_hi b_lo run as ONE block-scaled fp8 MFMA (v_mfma_scale_f32_16x16x128_f8f6f4, e4m3 planes with fixed
+ *                      power-of-two scales) beside the f16 a_hi b_hi MFMAs: 4 MFMA-units per 64 K instead of 6, 4 bytes per operand element
+ *                      instead of 6; 2 = wherever the shape allows (token rows a multiple of 256); 0 = three f16 planes everywhere
  *   "f32_split_guard"  1 (default) = fp32 mode: a forward in which a value left the f16 range of the hi/lo planes (|x| > 65504) is
  *                      repeated on the exact-fp32 kernels before rz_vision_forward returns (one stream synchronisation per forward;
  *                      not under stream capture); rz_get_model_option(h, "f32_split_guard_reruns") counts the repeats

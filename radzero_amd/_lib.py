@@ -140,6 +140,7 @@ SYMBOLS = {
     "rz_gemm": (_I, [_I, _I, _P, _P, _P, _P, _I, _I, _I, _P]),
     "rz_gemm_ex": (_I, [_I, _I, _P, _L, _P, _L, _P, _P, _L, _P, _P, _L, _I, _I, _I, _I, _I, _P]),
     "rz_gemm_qkv": (_I, [_I, _P, _P, _P, _P, _P, _I, _I, _I, _P, _P]),
+    "rz_gemm_f32_split": (_I, [_I, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
     "rz_layernorm": (_I, [_I, _P, _P, _P, _F, _P, _P, _L, _I, _P]),
     "rz_flash_attention": (_I, [_I, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "rz_flash_attention_split_workspace": (ctypes.c_size_t, [_I, _I, _I]),

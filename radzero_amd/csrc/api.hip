@@ -39,11 +39,12 @@ struct Options {
     int sim_op;           // VL-CABS similarity: 0 = "cos" (released config), 1 = "dot" (losses.py:214-215)
     int pad_rows;         // token rows per image: 0 = multiple of 128, of 256 when that costs < 2 % more rows | 128 | 256 = always that multiple
     int f32_split_guard;  // fp32 mode: 1 = a forward whose f16 planes overflowed is repeated on the exact-fp32 kernels (default)
+    int gemm_f32_mx;      // fp32 mode: 1 (default) = the split GEMMs' two correction terms run as one block-scaled fp8 MFMA (MX form, rz_common.h) for large batches; 2 = wherever the shape allows; 0 = three f16 planes
     int gemm_raster;      // gemm12.hip: tile order inside an XCD (GemmArgs::raster): 0 = 4 x tiles_n groups | S > 0 = slab walk, <= S n tiles per slab
 };
-Options g_opt = {0, 1, 0, 0, 0, 1, 1, 1, 0, 0, 1, 0};
+Options g_opt = {0, 1, 0, 0, 0, 1, 1, 1, 0, 0, 1, 1, 0};
 const Options kInherit = {RZ_OPT_INHERIT, RZ_OPT_INHERIT, RZ_OPT_INHERIT, RZ_OPT_INHERIT, RZ_OPT_INHERIT, RZ_OPT_INHERIT, RZ_OPT_INHERIT,
-                          RZ_OPT_INHERIT, RZ_OPT_INHERIT, RZ_OPT_INHERIT, RZ_OPT_INHERIT, RZ_OPT_INHERIT};
+                          RZ_OPT_INHERIT, RZ_OPT_INHERIT, RZ_OPT_INHERIT, RZ_OPT_INHERIT, RZ_OPT_INHERIT, RZ_OPT_INHERIT};
 int* option_field(Options& o, const char* name) {
 #ifdef RZ_EXPERIMENTS      // measured, never a gain (profiles/NOTEBOOK.md): known to the tools build only; the product runs one pass, one stream
     if (!strcmp(name, "vision_chunk")) return &o.vision_chunk;
@@ -59,6 +60,7 @@ int* option_field(Options& o, const char* name) {
     if (!strcmp(name, "sim_op")) return &o.sim_op;
     if (!strcmp(name, "pad_rows")) return &o.pad_rows;
     if (!strcmp(name, "f32_split_guard")) return &o.f32_split_guard;
+    if (!strcmp(name, "gemm_f32_mx")) return &o.gemm_f32_mx;
     return nullptr;
 }
 inline int pick(int own, int process_wide) { return own == RZ_OPT_INHERIT ? process_wide : own; }
@@ -123,6 +125,7 @@ struct DevBuf {
 struct Tensor {          // one packed checkpoint tensor on the device
     void* p = nullptr;
     void* p3 = nullptr;  // fp32 mode, matrices: [N][3K] f16 planes [hi | hi | lo] for the hi/lo-split GEMMs (rz_weights_ready)
+    void* p4 = nullptr;  // fp32 mode, matrices: the MX form [N][K f16 | per 64 columns: hi8 x 64, lo8 x 64] (4 K bytes per row; rz_common.h)
     bool loaded = false;
 };
 
@@ -158,6 +161,7 @@ struct rz_model {
     int o_attn_variant() const { return pick(opt.attn_variant, g_opt.attn_variant); }
     int o_gemm_variant() const { return pick(opt.gemm_variant, g_opt.gemm_variant); }
     int o_gemm_raster() const { return pick(opt.gemm_raster, g_opt.gemm_raster); }
+    int o_gemm_f32_mx() const { return pick(opt.gemm_f32_mx, g_opt.gemm_f32_mx); }
     bool o_gemm_f32_split() const { return pick(opt.gemm_f32_split, g_opt.gemm_f32_split) != 0 && !force_exact; }
     bool o_attn_f32_split() const { return pick(opt.attn_f32_split, g_opt.attn_f32_split) != 0 && !force_exact; }
     bool o_ln_fused() const { return pick(opt.ln_fused, g_opt.ln_fused) != 0; }
@@ -193,9 +197,10 @@ struct rz_model {
     DevBuf ovf;                          // fp32 mode: one word the hi/lo-split producers OR into when a value leaves the f16 range
     unsigned* ovf_host = nullptr;        // pinned mirror of it
     int64_t guard_reruns = 0;            // forwards repeated on the exact-fp32 kernels since rz_create
-    struct SplitW { const char* p; size_t bytes; const char* p3; };
+    struct SplitW { const char* p; size_t bytes; const char* p3; const char* p4; };
     std::vector<SplitW> split_w;         // fp32 weight matrix -> its split copy
     bool split_dirty = true;             // a weight was (re)loaded since the split copies were built
+    bool mx_weights_ok = false;          // every split weight fits the MX form's hi8 plane
     // state of the last vision forward
     int last_batch = 0, last_nvalid = 0, last_npad = 0;
     // profiling
@@ -403,7 +408,7 @@ int load_text_layer(rz_model* m, TextLayer& l, const char* rest, const float* da
 // reuse_split: A was split by the previous call (q|k and v projections share their input).
 enum { A_F32 = 0, A_SPLIT = 1, A_REUSE = 2 };   // the A operand: fp32 (split here), already [M][3K] hi|lo|hi planes, or split by the previous call
 
-int gemm_f32_split(rz_model* m, int epi, GemmArgs g, int a_mode, bool out_split, hipStream_t s, bool* done) {
+int gemm_f32_split(rz_model* m, int epi, GemmArgs g, int a_mode, bool out_split, hipStream_t s, bool* done, bool mx = false) {
     *done = false;
     if (!(epi == EPI_HEADS || epi == EPI_VT || epi == EPI_GELU || epi == EPI_RESID_SCALE || epi == EPI_PATCH)) return 0;
     if (g.M % 128 || g.lda != g.K || g.ldw != g.K) return 0;
@@ -413,11 +418,28 @@ int gemm_f32_split(rz_model* m, int epi, GemmArgs g, int a_mode, bool out_split,
         if (w >= e.p && w < e.p + e.bytes) {
             const size_t row = (size_t)(w - e.p) / ((size_t)g.K * 4);
             if (e.p + row * g.K * 4 != w) return 0;
-            w3 = e.p3 + row * 3 * g.K * 2;
+            w3 = mx ? e.p4 + row * 4 * g.K : e.p3 + row * 3 * g.K * 2;
             break;
         }
     }
-    if (!w3) return 0;
+    if (!w3) return mx ? fail(RZ_ERR_STATE, "MX GEMM requested for a weight without an MX copy") : 0;
+    if (mx) {
+        // MX form (rz_common.h): rows of 4 K bytes = 2 K f16-element units; A_SPLIT = already in that form (LayerNorm / attention / fc1
+        // epilogue wrote it), A_F32 = split here (the patch embedding's im2col matrix)
+        if (a_mode == A_REUSE) return fail(RZ_ERR_STATE, "MX GEMM: A_REUSE is not used on this path");
+        if (a_mode == A_F32) {
+            if (!m->asplit.p || (size_t)g.M * 4 * g.K > m->asplit.bytes) return fail(RZ_ERR_STATE, "MX GEMM: split scratch too small");
+            RZ_HIP(launch_split3((const float*)g.A, g.lda, m->asplit.p, g.M, g.K, 2, g.ovf_flag, s));
+            g.A = m->asplit.p;
+        }
+        g.W = w3; g.lda = g.ldw = 2 * (int64_t)g.K; g.K = 2 * g.K;
+        if (!gemm_v7_mx_ok(g)) return fail(RZ_ERR_STATE, "MX GEMM: shape not supported");
+        const int out_kind = (epi == EPI_RESID_SCALE || epi == EPI_PATCH) ? 0 : (epi == EPI_GELU ? 2 : 1);
+        if ((out_kind != 0) != out_split) return fail(RZ_ERR_STATE, "MX GEMM: output form mismatch");
+        RZ_HIP(launch_gemm_v7_mx(epi, g, out_kind, s));
+        *done = true;
+        return 0;
+    }
     if (a_mode != A_SPLIT) {
         if (!m->asplit.p) return 0;
         const size_t maxk = std::max((size_t)m->F, (size_t)m->KPAD);
@@ -443,7 +465,7 @@ int gemm_f32_split(rz_model* m, int epi, GemmArgs g, int a_mode, bool out_split,
 // a_mode / out_split / plane_off: fp32 mode's hi/lo-split path only (see gemm_f32_split); with A_SPLIT or out_split the call MUST take it
 int gemm(rz_model* m, int epi, const void* A, int64_t lda, const void* W, int64_t ldw, int M, int N, int K, const float* bias,
          void* out, int64_t ldo, const float* scale, float* resid, int64_t ldr, int rpi, int heads, hipStream_t s, int a_mode = A_F32,
-         bool out_split = false, int64_t plane_off = 0) {
+         bool out_split = false, int64_t plane_off = 0, bool mx = false) {
     GemmArgs g;
     g.A = A; g.lda = lda; g.W = W; g.ldw = ldw; g.M = M; g.N = N; g.K = K; g.bias = bias; g.out = out; g.ldo = ldo;
     g.scale = scale; g.resid = resid; g.ldr = ldr; g.rows_per_image = rpi; g.heads_total = heads; g.plane_off = plane_off;
@@ -451,7 +473,7 @@ int gemm(rz_model* m, int epi, const void* A, int64_t lda, const void* W, int64_
     ProfScope ps(m, RZ_PROF_GEMM, s);
     if (m->dt == RZ_F32 && m->o_gemm_f32_split()) {
         bool done = false;
-        int rc = gemm_f32_split(m, epi, g, a_mode, out_split, s, &done);
+        int rc = gemm_f32_split(m, epi, g, a_mode, out_split, s, &done, mx);
         if (rc || done) return rc;
     }
     if (a_mode == A_SPLIT || out_split) return fail(RZ_ERR_STATE, "split GEMM requested but not applicable");
@@ -700,16 +722,22 @@ int rz_weights_ready(rz_handle_t m) {
     if (m->dt == RZ_F32 && m->split_dirty) {     // f16 [hi | hi | lo] copies of the vision encoder's matrices for the hi/lo-split GEMMs
         m->split_w.clear();
         // overflow guard words: [0] activations (cleared by every forward), [1] weights (checked here, once)
-        RZ_HIP(m->ovf.ensure(8, true));
-        if (!m->ovf_host) RZ_HIP(hipHostMalloc((void**)&m->ovf_host, 8, hipHostMallocDefault));
-        RZ_HIP(hipMemset(m->ovf.p, 0, 8));
+        // overflow guard words: [0] activations, [1] weights beyond the f16 range, [2] weights beyond the MX hi8 range (|w| > 28)
+        RZ_HIP(m->ovf.ensure(16, true));
+        if (!m->ovf_host) RZ_HIP(hipHostMalloc((void**)&m->ovf_host, 16, hipHostMallocDefault));
+        RZ_HIP(hipMemset(m->ovf.p, 0, 16));
         auto split = [&](Tensor& t, size_t N, size_t K) -> int {
             if (!t.p3) {
                 RZ_HIP(hipMalloc(&t.p3, N * 3 * K * 2));
                 m->allocs.push_back(t.p3);
             }
             RZ_HIP(launch_split3((const float*)t.p, (int64_t)K, t.p3, (int64_t)N, (int)K, 1, (unsigned*)m->ovf.p + 1, nullptr));
-            m->split_w.push_back({(const char*)t.p, N * K * 4, (const char*)t.p3});
+            if (!t.p4) {                 // the MX form beside it (K % 64 == 0 everywhere on this path: 640, 768, 3072)
+                RZ_HIP(hipMalloc(&t.p4, N * 4 * K));
+                m->allocs.push_back(t.p4);
+            }
+            RZ_HIP(launch_split3((const float*)t.p, (int64_t)K, t.p4, (int64_t)N, (int)K, 3, (unsigned*)m->ovf.p + 2, nullptr));
+            m->split_w.push_back({(const char*)t.p, N * K * 4, (const char*)t.p3, (const char*)t.p4});
             return 0;
         };
         const size_t D = m->D, F = m->F;
@@ -718,8 +746,9 @@ int rz_weights_ready(rz_handle_t m) {
             if ((rc = split(b.wqkv, 3 * D, D)) || (rc = split(b.wo, D, D)) || (rc = split(b.w1, F, D)) || (rc = split(b.w2, D, F))) return rc;
         }
         RZ_HIP(hipDeviceSynchronize());
-        RZ_HIP(hipMemcpy(m->ovf_host, m->ovf.p, 8, hipMemcpyDeviceToHost));
+        RZ_HIP(hipMemcpy(m->ovf_host, m->ovf.p, 16, hipMemcpyDeviceToHost));
         if (m->ovf_host[1]) m->split_w.clear();      // a weight beyond the f16 range: this checkpoint runs on the exact-fp32 GEMM kernels
+        m->mx_weights_ok = !m->ovf_host[2];          // a weight beyond the hi8 plane's range: the three-plane f16 form only
         m->split_dirty = false;
     }
     return 0;
@@ -849,6 +878,10 @@ static int vision_forward_once(rz_handle_t m, const float* px, int B, int C, int
         // fp32 mode on the f16 matrix pipe: activations between the kernels travel as hi/lo f16 planes (6 bytes per element where they feed
         // a GEMM: [hi | lo | hi] along K; 4 where they feed the attention: hi plane, lo plane)
         const bool sp = m->dt == RZ_F32 && m->o_gemm_f32_split() && m->o_attn_f32_split() && !m->split_w.empty();
+        // MX form of the split GEMMs (rz_common.h): every GEMM of the chunk or none (the producers write ONE operand form).  The 256 x 256
+        // kernel that runs it needs M % 256 == 0; option 1 (default) takes it where that kernel's grid fills the chip, 2 wherever it applies
+        const int mxo = m->o_gemm_f32_mx();
+        const bool mx = sp && mxo != 0 && m->mx_weights_ok && M % 256 == 0 && (mxo == 2 || M >= 256 * 64);
         const size_t ex = m->dt == RZ_F32 ? 6 : es;
         char* xn = (char*)m->xn.p + row0 * D * ex;
         char* qkb = (char*)m->qk.p + row0 * 2 * D * es;
@@ -866,7 +899,7 @@ static int vision_forward_once(rz_handle_t m, const float* px, int B, int C, int
             RZ_HIP(launch_im2col(m->dt, pxc, mid, Bc, C, Himg, Wimg, P, gh, gw, np, m->KPAD, s));
         }
         if ((rc = gemm(m, EPI_PATCH, mid, m->KPAD, m->patch_w.p, m->KPAD, M, D, m->KPAD, nullptr, h, D,
-                       (const float*)it->second.buf.p, nullptr, 0, np, 0, s))) return rc;
+                       (const float*)it->second.buf.p, nullptr, 0, np, 0, s, A_F32, false, 0, mx))) return rc;
 
         const int nblocks = (int)m->blocks.size();
         // LayerNorm fused into the GEMMs either side of it (gemm8.hip): every block of this chunk or none
@@ -893,13 +926,13 @@ static int vision_forward_once(rz_handle_t m, const float* px, int B, int C, int
             if (sp) {
                 {
                     ProfScope ps(m, RZ_PROF_ROWOPS, s);
-                    RZ_HIP(launch_layernorm_split3(h, (const float*)b.ln1_g.p, (const float*)b.ln1_b.p, eps, xn, M, D, (unsigned*)m->ovf.p, s));
+                    RZ_HIP(launch_layernorm_split3(h, (const float*)b.ln1_g.p, (const float*)b.ln1_b.p, eps, xn, M, D, (unsigned*)m->ovf.p, s, mx));
                 }
                 // q | k -> hi / lo planes of [Bc][2H][np][64]; V^T -> hi / lo planes of [Bc][H][64][np]
                 const char* wv = (const char*)b.wqkv.p + (size_t)2 * D * D * 4;
                 if ((rc = gemm(m, EPI_HEADS, xn, D, b.wqkv.p, D, M, 2 * D, D, (const float*)b.bqkv.p, qkb, 0, nullptr, nullptr, 0, np, 2 * H, s, A_SPLIT, true,
-                               (int64_t)M * 2 * D))) return rc;
-                if ((rc = gemm(m, EPI_VT, xn, D, wv, D, M, D, D, (const float*)b.bqkv.p + 2 * D, vtb, 0, nullptr, nullptr, 0, np, H, s, A_SPLIT, true, (int64_t)M * D))) return rc;
+                               (int64_t)M * 2 * D, mx))) return rc;
+                if ((rc = gemm(m, EPI_VT, xn, D, wv, D, M, D, D, (const float*)b.bqkv.p + 2 * D, vtb, 0, nullptr, nullptr, 0, np, H, s, A_SPLIT, true, (int64_t)M * D, mx))) return rc;
             } else if (!fused) {
                 {
                     ProfScope ps(m, RZ_PROF_ROWOPS, s);
@@ -929,7 +962,7 @@ static int vision_forward_once(rz_handle_t m, const float* px, int B, int C, int
                 const char* kb = qb + (size_t)H * np * 64 * es;
                 if (sp)                                         // planes in (f16: k heads start H*np*64 ELEMENTS behind q), [hi | lo | hi] ctx out
                     RZ_HIP(launch_flash_attn_split_planes(qb, qb + (size_t)H * np * 64 * 2, vtb, ctxb, (int64_t)2 * H * np * 64, (int64_t)M * 2 * D, (int64_t)M * D,
-                                                          Bc, H, nv, np, (unsigned*)m->ovf.p, s));
+                                                          Bc, H, nv, np, (unsigned*)m->ovf.p, s, mx));
                 else if (m->dt == RZ_F32 && m->o_attn_f32_split())      // hi/lo f16 planes of q, k, V^T live in `mid` (free between the QKV and fc1 GEMMs: 3/4 of it)
                     RZ_HIP(launch_flash_attn_f32_split((const float*)qb, (const float*)kb, (const float*)vtb, (float*)ctxb, mid, (int64_t)2 * H * np * 64,
                                                        Bc, H, nv, np, (unsigned*)m->ovf.p, s));
@@ -937,10 +970,10 @@ static int vision_forward_once(rz_handle_t m, const float* px, int B, int C, int
                     RZ_HIP(flash_attn(m->o_attn_variant(), m->dt, qb, kb, vtb, ctxb, (int64_t)2 * H * np * 64, Bc, H, nv, np, s));
             }
             if (sp) {
-                if ((rc = gemm(m, EPI_RESID_SCALE, ctxb, D, b.wo.p, D, M, D, D, (const float*)b.bo.p, nullptr, 0, (const float*)b.ls1.p, h, D, np, 0, s, A_SPLIT))) return rc;
+                if ((rc = gemm(m, EPI_RESID_SCALE, ctxb, D, b.wo.p, D, M, D, D, (const float*)b.bo.p, nullptr, 0, (const float*)b.ls1.p, h, D, np, 0, s, A_SPLIT, false, 0, mx))) return rc;
                 {
                     ProfScope ps(m, RZ_PROF_ROWOPS, s);
-                    RZ_HIP(launch_layernorm_split3(h, (const float*)b.ln2_g.p, (const float*)b.ln2_b.p, eps, xn, M, D, (unsigned*)m->ovf.p, s));
+                    RZ_HIP(launch_layernorm_split3(h, (const float*)b.ln2_g.p, (const float*)b.ln2_b.p, eps, xn, M, D, (unsigned*)m->ovf.p, s, mx));
                 }
             } else if (!fused) {
                 if ((rc = gemm(m, EPI_RESID_SCALE, ctxb, D, b.wo.p, D, M, D, D, (const float*)b.bo.p, nullptr, 0, (const float*)b.ls1.p, h, D, np, 0, s))) return rc;
@@ -964,8 +997,8 @@ static int vision_forward_once(rz_handle_t m, const float* px, int B, int C, int
                     if ((rc = gemm_resid_ln(m, mid, F, b.w2, b.b2, b.ls2, M, F, h, np, m->blocks[li + 1].ln1_g, xn, part, lnmu, stat, eps, s))) return rc;
                 }
             } else if (sp) {        // fc1 writes [hi | lo | hi] of GELU(.) straight into fc2's A operand
-                if ((rc = gemm(m, EPI_GELU, xn, D, b.w1.p, D, M, F, D, (const float*)b.b1.p, mid, F, nullptr, nullptr, 0, np, 0, s, A_SPLIT, true))) return rc;
-                if ((rc = gemm(m, EPI_RESID_SCALE, mid, F, b.w2.p, F, M, D, F, (const float*)b.b2.p, nullptr, 0, (const float*)b.ls2.p, h, D, np, 0, s, A_SPLIT))) return rc;
+                if ((rc = gemm(m, EPI_GELU, xn, D, b.w1.p, D, M, F, D, (const float*)b.b1.p, mid, F, nullptr, nullptr, 0, np, 0, s, A_SPLIT, true, 0, mx))) return rc;
+                if ((rc = gemm(m, EPI_RESID_SCALE, mid, F, b.w2.p, F, M, D, F, (const float*)b.b2.p, nullptr, 0, (const float*)b.ls2.p, h, D, np, 0, s, A_SPLIT, false, 0, mx))) return rc;
             } else {
                 for (int i0 = 0; i0 < Bc; i0 += mlp_images) {
                     const int Mi = std::min(mlp_images, Bc - i0) * np;
@@ -1220,6 +1253,30 @@ int rz_gemm_ex(int dtype, int epilogue, const void* a, int64_t lda, const void* 
     g.scale = scale; g.resid = resid; g.ldr = ldr; g.rows_per_image = rows_per_image > 0 ? rows_per_image : M; g.heads_total = heads_total;
     g.variant = g_opt.gemm_variant; g.raster = g_opt.gemm_raster;
     RZ_HIP(launch_gemm(dtype, epilogue, g, (hipStream_t)stream));
+    return 0;
+}
+
+// fp32 GEMM on the f16 / fp8 matrix pipes, kernel level (the forms the fp32 mode's vision encoder uses): out[m][n] += a[m][:] . w[n][:] + bias[n]
+// (read-modify-write of the fp32 `out`, i.e. EPI_RESID_SCALE with LayerScale 1).  form 0: three f16 planes per operand ([hi | lo | hi] x
+// [hi | hi | lo]); form 1: the MX form (f16 hi plane + block-scaled e4m3 correction planes, rz_common.h).  ws_a / ws_w: 6 (form 0) or 4
+// (form 1) bytes per element of a / w; ones: N floats of 1.0 (the LayerScale vector).
+int rz_gemm_f32_split(int form, const float* a, const float* w, const float* bias, const float* ones, float* out, void* ws_a, void* ws_w,
+                      int M, int N, int K, void* stream) {
+    if (!a || !w || !out || !ws_a || !ws_w || !ones || (form != 0 && form != 1)) return fail(RZ_ERR_INVALID, "rz_gemm_f32_split: bad argument");
+    if (M % 256 || N % 256 || K % 64 || K < 128) return fail(RZ_ERR_INVALID, "rz_gemm_f32_split: M, N multiples of 256, K a multiple of 64 >= 128");
+    hipStream_t s = (hipStream_t)stream;
+    RZ_HIP(launch_split3(a, K, ws_a, M, K, form ? 2 : 0, nullptr, s));
+    RZ_HIP(launch_split3(w, K, ws_w, N, K, form ? 3 : 1, nullptr, s));
+    GemmArgs g;
+    g.A = ws_a; g.W = ws_w; g.M = M; g.N = N; g.bias = bias; g.out = nullptr; g.ldo = 0; g.scale = ones; g.resid = out; g.ldr = N;
+    g.rows_per_image = M; g.heads_total = 0;
+    if (form) {
+        g.lda = g.ldw = 2 * (int64_t)K; g.K = 2 * K;
+        RZ_HIP(launch_gemm_v7_mx(EPI_RESID_SCALE, g, 0, s));
+    } else {
+        g.lda = g.ldw = 3 * (int64_t)K; g.K = 3 * K; g.variant = 7;
+        RZ_HIP(launch_gemm_split_f32out(EPI_RESID_SCALE, g, s, false));
+    }
     return 0;
 }
 

@@ -835,8 +835,9 @@ __global__ __launch_bounds__(256, 1) void flash_attn_ks_kernel(const bf16_t* __r
 // Same tiles, fragment maps and XCD mapping as flash_attn_workgroup<f16, 4, 2>; LDS holds both planes of K and V^T, double buffered
 // (64 KB, two workgroups per CU); the running maximum is tracked (P <= 2^8 fits f16).  Output: fp32 ctx.
 // ---------------------------------------------------------------------------------------------
-// OUT_SPLIT: ctx leaves as the out-projection's split A operand [rows][3 * H * 64] f16 = [hi | lo | hi] instead of fp32.
-template <bool OUT_SPLIT>
+// OUT_SPLIT: ctx leaves as the out-projection's split A operand instead of fp32: 1 = [rows][3 * H * 64] f16 = [hi | lo | hi],
+// 2 = the MX form (rz_common.h: [hi f16 x D | per head: lo8 x 64, hi8 x 64], 4 D bytes per row).
+template <int OUT_SPLIT>
 __global__ __launch_bounds__(256, 2) void flash_attn_split_kernel(const f16_t* __restrict__ q, const f16_t* __restrict__ k,
                                                                   const f16_t* __restrict__ vT, void* __restrict__ ctx_out,
                                                                   int64_t qk_batch_stride, int64_t qk_lo_off, int64_t v_lo_off,
@@ -1073,7 +1074,20 @@ __global__ __launch_bounds__(256, 2) void flash_attn_split_kernel(const f16_t* _
         const float inv = 1.0f / l;
         const int qrow = q0 + qt * 16 + l15;
         const int D = H * 64;
-        if constexpr (OUT_SPLIT) {
+        if constexpr (OUT_SPLIT == 2) {
+            char* o = reinterpret_cast<char*>(ctx_out) + ((int64_t)b * n_pad + qrow) * (4 * D);
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                f16x4 hi;
+                uint32_t lo8, hi8;
+                split4_mx(oacc[qt][dt] * inv, hi, lo8, hi8, MX_A_HI_SCALE, MX_A_LO_SCALE, ovf_flag);
+                const int k = h * 64 + lg * 4 + dt * 16;
+                *reinterpret_cast<f16x4*>(o + 2 * k) = hi;
+                char* pr = o + mx_pair_off(D, k);
+                *reinterpret_cast<uint32_t*>(pr) = lo8;
+                *reinterpret_cast<uint32_t*>(pr + 64) = hi8;
+            }
+        } else if constexpr (OUT_SPLIT == 1) {
             f16_t* o = reinterpret_cast<f16_t*>(ctx_out) + ((int64_t)b * n_pad + qrow) * (3 * D) + h * 64 + lg * 4;
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt) {
@@ -1122,19 +1136,23 @@ hipError_t launch_flash_attn_f32_split(const float* q, const float* k, const flo
     hipLaunchKernelGGL(split_f16_kernel, sgrid, dim3(256), 0, s, vT, per, v_hi, v_hi + n, per / 4, ovf_flag);
     const int nq = n_pad / FA_QROWS;
     dim3 grid(((B * H * nq + 7) / 8) * 8), block(256);
-    hipLaunchKernelGGL(flash_attn_split_kernel<false>, grid, block, 0, s, q_hi, k_hi, v_hi, (void*)ctx, per, n, n, B, H, n_valid, n_pad, ovf_flag);
+    hipLaunchKernelGGL(flash_attn_split_kernel<0>, grid, block, 0, s, q_hi, k_hi, v_hi, (void*)ctx, per, n, n, B, H, n_valid, n_pad, ovf_flag);
     return hipGetLastError();
 }
 
 // The same kernel on operands that are ALREADY hi/lo planes (written by the split q|k / V^T epilogues, gemm_common.h): q_hi, k_hi
 // with batch stride qk_batch_stride, lo planes qk_lo_off / v_lo_off elements behind the hi planes; ctx3 = [rows][3 * H * 64] f16.
 hipError_t launch_flash_attn_split_planes(const void* q_hi, const void* k_hi, const void* v_hi, void* ctx3, int64_t qk_batch_stride,
-                                          int64_t qk_lo_off, int64_t v_lo_off, int B, int H, int n_valid, int n_pad, unsigned* ovf_flag, hipStream_t s) {
+                                          int64_t qk_lo_off, int64_t v_lo_off, int B, int H, int n_valid, int n_pad, unsigned* ovf_flag, hipStream_t s, int mx_out) {
     if (n_pad % FA_QROWS || n_valid <= 0 || n_valid > n_pad || B <= 0 || H <= 0) return hipErrorInvalidValue;
     const int nq = n_pad / FA_QROWS;
     dim3 grid(((B * H * nq + 7) / 8) * 8), block(256);
-    hipLaunchKernelGGL(flash_attn_split_kernel<true>, grid, block, 0, s, (const f16_t*)q_hi, (const f16_t*)k_hi, (const f16_t*)v_hi, ctx3,
-                       qk_batch_stride, qk_lo_off, v_lo_off, B, H, n_valid, n_pad, ovf_flag);
+    if (mx_out)
+        hipLaunchKernelGGL(flash_attn_split_kernel<2>, grid, block, 0, s, (const f16_t*)q_hi, (const f16_t*)k_hi, (const f16_t*)v_hi, ctx3,
+                           qk_batch_stride, qk_lo_off, v_lo_off, B, H, n_valid, n_pad, ovf_flag);
+    else
+        hipLaunchKernelGGL(flash_attn_split_kernel<1>, grid, block, 0, s, (const f16_t*)q_hi, (const f16_t*)k_hi, (const f16_t*)v_hi, ctx3,
+                           qk_batch_stride, qk_lo_off, v_lo_off, B, H, n_valid, n_pad, ovf_flag);
     return hipGetLastError();
 }
 

@@ -356,11 +356,36 @@ __global__ __launch_bounds__(256) void split3_rows_kernel(const float* __restric
     }
 }
 
+// src fp32 [rows][K] -> MX form (rz_common.h): row = [hi f16 x K | per 64 columns: activations lo8 x 64, hi8 x 64 | weights hi8 x 64, lo8 x 64]
+__global__ __launch_bounds__(256) void split_mx_rows_kernel(const float* __restrict__ src, int64_t ld, char* __restrict__ dst, int64_t rows,
+                                                            int K, int weights, unsigned* ovf_flag) {
+    const int k4 = K / 4;
+    const int64_t total = rows * k4;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t r = i / k4;
+        const int c = (int)(i - r * k4) * 4;
+        const f32x4 v = *reinterpret_cast<const f32x4*>(src + r * ld + c);
+        f16x4 h;
+        uint32_t lo8, hi8;
+        split4_mx(v, h, lo8, hi8, weights ? MX_W_HI_SCALE : MX_A_HI_SCALE, weights ? MX_W_LO_SCALE : MX_A_LO_SCALE, ovf_flag);
+        char* o = dst + r * 4 * K;
+        *reinterpret_cast<f16x4*>(o + 2 * c) = h;
+        char* pr = o + mx_pair_off(K, c);
+        *reinterpret_cast<uint32_t*>(pr) = weights ? hi8 : lo8;
+        *reinterpret_cast<uint32_t*>(pr + 64) = weights ? lo8 : hi8;
+    }
+}
+
 hipError_t launch_split3(const float* src, int64_t ld, void* dst, int64_t rows, int K, int w_layout, unsigned* ovf_flag, hipStream_t s) {
     if (rows <= 0 || K <= 0 || K % 4 || ld % 4) return hipErrorInvalidValue;
     const int64_t total = rows * (K / 4);
     const int blocks = (int)std::min<int64_t>((total + 255) / 256, 8192);
-    hipLaunchKernelGGL(split3_rows_kernel, dim3(blocks), dim3(256), 0, s, src, ld, (f16_t*)dst, rows, K, w_layout, ovf_flag);
+    if (w_layout >= 2) {
+        if (K % 64) return hipErrorInvalidValue;
+        hipLaunchKernelGGL(split_mx_rows_kernel, dim3(blocks), dim3(256), 0, s, src, ld, (char*)dst, rows, K, w_layout == 3 ? 1 : 0, ovf_flag);
+    } else {
+        hipLaunchKernelGGL(split3_rows_kernel, dim3(blocks), dim3(256), 0, s, src, ld, (f16_t*)dst, rows, K, w_layout, ovf_flag);
+    }
     return hipGetLastError();
 }
 

@@ -27,6 +27,8 @@
 //        in interval 2p+8 and a barrier follows, group 0 reads in interval 2p+10, group 1 in 2p+11.
 //   WAR  a unit overwrites rows whose last ds_read was issued at least two phases (four barriers) earlier by either
 //        group, and every ds_read is retired (lgkmcnt) before the MFMAs of its own phase.
+#include <type_traits>
+
 #include "gemm_common.h"
 
 namespace rz {
@@ -60,11 +62,13 @@ template <int N> __device__ __forceinline__ void v7_wait_vm() {
 
 // One K tile.  S1: tile T+1 exists (issue its U2, U3 into `nxt`), S2: tile T+2 exists (issue its U0, U1 into `cur`).
 // a1/w1 (a2/w2): this wave's per-lane source pointers at the K offset of tile T+1 (T+2).
-template <typename T, bool SWAP, bool S1, bool S2, int MODE>
+// MX: this K tile is a 128-byte fp8 tile of the fp32 mode's MX form (rz_common.h): ONE block-scaled MFMA per accumulator tile, with the
+// fragments of both k-halves as its 32-byte operands; sa / sw = this lane's E8M0 scale bytes for the A rows / the W rows.
+template <typename T, bool SWAP, bool S1, bool S2, int MODE, bool MX = false>
 __device__ __forceinline__ void v7_tile(f32x4 (&acc)[2][4][4], char* cur, char* nxt, unsigned a_rd, unsigned b_rd,
                                         const char* const (&a1)[2], const char* const (&w1)[2], const char* const (&a2)[2],
                                         const char* const (&w2)[2], int64_t a_sub, int64_t w_sub, unsigned a_dst, unsigned w_dst,
-                                        unsigned long long (&st)[24]) {
+                                        unsigned long long (&st)[24], int sa = 0, int sw = 0) {
     typedef typename Traits<T>::frag frag_t;
     frag_t fa[2][4], fb0[2][2], fb1[2][2];          // [k-half][fragment]
 #pragma unroll
@@ -105,13 +109,28 @@ __device__ __forceinline__ void v7_tile(f32x4 (&acc)[2][4][4], char* cur, char* 
         // ---- MFMA part: quadrant (mi, ni) = (0,0) (0,1) (1,1) (1,0)
         const int mi = u >> 1, ni = (u == 1 || u == 2) ? 1 : 0;
         __builtin_amdgcn_s_setprio(1);
+        if constexpr (MX) {
+            if constexpr (std::is_same<T, f16_t>::value) {
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
+                for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+                    for (int j = 0; j < 2; ++j) {
+                        f32x4& c = acc[mi][i][ni * 2 + j];
+                        const frag_t& b0 = ni ? fb1[0][j] : fb0[0][j];
+                        const frag_t& b1 = ni ? fb1[1][j] : fb0[1][j];
+                        if constexpr (SWAP) c = mma_mx(b0, b1, fa[0][i], fa[1][i], c, sw, sa);
+                        else c = mma_mx(fa[0][i], fa[1][i], b0, b1, c, sa, sw);
+                    }
+            }
+        } else {
 #pragma unroll
-                for (int j = 0; j < 2; ++j)
-                    v7_mma<T, SWAP>(acc[mi][i][ni * 2 + j], fa[ks][i], ni ? fb1[ks][j] : fb0[ks][j]);
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        v7_mma<T, SWAP>(acc[mi][i][ni * 2 + j], fa[ks][i], ni ? fb1[ks][j] : fb0[ks][j]);
+        }
         __builtin_amdgcn_s_setprio(0);
         RZ_STAMP(u * 6 + 3)
         // everything issued three or more phases ago must have landed: count the units issued in phases q-2, q-1, q
@@ -129,7 +148,9 @@ __device__ __forceinline__ void v7_tile(f32x4 (&acc)[2][4][4], char* cur, char* 
 }
 
 // OT = type of the outputs (default: the operand type); float / split_f16 = the fp32 mode's hi/lo-split GEMMs (gemm.hip)
-template <typename T, int EPI, int MODE, typename OT = T>
+// MXK: the fp32 mode's MX form — operand rows are [K f16 | 2 K fp8 bytes], g.K = 2 K counts 128-byte K tiles x 64: the first half of the
+// K tiles runs the f16 MFMAs (a_hi b_hi), the second half the block-scaled fp8 MFMA (the two correction terms)
+template <typename T, int EPI, int MODE, typename OT = T, bool MXK = false>
 __global__ __launch_bounds__(512, 2) void gemm_kernel_v7(GemmArgs g) {
     static_assert(sizeof(T) == 2, "v7 is for 16-bit operands");
     __shared__ __attribute__((aligned(1024))) char lds[2 * V7_STAGE];
@@ -198,8 +219,11 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel_v7(GemmArgs g) {
         for (int i = 0; i < 24; ++i) st[i] = 0;
         clk0 = __builtin_amdgcn_s_memtime(); rt0 = __builtin_amdgcn_s_memrealtime();
     }
+    // E8M0 scale byte of this lane's 32-element block (block index = lane >> 4): A rows = [lo8 | hi8], W rows = [hi8 | lo8]
+    const int sa = lg < 2 ? MX_E8_A_LO : MX_E8_A_HI, sw = lg < 2 ? MX_E8_W_HI : MX_E8_W_LO;
+    const int nkh = MXK ? nk / 2 : nk;          // MXK: nk >= 4 and even
     int kt = 0;
-    for (; kt + 2 < nk; ++kt) {
+    for (; kt + 2 < nk && kt < nkh; ++kt) {
         char* cur = lds + (kt & 1) * V7_STAGE;
         char* nxt = lds + ((kt + 1) & 1) * V7_STAGE;
         const int64_t k1 = (int64_t)(kt + 1) * 128, k2 = k1 + 128;
@@ -208,6 +232,18 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel_v7(GemmArgs g) {
         const char* a2[2] = {a_src[0] + k2, a_src[1] + k2};
         const char* w2[2] = {w_src[0] + k2, w_src[1] + k2};
         v7_tile<T, SWAP, true, true, MODE>(acc, cur, nxt, a_rd, b_rd, a1, w1, a2, w2, a_sub, w_sub, a_dst, w_dst, st);
+    }
+    if constexpr (MXK) {
+        for (; kt + 2 < nk; ++kt) {
+            char* cur = lds + (kt & 1) * V7_STAGE;
+            char* nxt = lds + ((kt + 1) & 1) * V7_STAGE;
+            const int64_t k1 = (int64_t)(kt + 1) * 128, k2 = k1 + 128;
+            const char* a1[2] = {a_src[0] + k1, a_src[1] + k1};
+            const char* w1[2] = {w_src[0] + k1, w_src[1] + k1};
+            const char* a2[2] = {a_src[0] + k2, a_src[1] + k2};
+            const char* w2[2] = {w_src[0] + k2, w_src[1] + k2};
+            v7_tile<T, SWAP, true, true, MODE, true>(acc, cur, nxt, a_rd, b_rd, a1, w1, a2, w2, a_sub, w_sub, a_dst, w_dst, st, sa, sw);
+        }
     }
     if constexpr (MODE == 2) {          // diagnostic build: stamps of the last steady-state K tile of workgroup 0 -> g.resid (u64[8][24] + 2)
         if (bid == 0 && lane == 0 && g.resid) {
@@ -226,8 +262,8 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel_v7(GemmArgs g) {
         const char* a1[2] = {a_src[0] + k1, a_src[1] + k1};
         const char* w1[2] = {w_src[0] + k1, w_src[1] + k1};
         unsigned long long st2[24];
-        v7_tile<T, SWAP, true, false, MODE == 2 ? 0 : MODE>(acc, cur, nxt, a_rd, b_rd, a1, w1, a1, w1, a_sub, w_sub, a_dst, w_dst, st2);
-        v7_tile<T, SWAP, false, false, MODE == 2 ? 0 : MODE>(acc, nxt, cur, a_rd, b_rd, a1, w1, a1, w1, a_sub, w_sub, a_dst, w_dst, st2);
+        v7_tile<T, SWAP, true, false, MODE == 2 ? 0 : MODE, MXK>(acc, cur, nxt, a_rd, b_rd, a1, w1, a1, w1, a_sub, w_sub, a_dst, w_dst, st2, sa, sw);
+        v7_tile<T, SWAP, false, false, MODE == 2 ? 0 : MODE, MXK>(acc, nxt, cur, a_rd, b_rd, a1, w1, a1, w1, a_sub, w_sub, a_dst, w_dst, st2, sa, sw);
     }
     if (wr == 0) __builtin_amdgcn_s_barrier();
     }
@@ -288,6 +324,27 @@ hipError_t launch_gemm_v7_f16_out(int epi, const GemmArgs& g, bool split_out, hi
         }
     }
 #undef RZ_CASE7O
+    return hipGetLastError();
+}
+
+// fp32 mode, MX form (rz_common.h): operand rows [K f16 | 2 K fp8 bytes], g.lda / g.ldw = 2 K and g.K = 2 K in f16-element units (so the
+// staging code sees an ordinary K' = 2 K GEMM).  out_kind 0: fp32 read-modify-write / table epilogues (EPI_RESID_SCALE, EPI_PATCH);
+// 1: hi/lo f16 planes for the attention (EPI_HEADS, EPI_VT); 2: the next GEMM's A operand in MX form (EPI_GELU).
+bool gemm_v7_mx_ok(const GemmArgs& g) {
+    return g.M % V7_BM == 0 && g.N % V7_BN == 0 && g.K % 128 == 0 && g.K >= 256;
+}
+hipError_t launch_gemm_v7_mx(int epi, const GemmArgs& g, int out_kind, hipStream_t s) {
+    if (!gemm_v7_mx_ok(g)) return hipErrorInvalidValue;
+    dim3 grid((g.M / V7_BM) * (g.N / V7_BN)), block(512);
+#define RZ_CASE7M(E, OT) case E: hipLaunchKernelGGL((gemm_kernel_v7<f16_t, E, 0, OT, true>), grid, block, 0, s, g); break;
+    if (out_kind == 0) {
+        switch (epi) { RZ_CASE7M(EPI_RESID_SCALE, f16_t) RZ_CASE7M(EPI_PATCH, f16_t) default: return hipErrorInvalidValue; }
+    } else if (out_kind == 1) {
+        switch (epi) { RZ_CASE7M(EPI_HEADS, split_f16) RZ_CASE7M(EPI_VT, split_f16) default: return hipErrorInvalidValue; }
+    } else {
+        switch (epi) { RZ_CASE7M(EPI_GELU, split_mx) default: return hipErrorInvalidValue; }
+    }
+#undef RZ_CASE7M
     return hipGetLastError();
 }
 

@@ -201,7 +201,18 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, const f32x4 (&a
                     const f32x4 b = *reinterpret_cast<const f32x4*>(g.bias + n);
                     v += b;
                 }
-                if constexpr (std::is_same<T, split_f16>::value) {
+                if constexpr (std::is_same<T, split_mx>::value) {
+                    // fp32 mode, MX form: exact-erf GELU -> the next GEMM's A operand [hi f16 x N | per 64 columns: lo8 x 64, hi8 x 64] (rz_common.h)
+                    static_assert(EPI == EPI_GELU, "MX-form output: the fc1 epilogue");
+                    f16x4 hi;
+                    uint32_t lo8, hi8;
+                    split4_mx((f32x4){gelu_erf(v[0]), gelu_erf(v[1]), gelu_erf(v[2]), gelu_erf(v[3])}, hi, lo8, hi8, MX_A_HI_SCALE, MX_A_LO_SCALE, g.ovf_flag);
+                    char* row = reinterpret_cast<char*>(g.out) + (int64_t)m * 4 * g.ldo;
+                    *reinterpret_cast<f16x4*>(row + 2 * n) = hi;
+                    char* pr = row + mx_pair_off((int)g.ldo, n);
+                    *reinterpret_cast<uint32_t*>(pr) = lo8;
+                    *reinterpret_cast<uint32_t*>(pr + 64) = hi8;
+                } else if constexpr (std::is_same<T, split_f16>::value) {
                     // fp32 mode, hi/lo-split outputs (rz_common.h split4): EPI_GELU -> the next GEMM's A operand [M][3N] = [hi | lo | hi]
                     // (exact-erf GELU as in every fp32 epilogue); EPI_HEADS -> two planes `plane_off` elements apart
                     f16x4 hi, lo;

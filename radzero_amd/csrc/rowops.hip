@@ -81,9 +81,34 @@ __global__ __launch_bounds__(256) void layernorm_split3_kernel(const float* __re
     }
 }
 
-hipError_t launch_layernorm_split3(const float* in, const float* gamma, const float* beta, float eps, void* out3, int64_t rows, int D, unsigned* ovf_flag, hipStream_t s) {
+// the same in the MX form (rz_common.h): row = [hi f16 x D | per 64 columns: lo8 x 64, hi8 x 64] = 4 D bytes
+template <int NV>
+__global__ __launch_bounds__(256) void layernorm_split_mx_kernel(const float* __restrict__ in, const float* __restrict__ gamma,
+                                                                 const float* __restrict__ beta, float eps, char* __restrict__ out, int64_t rows, unsigned* ovf_flag) {
+    constexpr int D = 256 * NV;
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    RowRegs<NV> r = load_row<NV>(in + row * D, lane);
+    row_layernorm<NV>(r, gamma, beta, eps, lane);
+    char* o = out + row * 4 * D;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        f16x4 hi;
+        uint32_t lo8, hi8;
+        split4_mx(r.v[i], hi, lo8, hi8, MX_A_HI_SCALE, MX_A_LO_SCALE, ovf_flag);
+        const int k = (lane + 64 * i) * 4;
+        *reinterpret_cast<f16x4*>(o + 2 * k) = hi;
+        char* pr = o + mx_pair_off(D, k);
+        *reinterpret_cast<uint32_t*>(pr) = lo8;
+        *reinterpret_cast<uint32_t*>(pr + 64) = hi8;
+    }
+}
+
+hipError_t launch_layernorm_split3(const float* in, const float* gamma, const float* beta, float eps, void* out3, int64_t rows, int D, unsigned* ovf_flag, hipStream_t s, int mx) {
     if (D != 768 || rows <= 0) return hipErrorInvalidValue;
-    hipLaunchKernelGGL((layernorm_split3_kernel<3>), dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, in, gamma, beta, eps, (f16_t*)out3, rows, ovf_flag);
+    if (mx) hipLaunchKernelGGL((layernorm_split_mx_kernel<3>), dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, in, gamma, beta, eps, (char*)out3, rows, ovf_flag);
+    else hipLaunchKernelGGL((layernorm_split3_kernel<3>), dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, in, gamma, beta, eps, (f16_t*)out3, rows, ovf_flag);
     return hipGetLastError();
 }
 

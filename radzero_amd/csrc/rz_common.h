@@ -95,6 +95,49 @@ __device__ __forceinline__ void split4(const f32x4& v, f16x4& hi, f16x4& lo, uns
     lo = pack4<f16_t>(v[0] - (float)hi[0], v[1] - (float)hi[1], v[2] - (float)hi[2], v[3] - (float)hi[3]);
 }
 
+// ---- fp32 mode, MX form (round 4): a product a b = a_hi b_hi + (a_lo b_hi + a_hi b_lo); the two correction terms sit 2^-11 below the main
+// one and need ~4 significant bits, so they run as ONE block-scaled fp8 MFMA (v_mfma_scale_f32_16x16x128_f8f6f4, e4m3 operands, 2 x the
+// f16 rate) over K' = 128 = [a_lo(64) | a_hi8(64)] . [b_hi8(64) | b_lo(64)] beside the two f16 MFMAs of a_hi b_hi: 4 MFMA-units per 64 K
+// instead of 6.  An operand row is [hi plane: K f16][K / 64 groups of 128 bytes: activations lo8 x 64 | hi8 x 64, weights hi8 x 64 | lo8 x 64]
+// = 4 K bytes (6 K in the three-plane f16 form).  Scales are FIXED powers of two per plane kind (E8M0 bytes below) — no per-block scale
+// plumbing: e4m3 spans 2^-9 .. 448 times its scale, an element far below its plane's scale loses RELATIVE precision only where its
+// ABSOLUTE contribution is negligible (the correction terms are already 2^-11 of the product), and an element above it is clamped and
+// flagged (the forward is then repeated on the exact kernels, as for the f16 planes).  Operand / scale layout of the instruction:
+// tools/mb_mx_probe.hip (profiles/r04/mx_mfma_layout_probe.txt); conversion numerics (RNE, overflow -> NaN, hence the clamp):
+// tools/mb_fp8_cvt.hip.
+struct split_mx {};       // output "type": the next GEMM's A operand in the form above
+constexpr float MX_A_HI_SCALE = 4.0f, MX_A_LO_SCALE = 4.0f / 2048.0f;          // activations: hi8 covers |x| <= 1792, lo8 = (x - f16(x)) / 2^-9
+constexpr float MX_W_HI_SCALE = 1.0f / 16.0f, MX_W_LO_SCALE = 1.0f / 32768.0f; // weights: hi8 covers |w| <= 28
+constexpr int MX_E8_A_HI = 129, MX_E8_A_LO = 118, MX_E8_W_HI = 123, MX_E8_W_LO = 112;      // E8M0 = 127 + log2(scale)
+__device__ __forceinline__ uint32_t cvt4_e4m3(float a, float b, float c, float d) {
+    int w = 0;
+    w = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, w, false);
+    w = __builtin_amdgcn_cvt_pk_fp8_f32(c, d, w, true);
+    return (uint32_t)w;
+}
+__device__ __forceinline__ float clamp448(float x) { return fminf(fmaxf(x, -448.f), 448.f); }
+// hi = f16(v); lo8 = e4m3((v - hi) / lo_scale); hi8 = e4m3(clamp(v / hi_scale)); flags |v| beyond the hi8 range (or the f16 range, or NaN)
+__device__ __forceinline__ void split4_mx(const f32x4& v, f16x4& hi, uint32_t& lo8, uint32_t& hi8, float hi_scale, float lo_scale, unsigned* flag) {
+    const float lim = 448.f * hi_scale;
+    const unsigned a = max(max(__float_as_uint(v[0]) & 0x7fffffffu, __float_as_uint(v[1]) & 0x7fffffffu),
+                           max(__float_as_uint(v[2]) & 0x7fffffffu, __float_as_uint(v[3]) & 0x7fffffffu));
+    if (a > __float_as_uint(fminf(lim, 65504.f)) && flag) atomicOr(flag, 1u);
+    hi = pack4<f16_t>(v[0], v[1], v[2], v[3]);
+    const float il = 1.0f / lo_scale, ih = 1.0f / hi_scale;
+    lo8 = cvt4_e4m3(clamp448((v[0] - (float)hi[0]) * il), clamp448((v[1] - (float)hi[1]) * il), clamp448((v[2] - (float)hi[2]) * il), clamp448((v[3] - (float)hi[3]) * il));
+    hi8 = cvt4_e4m3(clamp448(v[0] * ih), clamp448(v[1] * ih), clamp448(v[2] * ih), clamp448(v[3] * ih));
+}
+// byte offsets inside an MX operand row of K elements (row = 4 K bytes): element k
+__device__ __forceinline__ int64_t mx_pair_off(int K, int k) { return (int64_t)2 * K + (k >> 6) * 128 + (k & 63); }      // first byte plane of its 64-group; second = + 64
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x8 __attribute__((ext_vector_type(8)));
+// acc += sum over the 128-byte K' tile: a = chunks (lg, 4 + lg) of the A row, b likewise of the W row; sa / sb: the lane's E8M0 scale bytes
+__device__ __forceinline__ f32x4 mma_mx(const f16x8& a0, const f16x8& a1, const f16x8& b0, const f16x8& b1, f32x4 c, int sa, int sb) {
+    const i32x4 x0 = __builtin_bit_cast(i32x4, a0), x1 = __builtin_bit_cast(i32x4, a1), y0 = __builtin_bit_cast(i32x4, b0), y1 = __builtin_bit_cast(i32x4, b1);
+    const i32x8 a = __builtin_shufflevector(x0, x1, 0, 1, 2, 3, 4, 5, 6, 7), b = __builtin_shufflevector(y0, y1, 0, 1, 2, 3, 4, 5, 6, 7);
+    return __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a, b, c, 0, 0, 0, sa, 0, sb);
+}
+
 // 8 floats -> one operand fragment (pairwise packed converts: v_cvt_pk_bf16_f32 / v_cvt_f16 + pack)
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));

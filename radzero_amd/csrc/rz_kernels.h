@@ -57,7 +57,7 @@ bool gemm_qkv_fused_ok(int dtype, const GemmArgs& g);
 bool gemm_ln_fused_ok(int dtype, int M, int D, int F, int variant);   // may a Dinov2 block of M token rows use the fused-LayerNorm epilogues
 // fp32 mode on the f16 matrix pipe: operands split into f16 planes along K (gemm.hip)
 hipError_t launch_gemm_split_f32out(int epi, const GemmArgs& g, hipStream_t s, bool split_out = false);
-hipError_t launch_split3(const float* src, int64_t ld, void* dst, int64_t rows, int K, int w_layout, unsigned* ovf_flag, hipStream_t s);
+hipError_t launch_split3(const float* src, int64_t ld, void* dst, int64_t rows, int K, int w_layout, unsigned* ovf_flag, hipStream_t s);   // w_layout 0 / 1: f16 planes [hi|lo|hi] / [hi|hi|lo]; 2 / 3: MX form of an activation / weight matrix (K % 64 == 0)
 hipError_t launch_gemm_v8(int dtype, int epi, const GemmArgs& g, hipStream_t s);   // persistent 256x256 kernel (gemm8.hip)
 bool gemm_v10_ok(int dtype, int epi, const GemmArgs& g);
 bool gemm_v11_ok(int dtype, int epi, const GemmArgs& g);
@@ -67,6 +67,9 @@ bool gemm_v12_ok(int dtype, int epi, const GemmArgs& g);
 hipError_t launch_gemm_v12(int dtype, int epi, const GemmArgs& g, hipStream_t s);  // persistent, two 256x128 workgroups per CU (gemm12.hip)
 hipError_t launch_gemm_v7(int variant, int dtype, int epi, const GemmArgs& g, hipStream_t s);
 hipError_t launch_gemm_v7_f16_out(int epi, const GemmArgs& g, bool split_out, hipStream_t s);   // f16 operands, fp32 / hi-lo-split outputs
+// fp32 mode, MX form (rz_common.h "MX form"): f16 hi plane + block-scaled fp8 correction planes; out_kind 0 fp32 RMW / table, 1 hi/lo planes, 2 MX A operand
+bool gemm_v7_mx_ok(const GemmArgs& g);
+hipError_t launch_gemm_v7_mx(int epi, const GemmArgs& g, int out_kind, hipStream_t s);
 
 // Flash attention over per-head tensors: q,k [B][H][Npad][64], vT [B][H][64][Npad] -> ctx [B*Npad][H*64].
 // Scores are NOT rescaled inside (1/sqrt(dh) is folded into the packed q weights).
@@ -75,7 +78,8 @@ size_t flash_attn_split_workspace_bytes(int B, int H, int n_pad);
 hipError_t launch_flash_attn_f32_split(const float* q, const float* k, const float* vT, float* ctx, void* split_ws, int64_t qk_batch_stride,
                                        int B, int H, int n_valid, int n_pad, unsigned* ovf_flag, hipStream_t s);
 hipError_t launch_flash_attn_split_planes(const void* q_hi, const void* k_hi, const void* v_hi, void* ctx3, int64_t qk_batch_stride,
-                                          int64_t qk_lo_off, int64_t v_lo_off, int B, int H, int n_valid, int n_pad, unsigned* ovf_flag, hipStream_t s);
+                                          int64_t qk_lo_off, int64_t v_lo_off, int B, int H, int n_valid, int n_pad, unsigned* ovf_flag, hipStream_t s,
+                                          int mx_out = 0);      // mx_out: ctx in the MX form (4 bytes per element) instead of [hi | lo | hi] f16
 hipError_t launch_flash_attn(int dtype, const void* q, const void* k, const void* vT, void* ctx,
                              int64_t qk_batch_stride, int B, int H, int n_valid, int n_pad, int waves, hipStream_t s);
 
@@ -96,7 +100,7 @@ hipError_t launch_ln_prepare(int dtype, const float* in, const float* gamma, con
 
 // LayerNorm over rows of 768: fp32 in; writes T-typed normalized copy (out_t, may be null) and/or
 // fp32 (out_f32, may alias in).
-hipError_t launch_layernorm_split3(const float* in, const float* gamma, const float* beta, float eps, void* out3, int64_t rows, int D, unsigned* ovf_flag, hipStream_t s);
+hipError_t launch_layernorm_split3(const float* in, const float* gamma, const float* beta, float eps, void* out3, int64_t rows, int D, unsigned* ovf_flag, hipStream_t s, int mx = 0);   // mx: the MX form (rz_common.h), 4 D bytes per row
 hipError_t launch_layernorm(int dtype, const float* in, const float* gamma, const float* beta, float eps,
                             void* out_t, float* out_f32, int64_t rows, int D, hipStream_t s);
 

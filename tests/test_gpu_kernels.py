@@ -370,6 +370,33 @@ def test_fused_layernorm_model_path_matches_standalone(lib, dt, rows, images):
         m.close()
 
 
+@pytest.mark.parametrize("shape", [(512, 768, 768), (1024, 3072, 768), (768, 768, 3072), (512, 768, 640), (256, 256, 128)])
+def test_gemm_f32_split_forms_vs_fp64(lib, shape):
+    """The fp32 (1e-3) mode's GEMM forms, kernel level, against an fp64 reference of the SAME fp32 operands: form 0 = three f16 MFMAs per
+    product (22 mantissa bits), form 1 = "MX" (a_hi b_hi on the f16 pipe + the two correction terms as ONE block-scaled e4m3 MFMA: 4 bits in
+    terms that sit 2^-11 below the product).  Bars relative to sqrt(K) x |a| x |w| (the size of a dot product's rounding noise): form 0 within
+    4e-7 (fp32-accumulation noise), form 1 within 3e-5 — 30 x below what one f16 operand plane alone would give (1e-3).  Operands span four
+    binades and carry an outlier column (x 40) so that fixed plane scales are exercised away from 1."""
+    M, N, K = shape
+    g = torch.Generator(device="cpu").manual_seed(M + N + K)
+    a = torch.randn(M, K, generator=g) * torch.exp2(torch.randint(-2, 2, (M, 1), generator=g).float())
+    a[:, 5] *= 40.0
+    w = torch.randn(N, K, generator=g) / math.sqrt(K) * torch.exp2(torch.randint(-1, 2, (N, 1), generator=g).float())
+    bias = torch.randn(N, generator=g)
+    ref = a.double() @ w.double().t() + bias.double()
+    noise = math.sqrt(K) * float(a.abs().mean()) * float(w.abs().mean())
+    ad, wd, bd, ones = a.cuda(), w.cuda(), bias.cuda(), torch.ones(N, device="cuda")
+    errs = {}
+    for form in (0, 1):
+        out = torch.zeros(M, N, device="cuda")
+        ws_a = torch.empty(M * K * 6, dtype=torch.uint8, device="cuda")
+        ws_w = torch.empty(N * K * 6, dtype=torch.uint8, device="cuda")
+        check(lib, lib.rz_gemm_f32_split(form, P(ad), P(wd), P(bd), P(ones), P(out), P(ws_a), P(ws_w), M, N, K, stream()))
+        torch.cuda.synchronize()
+        errs[form] = float((out.double().cpu() - ref).abs().max()) / noise
+    assert errs[0] <= 4e-7 * 8 and errs[1] <= 3e-5, errs          # (the bars are in units of the dot product's own magnitude)
+
+
 @needs_experiments
 @pytest.mark.parametrize("raster", [0, 4, 8, 9])
 @pytest.mark.parametrize("shape", [(8192, 3072, 768), (5376, 2304, 768), (33792, 768, 3072), (2304, 384, 640)])

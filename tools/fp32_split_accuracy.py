@@ -14,8 +14,9 @@ lib = _lib.load()
 cfg = RadZeroConfig()
 sd = make_state_dict(cfg, 20260103)      # the checkpoint of tests/conftest.py (the goldens were produced from it)
 m = RadZeroModel.from_state_dict(sd, cfg, torch_dtype=torch.float32, device="cuda:0").eval()
-for attn, gemm in ((0, 0), (1, 0), (1, 1)):
-    lib.rz_set_option(b"attn_f32_split", attn); lib.rz_set_option(b"gemm_f32_split", gemm)
+m.set_model_option("pad_rows", 256)      # every padded token count a multiple of 256, so that the MX form (gemm_f32_mx = 2) applies to every fixture
+for attn, gemm, mx in ((0, 0, 0), (1, 0, 0), (1, 1, 0), (1, 1, 2)):
+    lib.rz_set_option(b"attn_f32_split", attn); lib.rz_set_option(b"gemm_f32_split", gemm); lib.rz_set_option(b"gemm_f32_mx", mx)
     worst = []
     for name in GOLDEN_CASES:
         g = load_golden(name)
@@ -25,7 +26,7 @@ for attn, gemm in ((0, 0), (1, 0), (1, 1)):
         es = float(np.abs(out["similarity_scores"].cpu().numpy() - g["similarity_scores"]).max())
         el = float(np.abs(out["logits"].cpu().numpy() - g["logits"]).max())
         worst.append((name, es, el))
-    print(f"attn_f32_split={attn} gemm_f32_split={gemm}: " + "  ".join(f"{n.split('_')[0]}:{es:.1e}/{el:.1e}" for n, es, el in worst))
+    print(f"attn_f32_split={attn} gemm_f32_split={gemm} gemm_f32_mx={mx}: " + "  ".join(f"{n.split('_')[0]}:{es:.1e}/{el:.1e}" for n, es, el in worst))
     print(f"    max over the 8 fixtures: scores {max(w[1] for w in worst):.2e}  logits {max(w[2] for w in worst):.2e}")
-lib.rz_set_option(b"attn_f32_split", 1); lib.rz_set_option(b"gemm_f32_split", 1)
+lib.rz_set_option(b"attn_f32_split", 1); lib.rz_set_option(b"gemm_f32_split", 1); lib.rz_set_option(b"gemm_f32_mx", 1)
 m.close()

@@ -72,6 +72,11 @@ int main(int argc, char** argv) {
         OK(rz_vision_forward(h, px.data(), 2, 3, 224, 224, nullptr, nullptr));
         FAILS(rz_vision_forward(h, px.data(), 2, 4, 224, 224, nullptr, nullptr));      // wrong channel count
         FAILS(rz_vision_forward(h, px.data(), 9, 3, 224, 224, nullptr, nullptr));      // beyond the reserved batch
+        OK(rz_set_model_option(h, "gemm_f32_mx", 2));                          // fp32 mode: the MX form wherever the rows are a multiple of 256 (2 x 384)
+        OK(rz_vision_forward(h, px.data(), 2, 3, 224, 224, nullptr, nullptr));
+        OK(rz_set_model_option(h, "gemm_f32_mx", 0));
+        OK(rz_vision_forward(h, px.data(), 2, 3, 224, 224, nullptr, nullptr));
+        OK(rz_set_model_option(h, "gemm_f32_mx", INT32_MIN));
         OK(rz_vision_forward(h, px.data(), B, 3, S, S, nullptr, nullptr));
         OK(rz_text_forward(h, ids.data(), mask.data(), T, L, rel.data(), feats.data(), nullptr));
         std::vector<float> scores((size_t)B * T * N), t2i((size_t)T * B), logits((size_t)B * T);

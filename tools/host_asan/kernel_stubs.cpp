@@ -103,10 +103,30 @@ hipError_t launch_gemm_split_f32out(int epi, const GemmArgs& g, hipStream_t s, b
     if (g.ovf_flag) wr(g.ovf_flag, 0, "ovf");
     return hipSuccess;
 }
-hipError_t launch_split3(const float* src, int64_t ld, void* dst, int64_t rows, int K, int, unsigned* ovf, hipStream_t) {
+hipError_t launch_split3(const float* src, int64_t ld, void* dst, int64_t rows, int K, int layout, unsigned* ovf, hipStream_t) {
     rd(src, ((size_t)(rows - 1) * ld + K) * 4, "split3 src");
-    wr(dst, (size_t)rows * 3 * K * 2, "split3 dst");
+    wr(dst, layout >= 2 ? (size_t)rows * 4 * K : (size_t)rows * 3 * K * 2, "split3 dst");          // 2 / 3: the MX form, 4 K bytes per row
     if (ovf) rd(ovf, 4, "split3 overflow word");
+    return hipSuccess;
+}
+// fp32 mode, MX form (gemm7.hip launch_gemm_v7_mx): rows of 4 K bytes, g.K = g.lda = g.ldw = 2 K f16-element units
+bool gemm_v7_mx_ok(const GemmArgs& g) { return g.M % 256 == 0 && g.N % 256 == 0 && g.K % 128 == 0 && g.K >= 256; }
+hipError_t launch_gemm_v7_mx(int epi, const GemmArgs& g, int out_kind, hipStream_t) {
+    if (!gemm_v7_mx_ok(g)) return hipErrorInvalidValue;
+    rd(g.A, ((size_t)(g.M - 1) * g.lda + g.K) * 2, "MX gemm A rows");
+    rd(g.W, ((size_t)(g.N - 1) * g.ldw + g.K) * 2, "MX gemm W rows");
+    if (g.bias) rd(g.bias, (size_t)g.N * 4, "MX gemm bias");
+    const size_t images = g.rows_per_image > 0 ? (size_t)g.M / g.rows_per_image : 1;
+    if (out_kind == 0) {
+        if (epi == EPI_PATCH) { rd(g.scale, (size_t)g.rows_per_image * g.N * 4, "patch table"); wr(g.out, ((size_t)(g.M - 1) * g.ldo + g.N) * 4, "MX gemm fp32 out"); }
+        else { rd(g.scale, (size_t)g.N * 4, "LayerScale"); wr(g.resid, ((size_t)(g.M - 1) * g.ldr + g.N) * 4, "MX gemm residual stream"); }
+    } else if (out_kind == 1) {
+        const size_t plane = images * g.heads_total * g.rows_per_image * 64;
+        wr(g.out, plane * 2, "MX gemm hi plane");
+        wr((char*)g.out + (size_t)g.plane_off * 2, plane * 2, "MX gemm lo plane");
+    } else {
+        wr(g.out, (size_t)g.M * 4 * g.ldo, "MX gemm MX-form out");
+    }
     return hipSuccess;
 }
 static bool big_tiles_pay(const GemmArgs& g) {          // gemm.hip
@@ -138,14 +158,14 @@ hipError_t launch_flash_attn_f32_split(const float* q, const float* k, const flo
     wr(ctx, (size_t)B * np * H * 64 * 4, "split attention ctx");
     return hipSuccess;
 }
-hipError_t launch_flash_attn_split_planes(const void* q_hi, const void* k_hi, const void* v_hi, void* ctx3, int64_t bs, int64_t qk_lo, int64_t v_lo, int B, int H, int nv, int np, unsigned*, hipStream_t) {
+hipError_t launch_flash_attn_split_planes(const void* q_hi, const void* k_hi, const void* v_hi, void* ctx3, int64_t bs, int64_t qk_lo, int64_t v_lo, int B, int H, int nv, int np, unsigned*, hipStream_t, int mx_out) {
     const size_t head = (size_t)np * 64;
     for (int plane = 0; plane < 2; ++plane) {
         rd((const char*)q_hi + (size_t)plane * qk_lo * 2, ((size_t)(B - 1) * bs + H * head) * 2, "split attention q plane");
         rd((const char*)k_hi + (size_t)plane * qk_lo * 2, ((size_t)(B - 1) * bs + H * head) * 2, "split attention k plane");
         rd((const char*)v_hi + (size_t)plane * v_lo * 2, (size_t)B * H * head * 2, "split attention v^T plane");
     }
-    wr(ctx3, (size_t)B * np * 3 * H * 64 * 2, "split attention [hi|lo|hi] ctx");
+    wr(ctx3, (size_t)B * np * (mx_out ? 4 : 6) * H * 64, "split attention ctx planes");
     return hipSuccess;
 }
 hipError_t launch_text_attn(int dtype, const void* qkv, const float* rel_bias, const int64_t* mask, void* ctx, int T, int L, int H, hipStream_t) {
@@ -168,9 +188,9 @@ hipError_t launch_ln_prepare(int dtype, const float* in, const float* g, const f
     wr(copy_t, (size_t)rows * D * esz(dtype), "ln_prepare copy"); wr(mu, (size_t)rows * 4, "ln_prepare mu"); wr(stat, (size_t)rows * 8, "ln_prepare stat");
     return hipSuccess;
 }
-hipError_t launch_layernorm_split3(const float* in, const float* g, const float* b, float, void* out3, int64_t rows, int D, unsigned*, hipStream_t) {
+hipError_t launch_layernorm_split3(const float* in, const float* g, const float* b, float, void* out3, int64_t rows, int D, unsigned*, hipStream_t, int mx) {
     rd(in, (size_t)rows * D * 4, "layernorm_split3 in"); rd(g, (size_t)D * 4, "gamma"); rd(b, (size_t)D * 4, "beta");
-    wr(out3, (size_t)rows * 3 * D * 2, "layernorm_split3 planes");
+    wr(out3, (size_t)rows * (mx ? 4 : 6) * D, "layernorm_split3 planes");
     return hipSuccess;
 }
 hipError_t launch_layernorm(int dtype, const float* in, const float* g, const float* b, float, void* out_t, float* out_f32, int64_t rows, int D, hipStream_t) {
