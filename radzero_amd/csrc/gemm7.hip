@@ -68,7 +68,9 @@ template <typename T, bool SWAP, bool S1, bool S2, int MODE, bool MX = false>
 __device__ __forceinline__ void v7_tile(f32x4 (&acc)[2][4][4], char* cur, char* nxt, unsigned a_rd, unsigned b_rd,
                                         const char* const (&a1)[2], const char* const (&w1)[2], const char* const (&a2)[2],
                                         const char* const (&w2)[2], int64_t a_sub, int64_t w_sub, unsigned a_dst, unsigned w_dst,
-                                        unsigned long long (&st)[24], int sa = 0, int sw = 0) {
+                                        unsigned long long (&st)[24], int sa = 0, int sw = 0, bool rt1 = true, bool rt2 = true) {
+    // rt1 / rt2 (wave-uniform, run time): AND-ed with S1 / S2 — lets ONE instantiation serve the steady state and the two tail tiles (the MX
+    // kernels: a second and third copy of this body made hipcc rename the accumulators between them and spill ~140 VGPRs at the seams)
     typedef typename Traits<T>::frag frag_t;
     frag_t fa[2][4], fb0[2][2], fb1[2][2];          // [k-half][fragment]
 #pragma unroll
@@ -96,10 +98,10 @@ __device__ __forceinline__ void v7_tile(f32x4 (&acc)[2][4][4], char* cur, char* 
         }
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
-            if (u == 0 && S1) v7_glds(w1[e] + w_sub, nxt + w_dst + 32 * 128 + e * 1024);     // U2(T+1)
-            if (u == 1 && S1) v7_glds(a1[e] + a_sub, nxt + a_dst + 64 * 128 + e * 1024);     // U3(T+1)
-            if (u == 2 && S2) v7_glds(a2[e], cur + a_dst + e * 1024);                        // U0(T+2)
-            if (u == 3 && S2) v7_glds(w2[e], cur + w_dst + e * 1024);                        // U1(T+2)
+            if (u == 0 && S1 && rt1) v7_glds(w1[e] + w_sub, nxt + w_dst + 32 * 128 + e * 1024);     // U2(T+1)
+            if (u == 1 && S1 && rt1) v7_glds(a1[e] + a_sub, nxt + a_dst + 64 * 128 + e * 1024);     // U3(T+1)
+            if (u == 2 && S2 && rt2) v7_glds(a2[e], cur + a_dst + e * 1024);                        // U0(T+2)
+            if (u == 3 && S2 && rt2) v7_glds(w2[e], cur + w_dst + e * 1024);                        // U1(T+2)
         }
         RZ_STAMP(u * 6 + 1)
         __builtin_amdgcn_sched_barrier(0);
@@ -135,10 +137,16 @@ __device__ __forceinline__ void v7_tile(f32x4 (&acc)[2][4][4], char* cur, char* 
         RZ_STAMP(u * 6 + 3)
         // everything issued three or more phases ago must have landed: count the units issued in phases q-2, q-1, q
         constexpr int kYoung[4] = {(S1 ? 3 : 0), (S1 ? 3 : 0), (S1 ? 2 : 0) + (S2 ? 1 : 0), (S1 ? 1 : 0) + (S2 ? 2 : 0)};
-        if (u == 0) v7_wait_vm<2 * kYoung[0]>();
-        if (u == 1) v7_wait_vm<2 * kYoung[1]>();
-        if (u == 2) v7_wait_vm<2 * kYoung[2]>();
-        if (u == 3) v7_wait_vm<2 * kYoung[3]>();
+        if (S1 && S2 && !(rt1 && rt2)) {
+            // run-time tail of a (true, true) instantiation: the counts of the (true, false) / (false, false) cases
+            if (rt1) { if (u < 2) v7_wait_vm<6>(); else if (u == 2) v7_wait_vm<4>(); else v7_wait_vm<2>(); }
+            else v7_wait_vm<0>();
+        } else {
+            if (u == 0) v7_wait_vm<2 * kYoung[0]>();
+            if (u == 1) v7_wait_vm<2 * kYoung[1]>();
+            if (u == 2) v7_wait_vm<2 * kYoung[2]>();
+            if (u == 3) v7_wait_vm<2 * kYoung[3]>();
+        }
         RZ_STAMP(u * 6 + 4)
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();
@@ -234,36 +242,27 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel_v7(GemmArgs g) {
         v7_tile<T, SWAP, true, true, MODE>(acc, cur, nxt, a_rd, b_rd, a1, w1, a2, w2, a_sub, w_sub, a_dst, w_dst, st);
     }
     if constexpr (MXK) {
-        for (; kt + 2 < nk; ++kt) {
+        // every MX tile, the last two included, through ONE copy of the body: the tail's "no tile T+1 / T+2" is a run-time flag
+        for (; kt < nk; ++kt) {
             char* cur = lds + (kt & 1) * V7_STAGE;
             char* nxt = lds + ((kt + 1) & 1) * V7_STAGE;
-            const int64_t k1 = (int64_t)(kt + 1) * 128, k2 = k1 + 128;
+            const bool s1 = kt + 1 < nk, s2 = kt + 2 < nk;
+            const int64_t k1 = (int64_t)(s1 ? kt + 1 : kt) * 128, k2 = (int64_t)(s2 ? kt + 2 : kt) * 128;
             const char* a1[2] = {a_src[0] + k1, a_src[1] + k1};
             const char* w1[2] = {w_src[0] + k1, w_src[1] + k1};
             const char* a2[2] = {a_src[0] + k2, a_src[1] + k2};
             const char* w2[2] = {w_src[0] + k2, w_src[1] + k2};
-            v7_tile<T, SWAP, true, true, MODE, true>(acc, cur, nxt, a_rd, b_rd, a1, w1, a2, w2, a_sub, w_sub, a_dst, w_dst, st, sa, sw);
+            v7_tile<T, SWAP, true, true, MODE == 2 ? 0 : MODE, true>(acc, cur, nxt, a_rd, b_rd, a1, w1, a2, w2, a_sub, w_sub, a_dst, w_dst, st, sa, sw, s1, s2);
         }
-    }
-    if constexpr (MODE == 2) {          // diagnostic build: stamps of the last steady-state K tile of workgroup 0 -> g.resid (u64[8][24] + 2)
-        if (bid == 0 && lane == 0 && g.resid) {
-#pragma unroll
-            for (int i = 0; i < 24; ++i) reinterpret_cast<unsigned long long*>(g.resid)[wave * 24 + i] = st[i];
-            if (wave == 0) {            // the steady-state loop of this workgroup: shader cycles and 100 MHz real-time ticks
-                reinterpret_cast<unsigned long long*>(g.resid)[192] = __builtin_amdgcn_s_memtime() - clk0;
-                reinterpret_cast<unsigned long long*>(g.resid)[193] = __builtin_amdgcn_s_memrealtime() - rt0;
-            }
-        }
-    }
-    {
+    } else {
         char* cur = lds + (kt & 1) * V7_STAGE;
         char* nxt = lds + ((kt + 1) & 1) * V7_STAGE;
         const int64_t k1 = (int64_t)(kt + 1) * 128;
         const char* a1[2] = {a_src[0] + k1, a_src[1] + k1};
         const char* w1[2] = {w_src[0] + k1, w_src[1] + k1};
         unsigned long long st2[24];
-        v7_tile<T, SWAP, true, false, MODE == 2 ? 0 : MODE, MXK>(acc, cur, nxt, a_rd, b_rd, a1, w1, a1, w1, a_sub, w_sub, a_dst, w_dst, st2, sa, sw);
-        v7_tile<T, SWAP, false, false, MODE == 2 ? 0 : MODE, MXK>(acc, nxt, cur, a_rd, b_rd, a1, w1, a1, w1, a_sub, w_sub, a_dst, w_dst, st2, sa, sw);
+        v7_tile<T, SWAP, true, false, MODE == 2 ? 0 : MODE>(acc, cur, nxt, a_rd, b_rd, a1, w1, a1, w1, a_sub, w_sub, a_dst, w_dst, st2);
+        v7_tile<T, SWAP, false, false, MODE == 2 ? 0 : MODE>(acc, nxt, cur, a_rd, b_rd, a1, w1, a1, w1, a_sub, w_sub, a_dst, w_dst, st2);
     }
     if (wr == 0) __builtin_amdgcn_s_barrier();
     }
@@ -272,6 +271,10 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel_v7(GemmArgs g) {
     if constexpr (sizeof(OT) == 2 && (EPI == EPI_STORE || EPI == EPI_GELU || EPI == EPI_HEADS || EPI == EPI_VT)) {
         __syncthreads();            // every wave is past its last operand read: LDS is free
         gemm_epilogue_tile16<OT, EPI>(g, acc, lds, m0, n0, wr, wc, lane, tid);
+    } else if constexpr ((std::is_same<OT, split_f16>::value && (EPI == EPI_GELU || EPI == EPI_HEADS || EPI == EPI_VT)) ||
+                         (std::is_same<OT, split_mx>::value && EPI == EPI_GELU)) {
+        __syncthreads();
+        gemm_epilogue_tile_split<EPI, std::is_same<OT, split_mx>::value ? 1 : 0>(g, acc, lds, m0, n0, wr, wc, lane, tid);
     } else {
         gemm_epilogue<OT, EPI>(g, acc[0], mw, nw, l15, lg);
         gemm_epilogue<OT, EPI>(g, acc[1], mw + 64, nw, l15, lg);

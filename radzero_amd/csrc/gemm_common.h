@@ -454,4 +454,106 @@ __device__ __forceinline__ void gemm_epilogue_tile16(const GemmArgs& g, const f3
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------
+// Whole-tile epilogue of the fp32 mode's SPLIT outputs for the 8-wave 256x256 kernels (round 4).  The direct form (gemm_epilogue above)
+// writes 8- and 4-byte pieces straight from the accumulator layout — 32-64 contiguous bytes per row per instruction — and cost 40-60 us per
+// tile against a 35-50 us K loop (profiles/r04: the fp32 mode's q|k, V^T and fc1 GEMMs were epilogue-bound).  Here the final fp32 values
+// (bias, exact-erf GELU) are formed once in registers and leave plane by plane through the 256-row x 512-byte LDS image of
+// gemm_epilogue_tile16 — 2 rows x 512 contiguous bytes per wave instruction:
+//   FORM 0 (three f16 planes): hi = f16(v), lo = f16(v - hi);  EPI_HEADS / EPI_VT -> planes `plane_off` elements apart;
+//                              EPI_GELU -> the next GEMM's A operand [M][3 ldo] = [hi | lo | hi]
+//   FORM 1 (MX, rz_common.h):  EPI_GELU -> [hi f16 x ldo | per 64 columns: lo8 x 64, hi8 x 64]: the tile's 256 columns are 512 bytes of
+//                              the hi plane and 512 bytes (4 groups) of the pair plane
+// ---------------------------------------------------------------------------------------------------
+template <int EPI, int FORM>
+__device__ __forceinline__ void gemm_epilogue_tile_split(const GemmArgs& g, f32x4 (&acc)[2][4][4], char* lds, int m0, int n0,
+                                                         int wr, int wc, int lane, int tid) {
+    static_assert(EPI == EPI_GELU || ((EPI == EPI_HEADS || EPI == EPI_VT) && FORM == 0), "split outputs: q|k, V^T (f16 planes), fc1 (either form)");
+    constexpr bool SWAP = (EPI != EPI_VT);
+    const int l15 = lane & 15, lg = lane >> 4;
+    // final values, in place
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            f32x4 b4 = (f32x4){0.f, 0.f, 0.f, 0.f};
+            float bv = 0.f;
+            if constexpr (SWAP) { if (g.bias) b4 = *reinterpret_cast<const f32x4*>(g.bias + n0 + wc * 64 + j * 16 + 4 * lg); }
+            else { if (g.bias) bv = g.bias[n0 + wc * 64 + j * 16 + l15]; }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                f32x4 v = acc[a][i][j];
+                if constexpr (SWAP) v += b4; else v += bv;
+                if constexpr (EPI == EPI_GELU) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
+                }
+                acc[a][i][j] = v;
+            }
+        }
+    constexpr int NPASS = (FORM == 0 ? 2 : 2);
+#pragma unroll
+    for (int pass = 0; pass < NPASS; ++pass) {
+        if (pass) __syncthreads();              // the previous plane has been read out of the image
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const f32x4 v = acc[a][i][j];
+                    int row, c16;
+                    if constexpr (SWAP) { row = wr * 128 + a * 64 + i * 16 + l15; c16 = wc * 8 + j * 2 + (lg >> 1); }
+                    else { row = wc * 64 + j * 16 + l15; c16 = wr * 16 + a * 8 + i * 2 + (lg >> 1); }
+                    const f16x4 hi = pack4<f16_t>(v[0], v[1], v[2], v[3]);
+                    if (FORM == 1 && pass == 1) {
+                        // pair plane: 4 bytes lo8 at byte 128 wc + 16 j + 4 lg of the row's 512, 4 bytes hi8 64 bytes further
+                        uint32_t lo8, hi8;
+                        f16x4 h2;
+                        split4_mx(v, h2, lo8, hi8, MX_A_HI_SCALE, MX_A_LO_SCALE, g.ovf_flag);
+                        const int cl = wc * 8 + j, ch = cl + 4;
+                        *reinterpret_cast<uint32_t*>(lds + row * 512 + ((cl ^ (row & 15)) << 4) + 4 * lg) = lo8;
+                        *reinterpret_cast<uint32_t*>(lds + row * 512 + ((ch ^ (row & 15)) << 4) + 4 * lg) = hi8;
+                    } else {
+                        f16x4 o = hi;
+                        if (pass == 0) { if (FORM == 0) flag_f16_range(v, g.ovf_flag); }
+                        else o = pack4<f16_t>(v[0] - (float)hi[0], v[1] - (float)hi[1], v[2] - (float)hi[2], v[3] - (float)hi[3]);
+                        *reinterpret_cast<f16x4*>(lds + row * 512 + ((c16 ^ (row & 15)) << 4) + (lg & 1) * 8) = o;
+                    }
+                }
+        __syncthreads();
+#pragma unroll 4
+        for (int it = 0; it < 16; ++it) {
+            const int q = it * 512 + tid;
+            const int row = q >> 5, c16 = q & 31;
+            const f16x8 v = *reinterpret_cast<const f16x8*>(lds + row * 512 + ((c16 ^ (row & 15)) << 4));
+            if constexpr (EPI == EPI_GELU) {
+                const int m = m0 + row;
+                if constexpr (FORM == 0) {
+                    f16_t* o = reinterpret_cast<f16_t*>(g.out) + (int64_t)m * 3 * g.ldo + n0 + c16 * 8;
+                    if (pass == 0) { *reinterpret_cast<f16x8*>(o) = v; *reinterpret_cast<f16x8*>(o + 2 * g.ldo) = v; }
+                    else *reinterpret_cast<f16x8*>(o + g.ldo) = v;
+                } else {
+                    char* rowp = reinterpret_cast<char*>(g.out) + (int64_t)m * 4 * g.ldo;
+                    if (pass == 0) *reinterpret_cast<f16x8*>(rowp + 2 * (n0 + c16 * 8)) = v;
+                    else *reinterpret_cast<f16x8*>(rowp + 2 * g.ldo + (n0 >> 6) * 128 + c16 * 16) = v;
+                }
+            } else {
+                f16_t* o;
+                if constexpr (EPI == EPI_VT) {
+                    const int n = n0 + row, m = m0 + c16 * 8;
+                    const int b = m / g.rows_per_image, tok = m - b * g.rows_per_image;
+                    o = reinterpret_cast<f16_t*>(g.out) + (((int64_t)b * g.heads_total + (n >> 6)) * 64 + (n & 63)) * g.rows_per_image + tok;
+                } else {
+                    const int m = m0 + row, n = n0 + c16 * 8;
+                    const int b = m / g.rows_per_image, tok = m - b * g.rows_per_image;
+                    o = reinterpret_cast<f16_t*>(g.out) + (((int64_t)b * g.heads_total + (n >> 6)) * g.rows_per_image + tok) * 64 + (n & 63);
+                }
+                *reinterpret_cast<f16x8*>(pass == 0 ? o : o + g.plane_off) = v;
+            }
+        }
+    }
+}
+
 }  // namespace rz
