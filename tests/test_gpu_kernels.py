@@ -374,9 +374,10 @@ def test_fused_layernorm_model_path_matches_standalone(lib, dt, rows, images):
 def test_gemm_f32_split_forms_vs_fp64(lib, shape):
     """The fp32 (1e-3) mode's GEMM forms, kernel level, against an fp64 reference of the SAME fp32 operands: form 0 = three f16 MFMAs per
     product (22 mantissa bits), form 1 = "MX" (a_hi b_hi on the f16 pipe + the two correction terms as ONE block-scaled e4m3 MFMA: 4 bits in
-    terms that sit 2^-11 below the product).  Bars relative to sqrt(K) x |a| x |w| (the size of a dot product's rounding noise): form 0 within
-    4e-7 (fp32-accumulation noise), form 1 within 3e-5 — 30 x below what one f16 operand plane alone would give (1e-3).  Operands span four
-    binades and carry an outlier column (x 40) so that fixed plane scales are exercised away from 1."""
+    terms that sit 2^-11 below the product).  Bars on the worst element's |error| / sqrt(sum_k a^2 w^2) (the rms size of its dot product):
+    form 0 <= 2.5e-5 (measured 0.5-1.2e-5: torch's own fp32 matmul gives 0.5-1.1e-5 on the same operands), form 1 <= 1.5e-4 (measured 5-6e-5;
+    a single f16 plane per operand would give ~1e-3).  Operands span four binades and carry an outlier column (x 40) so that the fixed
+    plane scales are exercised away from 1."""
     M, N, K = shape
     g = torch.Generator(device="cpu").manual_seed(M + N + K)
     a = torch.randn(M, K, generator=g) * torch.exp2(torch.randint(-2, 2, (M, 1), generator=g).float())
@@ -384,7 +385,7 @@ def test_gemm_f32_split_forms_vs_fp64(lib, shape):
     w = torch.randn(N, K, generator=g) / math.sqrt(K) * torch.exp2(torch.randint(-1, 2, (N, 1), generator=g).float())
     bias = torch.randn(N, generator=g)
     ref = a.double() @ w.double().t() + bias.double()
-    noise = math.sqrt(K) * float(a.abs().mean()) * float(w.abs().mean())
+    rms = torch.sqrt((a.double() ** 2) @ (w.double() ** 2).t())
     ad, wd, bd, ones = a.cuda(), w.cuda(), bias.cuda(), torch.ones(N, device="cuda")
     errs = {}
     for form in (0, 1):
@@ -393,8 +394,8 @@ def test_gemm_f32_split_forms_vs_fp64(lib, shape):
         ws_w = torch.empty(N * K * 6, dtype=torch.uint8, device="cuda")
         check(lib, lib.rz_gemm_f32_split(form, P(ad), P(wd), P(bd), P(ones), P(out), P(ws_a), P(ws_w), M, N, K, stream()))
         torch.cuda.synchronize()
-        errs[form] = float((out.double().cpu() - ref).abs().max()) / noise
-    assert errs[0] <= 4e-7 * 8 and errs[1] <= 3e-5, errs          # (the bars are in units of the dot product's own magnitude)
+        errs[form] = float(((out.double().cpu() - ref).abs() / rms).max())
+    assert errs[0] <= 2.5e-5 and errs[1] <= 1.5e-4, errs
 
 
 @needs_experiments
