@@ -185,6 +185,10 @@ int rz_flash_attention(int dtype, const void* q_dev, const void* k_dev, const vo
 size_t rz_flash_attention_split_workspace(int batch, int heads, int n_pad);
 int rz_flash_attention_f32_split(const float* q_dev, const float* k_dev, const float* v_t_dev, float* ctx_dev, void* workspace_dev,
                                  int batch, int heads, int n_valid, int n_pad, void* stream);
+/* the same with the two correction terms of every product as ONE block-scaled e4m3 MFMA (the "MX" form the fp32 mode runs for large
+ * batches, option "gemm_f32_mx"): hi f16 planes + e4m3 pair planes are built in the same workspace */
+int rz_flash_attention_f32_mx(const float* q_dev, const float* k_dev, const float* v_t_dev, float* ctx_dev, void* workspace_dev,
+                              int batch, int heads, int n_valid, int n_pad, void* stream);
 
 /* ---- the text side and the patch embedding, kernel by kernel (the model reaches them through rz_text_forward /
  *      rz_vision_forward) ---- */
@@ -232,7 +236,12 @@ int rz_gemm_f32_split(int form, const float* a_dev, const float* w_dev, const fl
  *   "gemm_f32_mx"      fp32 mode, hi/lo-split GEMMs: 1 (default) = for large batches (>= 64 row tiles of 256) the two correction terms
  *                      a_lo b_hi + a_hi b_lo run as ONE block-scaled fp8 MFMA (v_mfma_scale_f32_16x16x128_f8f6f4, e4m3 planes with fixed
  *                      power-of-two scales) beside the f16 a_hi b_hi MFMAs: 4 MFMA-units per 64 K instead of 6, 4 bytes per operand element
- *                      instead of 6; 2 = wherever the shape allows (token rows a multiple of 256); 0 = three f16 planes everywhere
+ *                      instead of 6, and the attention's second planes (q, k, V^T, P) likewise (32 f16 + 16 block-scaled MFMAs per wave and
+ *                      64-key tile instead of 96); 2 = wherever the shape allows (token rows a multiple of 256); 0 = three f16 planes everywhere
+ *   "attn_f32_mx"      fp32 mode, where "gemm_f32_mx" applies: 1 (default) = the attention's P V correction terms as block-scaled e4m3 MFMAs, the
+ *                      scores Q K^T stay on three f16 planes (a score's error is exponentiated: 22 bits there); 2 = the scores' correction
+ *                      terms too (2^-16 sum |q_d k_d| of error in a score: fine on small logits — the synthetic checkpoint's — only);
+ *                      0 = three f16 planes throughout the attention
  *   "f32_split_guard"  1 (default) = fp32 mode: a forward in which a value left the f16 range of the hi/lo planes (|x| > 65504) is
  *                      repeated on the exact-fp32 kernels before rz_vision_forward returns (one stream synchronisation per forward;
  *                      not under stream capture); rz_get_model_option(h, "f32_split_guard_reruns") counts the repeats

@@ -145,6 +145,7 @@ SYMBOLS = {
     "rz_flash_attention": (_I, [_I, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "rz_flash_attention_split_workspace": (ctypes.c_size_t, [_I, _I, _I]),
     "rz_flash_attention_f32_split": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "rz_flash_attention_f32_mx": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "rz_text_embed_ln": (_I, [_I, _P, _P, _P, _P, _P, _F, _P, _P, _I, _I, _I, _I, _I, _P]),
     "rz_text_attention": (_I, [_I, _P, _P, _P, _P, _I, _I, _I, _P]),
     "rz_masked_meanpool": (_I, [_P, _P, _P, _I, _I, _I, _P]),

@@ -40,11 +40,12 @@ struct Options {
     int pad_rows;         // token rows per image: 0 = multiple of 128, of 256 when that costs < 2 % more rows | 128 | 256 = always that multiple
     int f32_split_guard;  // fp32 mode: 1 = a forward whose f16 planes overflowed is repeated on the exact-fp32 kernels (default)
     int gemm_f32_mx;      // fp32 mode: 1 (default) = the split GEMMs' two correction terms run as one block-scaled fp8 MFMA (MX form, rz_common.h) for large batches; 2 = wherever the shape allows; 0 = three f16 planes
+    int attn_f32_mx;      // fp32 mode, with the MX GEMM form: 1 (default) = the attention's P V correction terms as block-scaled fp8 MFMAs, scores at 22 bits; 2 = scores too; 0 = f16 planes
     int gemm_raster;      // gemm12.hip: tile order inside an XCD (GemmArgs::raster): 0 = 4 x tiles_n groups | S > 0 = slab walk, <= S n tiles per slab
 };
-Options g_opt = {0, 1, 0, 0, 0, 1, 1, 1, 0, 0, 1, 1, 0};
+Options g_opt = {0, 1, 0, 0, 0, 1, 1, 1, 0, 0, 1, 1, 1, 0};
 const Options kInherit = {RZ_OPT_INHERIT, RZ_OPT_INHERIT, RZ_OPT_INHERIT, RZ_OPT_INHERIT, RZ_OPT_INHERIT, RZ_OPT_INHERIT, RZ_OPT_INHERIT,
-                          RZ_OPT_INHERIT, RZ_OPT_INHERIT, RZ_OPT_INHERIT, RZ_OPT_INHERIT, RZ_OPT_INHERIT, RZ_OPT_INHERIT};
+                          RZ_OPT_INHERIT, RZ_OPT_INHERIT, RZ_OPT_INHERIT, RZ_OPT_INHERIT, RZ_OPT_INHERIT, RZ_OPT_INHERIT, RZ_OPT_INHERIT};
 int* option_field(Options& o, const char* name) {
 #ifdef RZ_EXPERIMENTS      // measured, never a gain (profiles/NOTEBOOK.md): known to the tools build only; the product runs one pass, one stream
     if (!strcmp(name, "vision_chunk")) return &o.vision_chunk;
@@ -61,6 +62,7 @@ int* option_field(Options& o, const char* name) {
     if (!strcmp(name, "pad_rows")) return &o.pad_rows;
     if (!strcmp(name, "f32_split_guard")) return &o.f32_split_guard;
     if (!strcmp(name, "gemm_f32_mx")) return &o.gemm_f32_mx;
+    if (!strcmp(name, "attn_f32_mx")) return &o.attn_f32_mx;
     return nullptr;
 }
 inline int pick(int own, int process_wide) { return own == RZ_OPT_INHERIT ? process_wide : own; }
@@ -162,6 +164,7 @@ struct rz_model {
     int o_gemm_variant() const { return pick(opt.gemm_variant, g_opt.gemm_variant); }
     int o_gemm_raster() const { return pick(opt.gemm_raster, g_opt.gemm_raster); }
     int o_gemm_f32_mx() const { return pick(opt.gemm_f32_mx, g_opt.gemm_f32_mx); }
+    int o_attn_f32_mx() const { return pick(opt.attn_f32_mx, g_opt.attn_f32_mx); }
     bool o_gemm_f32_split() const { return pick(opt.gemm_f32_split, g_opt.gemm_f32_split) != 0 && !force_exact; }
     bool o_attn_f32_split() const { return pick(opt.attn_f32_split, g_opt.attn_f32_split) != 0 && !force_exact; }
     bool o_ln_fused() const { return pick(opt.ln_fused, g_opt.ln_fused) != 0; }
@@ -408,7 +411,9 @@ int load_text_layer(rz_model* m, TextLayer& l, const char* rest, const float* da
 // reuse_split: A was split by the previous call (q|k and v projections share their input).
 enum { A_F32 = 0, A_SPLIT = 1, A_REUSE = 2 };   // the A operand: fp32 (split here), already [M][3K] hi|lo|hi planes, or split by the previous call
 
-int gemm_f32_split(rz_model* m, int epi, GemmArgs g, int a_mode, bool out_split, hipStream_t s, bool* done, bool mx = false) {
+// mx: 0 = three f16 planes; else the MX form, and bits 1 / 2 say which attention operands leave with an e4m3 pair plane instead of an f16 lo plane
+// (2: V^T, 4: q | k)
+int gemm_f32_split(rz_model* m, int epi, GemmArgs g, int a_mode, bool out_split, hipStream_t s, bool* done, int mx = 0) {
     *done = false;
     if (!(epi == EPI_HEADS || epi == EPI_VT || epi == EPI_GELU || epi == EPI_RESID_SCALE || epi == EPI_PATCH)) return 0;
     if (g.M % 128 || g.lda != g.K || g.ldw != g.K) return 0;
@@ -434,7 +439,8 @@ int gemm_f32_split(rz_model* m, int epi, GemmArgs g, int a_mode, bool out_split,
         }
         g.W = w3; g.lda = g.ldw = 2 * (int64_t)g.K; g.K = 2 * g.K;
         if (!gemm_v7_mx_ok(g)) return fail(RZ_ERR_STATE, "MX GEMM: shape not supported");
-        const int out_kind = (epi == EPI_RESID_SCALE || epi == EPI_PATCH) ? 0 : (epi == EPI_GELU ? 2 : 1);
+        const int out_kind = (epi == EPI_RESID_SCALE || epi == EPI_PATCH) ? 0 : epi == EPI_GELU ? 2 :
+                             ((epi == EPI_VT && (mx & 2)) || (epi == EPI_HEADS && (mx & 4))) ? 3 : 1;       // 3: hi f16 + e4m3 pair planes (MX attention)
         if ((out_kind != 0) != out_split) return fail(RZ_ERR_STATE, "MX GEMM: output form mismatch");
         RZ_HIP(launch_gemm_v7_mx(epi, g, out_kind, s));
         *done = true;
@@ -465,7 +471,7 @@ int gemm_f32_split(rz_model* m, int epi, GemmArgs g, int a_mode, bool out_split,
 // a_mode / out_split / plane_off: fp32 mode's hi/lo-split path only (see gemm_f32_split); with A_SPLIT or out_split the call MUST take it
 int gemm(rz_model* m, int epi, const void* A, int64_t lda, const void* W, int64_t ldw, int M, int N, int K, const float* bias,
          void* out, int64_t ldo, const float* scale, float* resid, int64_t ldr, int rpi, int heads, hipStream_t s, int a_mode = A_F32,
-         bool out_split = false, int64_t plane_off = 0, bool mx = false) {
+         bool out_split = false, int64_t plane_off = 0, int mx = 0) {
     GemmArgs g;
     g.A = A; g.lda = lda; g.W = W; g.ldw = ldw; g.M = M; g.N = N; g.K = K; g.bias = bias; g.out = out; g.ldo = ldo;
     g.scale = scale; g.resid = resid; g.ldr = ldr; g.rows_per_image = rpi; g.heads_total = heads; g.plane_off = plane_off;
@@ -881,7 +887,9 @@ static int vision_forward_once(rz_handle_t m, const float* px, int B, int C, int
         // MX form of the split GEMMs (rz_common.h): every GEMM of the chunk or none (the producers write ONE operand form).  The 256 x 256
         // kernel that runs it needs M % 256 == 0; option 1 (default) takes it where that kernel's grid fills the chip, 2 wherever it applies
         const int mxo = m->o_gemm_f32_mx();
-        const bool mx = sp && mxo != 0 && m->mx_weights_ok && M % 256 == 0 && (mxo == 2 || M >= 256 * 64);
+        const bool mxg = sp && mxo != 0 && m->mx_weights_ok && M % 256 == 0 && (mxo == 2 || M >= 256 * 64);
+        const int mxa = mxg ? m->o_attn_f32_mx() : 0;                         // the attention's MX form rides on the GEMMs' (its ctx leaves in the MX form)
+        const int mx = mxg ? (1 | (mxa >= 1 ? 2 : 0) | (mxa >= 2 ? 4 : 0)) : 0;
         const size_t ex = m->dt == RZ_F32 ? 6 : es;
         char* xn = (char*)m->xn.p + row0 * D * ex;
         char* qkb = (char*)m->qk.p + row0 * 2 * D * es;
@@ -926,7 +934,7 @@ static int vision_forward_once(rz_handle_t m, const float* px, int B, int C, int
             if (sp) {
                 {
                     ProfScope ps(m, RZ_PROF_ROWOPS, s);
-                    RZ_HIP(launch_layernorm_split3(h, (const float*)b.ln1_g.p, (const float*)b.ln1_b.p, eps, xn, M, D, (unsigned*)m->ovf.p, s, mx));
+                    RZ_HIP(launch_layernorm_split3(h, (const float*)b.ln1_g.p, (const float*)b.ln1_b.p, eps, xn, M, D, (unsigned*)m->ovf.p, s, mx != 0));
                 }
                 // q | k -> hi / lo planes of [Bc][2H][np][64]; V^T -> hi / lo planes of [Bc][H][64][np]
                 const char* wv = (const char*)b.wqkv.p + (size_t)2 * D * D * 4;
@@ -962,7 +970,7 @@ static int vision_forward_once(rz_handle_t m, const float* px, int B, int C, int
                 const char* kb = qb + (size_t)H * np * 64 * es;
                 if (sp)                                         // planes in (f16: k heads start H*np*64 ELEMENTS behind q), [hi | lo | hi] ctx out
                     RZ_HIP(launch_flash_attn_split_planes(qb, qb + (size_t)H * np * 64 * 2, vtb, ctxb, (int64_t)2 * H * np * 64, (int64_t)M * 2 * D, (int64_t)M * D,
-                                                          Bc, H, nv, np, (unsigned*)m->ovf.p, s, mx));
+                                                          Bc, H, nv, np, (unsigned*)m->ovf.p, s, mx != 0, mxa));
                 else if (m->dt == RZ_F32 && m->o_attn_f32_split())      // hi/lo f16 planes of q, k, V^T live in `mid` (free between the QKV and fc1 GEMMs: 3/4 of it)
                     RZ_HIP(launch_flash_attn_f32_split((const float*)qb, (const float*)kb, (const float*)vtb, (float*)ctxb, mid, (int64_t)2 * H * np * 64,
                                                        Bc, H, nv, np, (unsigned*)m->ovf.p, s));
@@ -973,7 +981,7 @@ static int vision_forward_once(rz_handle_t m, const float* px, int B, int C, int
                 if ((rc = gemm(m, EPI_RESID_SCALE, ctxb, D, b.wo.p, D, M, D, D, (const float*)b.bo.p, nullptr, 0, (const float*)b.ls1.p, h, D, np, 0, s, A_SPLIT, false, 0, mx))) return rc;
                 {
                     ProfScope ps(m, RZ_PROF_ROWOPS, s);
-                    RZ_HIP(launch_layernorm_split3(h, (const float*)b.ln2_g.p, (const float*)b.ln2_b.p, eps, xn, M, D, (unsigned*)m->ovf.p, s, mx));
+                    RZ_HIP(launch_layernorm_split3(h, (const float*)b.ln2_g.p, (const float*)b.ln2_b.p, eps, xn, M, D, (unsigned*)m->ovf.p, s, mx != 0));
                 }
             } else if (!fused) {
                 if ((rc = gemm(m, EPI_RESID_SCALE, ctxb, D, b.wo.p, D, M, D, D, (const float*)b.bo.p, nullptr, 0, (const float*)b.ls1.p, h, D, np, 0, s))) return rc;
@@ -1327,6 +1335,14 @@ int rz_flash_attention_f32_split(const float* q, const float* k, const float* vt
     if (!q || !k || !vt || !ctx || !ws) return fail(RZ_ERR_INVALID, "rz_flash_attention_f32_split: null argument");
     if (n_pad % 128 || n_valid <= 0 || n_valid > n_pad) return fail(RZ_ERR_INVALID, "rz_flash_attention_f32_split: n_pad must be a multiple of 128 >= n_valid > 0");
     RZ_HIP(launch_flash_attn_f32_split(q, k, vt, ctx, ws, (int64_t)H * n_pad * 64, B, H, n_valid, n_pad, nullptr, (hipStream_t)stream));
+    return 0;
+}
+
+int rz_flash_attention_f32_mx(const float* q, const float* k, const float* vt, float* ctx, void* ws, int B, int H, int n_valid, int n_pad,
+                              void* stream) {
+    if (!q || !k || !vt || !ctx || !ws) return fail(RZ_ERR_INVALID, "rz_flash_attention_f32_mx: null argument");
+    if (n_pad % 128 || n_valid <= 0 || n_valid > n_pad) return fail(RZ_ERR_INVALID, "rz_flash_attention_f32_mx: n_pad must be a multiple of 128 >= n_valid > 0");
+    RZ_HIP(launch_flash_attn_f32_split(q, k, vt, ctx, ws, (int64_t)H * n_pad * 64, B, H, n_valid, n_pad, nullptr, (hipStream_t)stream, g_opt.attn_f32_mx >= 2 ? 2 : 1));
     return 0;
 }
 

@@ -837,7 +837,15 @@ __global__ __launch_bounds__(256, 1) void flash_attn_ks_kernel(const bf16_t* __r
 // ---------------------------------------------------------------------------------------------
 // OUT_SPLIT: ctx leaves as the out-projection's split A operand instead of fp32: 1 = [rows][3 * H * 64] f16 = [hi | lo | hi],
 // 2 = the MX form (rz_common.h: [hi f16 x D | per head: lo8 x 64, hi8 x 64], 4 D bytes per row).
-template <int OUT_SPLIT>
+// MXA (round 4): the MX form of the two correction terms (rz_common.h "MX form"): the second plane of q, k and V^T is not f16(x - hi) but
+// 128 bytes of e4m3 per row — q: [lo8 x 64 | hi8 x 64], k: [hi8 | lo8] (per key / query, along d), V^T: [hi8 | lo8] per (d, 64-key
+// block), the 64 keys of a block in the order the score accumulators hand them to a lane (position 16 g + j holds key 8 g + j for j < 8,
+// 32 + 8 g + j - 8 beyond: gemm_common.h writes it so) — and each pair of correction terms is ONE block-scaled MFMA over K' = 128:
+// S += [k_hi8 | k_lo8] . [q_lo8 | q_hi8],  O += [v_hi8 | v_lo8] . [p_lo8 | p_hi8]  (P split in registers, fixed scales 1 and 2^-11).
+// 32 f16 MFMAs + 16 block-scaled ones per wave and 64-key tile instead of 96 f16 ones; same bytes staged, same LDS image.
+// MXA 1 = P V only (q and k keep their f16 lo planes: the scores stay at 22 bits — a score's error is EXPONENTIATED, and 4-bit correction
+// terms leave it at 2^-16 sum |q_d k_d|, harmless on small logits only), 2 = scores as well.
+template <int OUT_SPLIT, int MXA = 0>
 __global__ __launch_bounds__(256, 2) void flash_attn_split_kernel(const f16_t* __restrict__ q, const f16_t* __restrict__ k,
                                                                   const f16_t* __restrict__ vT, void* __restrict__ ctx_out,
                                                                   int64_t qk_batch_stride, int64_t qk_lo_off, int64_t v_lo_off,
@@ -911,6 +919,8 @@ __global__ __launch_bounds__(256, 2) void flash_attn_split_kernel(const f16_t* _
 #pragma unroll
         for (int c = 0; c < 4; ++c) oacc[a][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
     }
+    // MXA: E8M0 scale byte of this lane's 32-element block (block = lane >> 4): [hi8 | lo8] rows (k, V^T), [lo8 | hi8] rows (q), P
+    [[maybe_unused]] const int sc_hl = lg < 2 ? MX_E8_A_HI : MX_E8_A_LO, sc_lh = lg < 2 ? MX_E8_A_LO : MX_E8_A_HI, sc_p = lg < 2 ? 116 : 127;
 
     auto tile = [&](int t, auto first_c, auto mask_c) {
         constexpr bool FIRST = decltype(first_c)::value, MASK = decltype(mask_c)::value;
@@ -923,7 +933,6 @@ __global__ __launch_bounds__(256, 2) void flash_attn_split_kernel(const f16_t* _
         auto load_v = [&](int pl, int kk, int dt) -> frag_t {
             return *reinterpret_cast<const frag_t*>(sv + pl * TILE + voff[kk] + dt * 2048);
         };
-        // ---- S' = K Q^T - mrow:  kh.qh + kh.ql + kl.qh ----
         f32x4 sacc[2][4];
         {
             frag_t kf[2][4];
@@ -939,22 +948,34 @@ __global__ __launch_bounds__(256, 2) void flash_attn_split_kernel(const f16_t* _
             for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
                 for (int a = 0; a < 2; ++a) sacc[a][kt] = mma(kf[1][kt], qh[a][1], sacc[a][kt]);
+            if constexpr (MXA == 2) {
+                // the key's pair row [k_hi8 | k_lo8] against the query's [q_lo8 | q_hi8] (ql[a][0 / 1] hold its chunks lg and 4 + lg)
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks)
+                for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-                for (int kt = 0; kt < 4; ++kt)
-#pragma unroll
-                    for (int a = 0; a < 2; ++a) sacc[a][kt] = mma(kf[ks][kt], ql[a][ks], sacc[a][kt]);
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-                for (int kt = 0; kt < 4; ++kt) kf[ks][kt] = load_k(1, ks, kt);
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks)
+                    for (int kt = 0; kt < 4; ++kt) kf[ks][kt] = load_k(1, ks, kt);
 #pragma unroll
                 for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
-                    for (int a = 0; a < 2; ++a) sacc[a][kt] = mma(kf[ks][kt], qh[a][ks], sacc[a][kt]);
+                    for (int a = 0; a < 2; ++a) sacc[a][kt] = mma_mx(kf[0][kt], kf[1][kt], ql[a][0], ql[a][1], sacc[a][kt], sc_hl, sc_lh);
+            } else {
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                    for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                        for (int a = 0; a < 2; ++a) sacc[a][kt] = mma(kf[ks][kt], ql[a][ks], sacc[a][kt]);
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                    for (int kt = 0; kt < 4; ++kt) kf[ks][kt] = load_k(1, ks, kt);
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                    for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                        for (int a = 0; a < 2; ++a) sacc[a][kt] = mma(kf[ks][kt], qh[a][ks], sacc[a][kt]);
+            }
         }
         if constexpr (MASK) {
             const int key0 = t * FA_KEYS;
@@ -1004,11 +1025,12 @@ __global__ __launch_bounds__(256, 2) void flash_attn_split_kernel(const f16_t* _
             }
             asm volatile("" ::: "memory");
         }
-        // ---- P = 2^S' (fp32), row sums, split into f16 planes ----
-        frag_t ph[2][2], pl[2][2];
+        // ---- P = 2^S' (fp32), row sums, split into planes ----
+        frag_t ph[2][2], pl[2][2];       // MXA: pl[qt][0] = [p_lo8 of the lane's 16 keys], pl[qt][1] = [p_hi8 ...] (16 bytes each)
 #pragma unroll
         for (int qt = 0; qt < 2; ++qt) {
             float psum = 0.f;
+            uint32_t w8[2][4];           // MXA: [lo8 | hi8][kk * 2 + half]
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk) {
                 float pv[8], pr[8];
@@ -1020,29 +1042,63 @@ __global__ __launch_bounds__(256, 2) void flash_attn_split_kernel(const f16_t* _
                 ph[qt][kk] = pack8<f16_t>(pv[0], pv[1], pv[2], pv[3], pv[4], pv[5], pv[6], pv[7]);
 #pragma unroll
                 for (int i = 0; i < 8; ++i) pr[i] = pv[i] - (float)ph[qt][kk][i];
-                pl[qt][kk] = pack8<f16_t>(pr[0], pr[1], pr[2], pr[3], pr[4], pr[5], pr[6], pr[7]);
+                if constexpr (MXA) {
+                    // P <= 2^8 (FA_DEFER): hi8 = e4m3(p) with scale 1, lo8 = e4m3((p - f16(p)) 2^11) with scale 2^-11: both within +-448
+                    w8[0][kk * 2 + 0] = cvt4_e4m3(pr[0] * 2048.f, pr[1] * 2048.f, pr[2] * 2048.f, pr[3] * 2048.f);
+                    w8[0][kk * 2 + 1] = cvt4_e4m3(pr[4] * 2048.f, pr[5] * 2048.f, pr[6] * 2048.f, pr[7] * 2048.f);
+                    w8[1][kk * 2 + 0] = cvt4_e4m3(pv[0], pv[1], pv[2], pv[3]);
+                    w8[1][kk * 2 + 1] = cvt4_e4m3(pv[4], pv[5], pv[6], pv[7]);
+                } else {
+                    pl[qt][kk] = pack8<f16_t>(pr[0], pr[1], pr[2], pr[3], pr[4], pr[5], pr[6], pr[7]);
+                }
+            }
+            if constexpr (MXA) {
+                pl[qt][0] = __builtin_bit_cast(frag_t, (u32x4){w8[0][0], w8[0][1], w8[0][2], w8[0][3]});
+                pl[qt][1] = __builtin_bit_cast(frag_t, (u32x4){w8[1][0], w8[1][1], w8[1][2], w8[1][3]});
             }
             lrow[qt] += psum;
         }
         // ---- O^T += V^T P^T:  vh.ph + vh.pl + vl.ph ----
+        if constexpr (MXA) {
 #pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-            frag_t vf[4];
+            for (int kk = 0; kk < 2; ++kk) {
+                frag_t vf[4];
 #pragma unroll
-            for (int dt = 0; dt < 4; ++dt) vf[dt] = load_v(0, kk, dt);
+                for (int dt = 0; dt < 4; ++dt) vf[dt] = load_v(0, kk, dt);
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+                    for (int a = 0; a < 2; ++a) oacc[a][dt] = mma(vf[dt], ph[a][kk], oacc[a][dt]);
+            }
+            frag_t v8[2][4];             // the d row's pair block [v_hi8 | v_lo8], keys in the lanes' order: chunks lg and 4 + lg
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) v8[kk][dt] = load_v(1, kk, dt);
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt)
 #pragma unroll
-                for (int a = 0; a < 2; ++a) {
-                    oacc[a][dt] = mma(vf[dt], pl[a][kk], oacc[a][dt]);
-                    oacc[a][dt] = mma(vf[dt], ph[a][kk], oacc[a][dt]);
-                }
+                for (int a = 0; a < 2; ++a) oacc[a][dt] = mma_mx(v8[0][dt], v8[1][dt], pl[a][0], pl[a][1], oacc[a][dt], sc_hl, sc_p);
+        } else {
 #pragma unroll
-            for (int dt = 0; dt < 4; ++dt) vf[dt] = load_v(1, kk, dt);
+            for (int kk = 0; kk < 2; ++kk) {
+                frag_t vf[4];
 #pragma unroll
-            for (int dt = 0; dt < 4; ++dt)
+                for (int dt = 0; dt < 4; ++dt) vf[dt] = load_v(0, kk, dt);
 #pragma unroll
-                for (int a = 0; a < 2; ++a) oacc[a][dt] = mma(vf[dt], ph[a][kk], oacc[a][dt]);
+                for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+                    for (int a = 0; a < 2; ++a) {
+                        oacc[a][dt] = mma(vf[dt], pl[a][kk], oacc[a][dt]);
+                        oacc[a][dt] = mma(vf[dt], ph[a][kk], oacc[a][dt]);
+                    }
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) vf[dt] = load_v(1, kk, dt);
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+                    for (int a = 0; a < 2; ++a) oacc[a][dt] = mma(vf[dt], ph[a][kk], oacc[a][dt]);
+            }
         }
     };
     using TrueT = std::integral_constant<bool, true>;
@@ -1119,18 +1175,56 @@ __global__ __launch_bounds__(256) void split_f16_kernel(const float* __restrict_
     }
 }
 
+// x (fp32) -> hi = f16(x) plane + e4m3 pair plane of the MX attention (see flash_attn_split_kernel "MXA"): kind 0 = q rows [lo8 | hi8] per 64
+// elements, 1 = k rows [hi8 | lo8], 2 = V^T rows (row_len tokens per row): [hi8 | lo8] per 64-token block, tokens in the lanes' order
+__global__ __launch_bounds__(256) void split_mxa_kernel(const float* __restrict__ x, int64_t src_stride, f16_t* __restrict__ hi, char* __restrict__ pair,
+                                                        int64_t per4, int kind, int row_len, unsigned* ovf_flag) {
+    const float* src = x + (int64_t)blockIdx.y * src_stride;
+    const int64_t dst0 = (int64_t)blockIdx.y * per4 * 4;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < per4; i += (int64_t)gridDim.x * 256) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(src + 4 * i);
+        f16x4 h;
+        uint32_t lo8, hi8;
+        split4_mx(v, h, lo8, hi8, MX_A_HI_SCALE, MX_A_LO_SCALE, ovf_flag);
+        const int64_t e = dst0 + 4 * i;                   // element index; 64 elements = one 128-byte pair block
+        *reinterpret_cast<f16x4*>(hi + e) = h;
+        const int in64 = (int)(e & 63);
+        int pos = in64;
+        if (kind == 2) { (void)row_len; pos = 16 * ((in64 & 31) >> 3) + 8 * (in64 >> 5) + (in64 & 7); }        // rows are multiples of 64 tokens long
+        char* blk = pair + (e >> 6) * 128;
+        *reinterpret_cast<uint32_t*>(blk + pos) = kind == 0 ? lo8 : hi8;
+        *reinterpret_cast<uint32_t*>(blk + 64 + pos) = kind == 0 ? hi8 : lo8;
+    }
+}
+
 size_t flash_attn_split_workspace_bytes(int B, int H, int n_pad) { return (size_t)3 * B * H * n_pad * 64 * 4; }
 
 // fp32 q, k ([B][H][n_pad][64] each, batch stride qk_batch_stride) and V^T ([B][H][64][n_pad]) -> fp32 ctx through the split kernel.
 // split_ws (flash_attn_split_workspace_bytes): planes q_hi q_lo k_hi k_lo v_hi v_lo, each B*H*n_pad*64 f16.
 hipError_t launch_flash_attn_f32_split(const float* q, const float* k, const float* vT, float* ctx, void* split_ws, int64_t qk_batch_stride,
-                                       int B, int H, int n_valid, int n_pad, unsigned* ovf_flag, hipStream_t s) {
+                                       int B, int H, int n_valid, int n_pad, unsigned* ovf_flag, hipStream_t s, int mxa) {
     if (n_pad % FA_QROWS || n_valid <= 0 || n_valid > n_pad || B <= 0 || H <= 0 || !split_ws) return hipErrorInvalidValue;
     const int64_t per = (int64_t)H * n_pad * 64, n = (int64_t)B * per;
     f16_t* q_hi = reinterpret_cast<f16_t*>(split_ws);
     f16_t* k_hi = q_hi + 2 * n;
     f16_t* v_hi = q_hi + 4 * n;
     const dim3 sgrid(256, B);
+    if (mxa) {
+        if (n_pad % 64) return hipErrorInvalidValue;
+        if (mxa == 2) {
+            hipLaunchKernelGGL(split_mxa_kernel, sgrid, dim3(256), 0, s, q, qk_batch_stride, q_hi, (char*)(q_hi + n), per / 4, 0, 64, ovf_flag);
+            hipLaunchKernelGGL(split_mxa_kernel, sgrid, dim3(256), 0, s, k, qk_batch_stride, k_hi, (char*)(k_hi + n), per / 4, 1, 64, ovf_flag);
+        } else {
+            hipLaunchKernelGGL(split_f16_kernel, sgrid, dim3(256), 0, s, q, qk_batch_stride, q_hi, q_hi + n, per / 4, ovf_flag);
+            hipLaunchKernelGGL(split_f16_kernel, sgrid, dim3(256), 0, s, k, qk_batch_stride, k_hi, k_hi + n, per / 4, ovf_flag);
+        }
+        hipLaunchKernelGGL(split_mxa_kernel, sgrid, dim3(256), 0, s, vT, per, v_hi, (char*)(v_hi + n), per / 4, 2, n_pad, ovf_flag);
+        const int nq = n_pad / FA_QROWS;
+        dim3 grid(((B * H * nq + 7) / 8) * 8), block(256);
+        if (mxa == 2) hipLaunchKernelGGL((flash_attn_split_kernel<0, 2>), grid, block, 0, s, q_hi, k_hi, v_hi, (void*)ctx, per, n, n, B, H, n_valid, n_pad, ovf_flag);
+        else hipLaunchKernelGGL((flash_attn_split_kernel<0, 1>), grid, block, 0, s, q_hi, k_hi, v_hi, (void*)ctx, per, n, n, B, H, n_valid, n_pad, ovf_flag);
+        return hipGetLastError();
+    }
     hipLaunchKernelGGL(split_f16_kernel, sgrid, dim3(256), 0, s, q, qk_batch_stride, q_hi, q_hi + n, per / 4, ovf_flag);
     hipLaunchKernelGGL(split_f16_kernel, sgrid, dim3(256), 0, s, k, qk_batch_stride, k_hi, k_hi + n, per / 4, ovf_flag);
     hipLaunchKernelGGL(split_f16_kernel, sgrid, dim3(256), 0, s, vT, per, v_hi, v_hi + n, per / 4, ovf_flag);
@@ -1143,11 +1237,18 @@ hipError_t launch_flash_attn_f32_split(const float* q, const float* k, const flo
 // The same kernel on operands that are ALREADY hi/lo planes (written by the split q|k / V^T epilogues, gemm_common.h): q_hi, k_hi
 // with batch stride qk_batch_stride, lo planes qk_lo_off / v_lo_off elements behind the hi planes; ctx3 = [rows][3 * H * 64] f16.
 hipError_t launch_flash_attn_split_planes(const void* q_hi, const void* k_hi, const void* v_hi, void* ctx3, int64_t qk_batch_stride,
-                                          int64_t qk_lo_off, int64_t v_lo_off, int B, int H, int n_valid, int n_pad, unsigned* ovf_flag, hipStream_t s, int mx_out) {
-    if (n_pad % FA_QROWS || n_valid <= 0 || n_valid > n_pad || B <= 0 || H <= 0) return hipErrorInvalidValue;
+                                          int64_t qk_lo_off, int64_t v_lo_off, int B, int H, int n_valid, int n_pad, unsigned* ovf_flag, hipStream_t s, int mx_out,
+                                          int mxa) {
+    if (n_pad % FA_QROWS || n_valid <= 0 || n_valid > n_pad || B <= 0 || H <= 0 || (mxa && !mx_out)) return hipErrorInvalidValue;
     const int nq = n_pad / FA_QROWS;
     dim3 grid(((B * H * nq + 7) / 8) * 8), block(256);
-    if (mx_out)
+    if (mxa == 2)
+        hipLaunchKernelGGL((flash_attn_split_kernel<2, 2>), grid, block, 0, s, (const f16_t*)q_hi, (const f16_t*)k_hi, (const f16_t*)v_hi, ctx3,
+                           qk_batch_stride, qk_lo_off, v_lo_off, B, H, n_valid, n_pad, ovf_flag);
+    else if (mxa)
+        hipLaunchKernelGGL((flash_attn_split_kernel<2, 1>), grid, block, 0, s, (const f16_t*)q_hi, (const f16_t*)k_hi, (const f16_t*)v_hi, ctx3,
+                           qk_batch_stride, qk_lo_off, v_lo_off, B, H, n_valid, n_pad, ovf_flag);
+    else if (mx_out)
         hipLaunchKernelGGL(flash_attn_split_kernel<2>, grid, block, 0, s, (const f16_t*)q_hi, (const f16_t*)k_hi, (const f16_t*)v_hi, ctx3,
                            qk_batch_stride, qk_lo_off, v_lo_off, B, H, n_valid, n_pad, ovf_flag);
     else

@@ -272,9 +272,10 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel_v7(GemmArgs g) {
         __syncthreads();            // every wave is past its last operand read: LDS is free
         gemm_epilogue_tile16<OT, EPI>(g, acc, lds, m0, n0, wr, wc, lane, tid);
     } else if constexpr ((std::is_same<OT, split_f16>::value && (EPI == EPI_GELU || EPI == EPI_HEADS || EPI == EPI_VT)) ||
-                         (std::is_same<OT, split_mx>::value && EPI == EPI_GELU)) {
+                         (std::is_same<OT, split_mx>::value && EPI == EPI_GELU) ||
+                         (std::is_same<OT, split_mxa>::value && (EPI == EPI_HEADS || EPI == EPI_VT))) {
         __syncthreads();
-        gemm_epilogue_tile_split<EPI, std::is_same<OT, split_mx>::value ? 1 : 0>(g, acc, lds, m0, n0, wr, wc, lane, tid);
+        gemm_epilogue_tile_split<EPI, std::is_same<OT, split_mx>::value ? 1 : (std::is_same<OT, split_mxa>::value ? 2 : 0)>(g, acc, lds, m0, n0, wr, wc, lane, tid);
     } else {
         gemm_epilogue<OT, EPI>(g, acc[0], mw, nw, l15, lg);
         gemm_epilogue<OT, EPI>(g, acc[1], mw + 64, nw, l15, lg);
@@ -332,7 +333,8 @@ hipError_t launch_gemm_v7_f16_out(int epi, const GemmArgs& g, bool split_out, hi
 
 // fp32 mode, MX form (rz_common.h): operand rows [K f16 | 2 K fp8 bytes], g.lda / g.ldw = 2 K and g.K = 2 K in f16-element units (so the
 // staging code sees an ordinary K' = 2 K GEMM).  out_kind 0: fp32 read-modify-write / table epilogues (EPI_RESID_SCALE, EPI_PATCH);
-// 1: hi/lo f16 planes for the attention (EPI_HEADS, EPI_VT); 2: the next GEMM's A operand in MX form (EPI_GELU).
+// 1: hi/lo f16 planes for the attention (EPI_HEADS, EPI_VT); 2: the next GEMM's A operand in MX form (EPI_GELU); 3: hi f16 plane + e4m3
+// pair plane for the MX attention (EPI_HEADS, EPI_VT).
 bool gemm_v7_mx_ok(const GemmArgs& g) {
     return g.M % V7_BM == 0 && g.N % V7_BN == 0 && g.K % 128 == 0 && g.K >= 256;
 }
@@ -344,6 +346,8 @@ hipError_t launch_gemm_v7_mx(int epi, const GemmArgs& g, int out_kind, hipStream
         switch (epi) { RZ_CASE7M(EPI_RESID_SCALE, f16_t) RZ_CASE7M(EPI_PATCH, f16_t) default: return hipErrorInvalidValue; }
     } else if (out_kind == 1) {
         switch (epi) { RZ_CASE7M(EPI_HEADS, split_f16) RZ_CASE7M(EPI_VT, split_f16) default: return hipErrorInvalidValue; }
+    } else if (out_kind == 3) {
+        switch (epi) { RZ_CASE7M(EPI_HEADS, split_mxa) RZ_CASE7M(EPI_VT, split_mxa) default: return hipErrorInvalidValue; }
     } else {
         switch (epi) { RZ_CASE7M(EPI_GELU, split_mx) default: return hipErrorInvalidValue; }
     }

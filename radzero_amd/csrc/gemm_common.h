@@ -466,10 +466,15 @@ __device__ __forceinline__ void gemm_epilogue_tile16(const GemmArgs& g, const f3
 //   FORM 1 (MX, rz_common.h):  EPI_GELU -> [hi f16 x ldo | per 64 columns: lo8 x 64, hi8 x 64]: the tile's 256 columns are 512 bytes of
 //                              the hi plane and 512 bytes (4 groups) of the pair plane
 // ---------------------------------------------------------------------------------------------------
+//   FORM 2 (MX attention operands, attention.hip "MXA"): EPI_HEADS / EPI_VT -> hi f16 plane + a pair plane `plane_off` elements behind it with
+//                              128 bytes of e4m3 per 64 elements: q heads [lo8 | hi8], k heads and V^T [hi8 | lo8]; V^T's 64 tokens of a
+//                              block sit at position 16 g + j = token 8 g + j (j < 8) | 32 + 8 g + j - 8 (the order the attention's
+//                              score accumulators hand keys to a lane)
 template <int EPI, int FORM>
 __device__ __forceinline__ void gemm_epilogue_tile_split(const GemmArgs& g, f32x4 (&acc)[2][4][4], char* lds, int m0, int n0,
                                                          int wr, int wc, int lane, int tid) {
-    static_assert(EPI == EPI_GELU || ((EPI == EPI_HEADS || EPI == EPI_VT) && FORM == 0), "split outputs: q|k, V^T (f16 planes), fc1 (either form)");
+    static_assert(EPI == EPI_GELU || ((EPI == EPI_HEADS || EPI == EPI_VT) && (FORM == 0 || FORM == 2)), "split outputs: q|k, V^T (planes), fc1 (either form)");
+    static_assert(!(EPI == EPI_GELU && FORM == 2), "FORM 2 is the attention operands' form");
     constexpr bool SWAP = (EPI != EPI_VT);
     const int l15 = lane & 15, lg = lane >> 4;
     // final values, in place
@@ -507,7 +512,23 @@ __device__ __forceinline__ void gemm_epilogue_tile_split(const GemmArgs& g, f32x
                     if constexpr (SWAP) { row = wr * 128 + a * 64 + i * 16 + l15; c16 = wc * 8 + j * 2 + (lg >> 1); }
                     else { row = wc * 64 + j * 16 + l15; c16 = wr * 16 + a * 8 + i * 2 + (lg >> 1); }
                     const f16x4 hi = pack4<f16_t>(v[0], v[1], v[2], v[3]);
-                    if (FORM == 1 && pass == 1) {
+                    if (FORM == 2 && pass == 1) {
+                        uint32_t lo8, hi8;
+                        f16x4 h2;
+                        split4_mx(v, h2, lo8, hi8, MX_A_HI_SCALE, MX_A_LO_SCALE, g.ovf_flag);
+                        int c_first, byte;            // 16-byte chunk (of the row's 32) and byte in it of the FIRST 4-byte piece; the second is 4 chunks on
+                        bool hi_first;
+                        if constexpr (SWAP) {         // q|k: the wave's 64 columns are one head = one 128-byte pair row
+                            c_first = wc * 8 + j; byte = 4 * lg;
+                            hi_first = (n0 >> 6) + wc >= (g.heads_total >> 1);       // k heads: [hi8 | lo8]; q heads: [lo8 | hi8]
+                        } else {                      // V^T: tokens along the row; 64-token block (wr, a), token i * 16 + 4 lg + r inside it
+                            const int kq = i * 16 + 4 * lg, pos = 16 * ((kq & 31) >> 3) + 8 * (kq >> 5) + (kq & 7);
+                            c_first = (wr * 2 + a) * 8 + (pos >> 4); byte = pos & 15;
+                            hi_first = true;
+                        }
+                        *reinterpret_cast<uint32_t*>(lds + row * 512 + ((c_first ^ (row & 15)) << 4) + byte) = hi_first ? hi8 : lo8;
+                        *reinterpret_cast<uint32_t*>(lds + row * 512 + (((c_first + 4) ^ (row & 15)) << 4) + byte) = hi_first ? lo8 : hi8;
+                    } else if (FORM == 1 && pass == 1) {
                         // pair plane: 4 bytes lo8 at byte 128 wc + 16 j + 4 lg of the row's 512, 4 bytes hi8 64 bytes further
                         uint32_t lo8, hi8;
                         f16x4 h2;

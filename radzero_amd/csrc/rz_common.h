@@ -106,6 +106,7 @@ __device__ __forceinline__ void split4(const f32x4& v, f16x4& hi, f16x4& lo, uns
 // tools/mb_mx_probe.hip (profiles/r04/mx_mfma_layout_probe.txt); conversion numerics (RNE, overflow -> NaN, hence the clamp):
 // tools/mb_fp8_cvt.hip.
 struct split_mx {};       // output "type": the next GEMM's A operand in the form above
+struct split_mxa {};      // output "type": the attention's q | k / V^T operands: hi f16 plane + e4m3 pair plane (attention.hip "MXA")
 constexpr float MX_A_HI_SCALE = 4.0f, MX_A_LO_SCALE = 4.0f / 2048.0f;          // activations: hi8 covers |x| <= 1792, lo8 = (x - f16(x)) / 2^-9
 constexpr float MX_W_HI_SCALE = 1.0f / 16.0f, MX_W_LO_SCALE = 1.0f / 32768.0f; // weights: hi8 covers |w| <= 28
 constexpr int MX_E8_A_HI = 129, MX_E8_A_LO = 118, MX_E8_W_HI = 123, MX_E8_W_LO = 112;      // E8M0 = 127 + log2(scale)

@@ -120,7 +120,7 @@ hipError_t launch_gemm_v7_mx(int epi, const GemmArgs& g, int out_kind, hipStream
     if (out_kind == 0) {
         if (epi == EPI_PATCH) { rd(g.scale, (size_t)g.rows_per_image * g.N * 4, "patch table"); wr(g.out, ((size_t)(g.M - 1) * g.ldo + g.N) * 4, "MX gemm fp32 out"); }
         else { rd(g.scale, (size_t)g.N * 4, "LayerScale"); wr(g.resid, ((size_t)(g.M - 1) * g.ldr + g.N) * 4, "MX gemm residual stream"); }
-    } else if (out_kind == 1) {
+    } else if (out_kind == 1 || out_kind == 3) {
         const size_t plane = images * g.heads_total * g.rows_per_image * 64;
         wr(g.out, plane * 2, "MX gemm hi plane");
         wr((char*)g.out + (size_t)g.plane_off * 2, plane * 2, "MX gemm lo plane");
@@ -149,7 +149,7 @@ hipError_t launch_flash_attn(int dtype, const void* q, const void* k, const void
     return hipSuccess;
 }
 size_t flash_attn_split_workspace_bytes(int B, int H, int n_pad) { return (size_t)3 * B * H * n_pad * 64 * 4; }      // attention.hip
-hipError_t launch_flash_attn_f32_split(const float* q, const float* k, const float* vT, float* ctx, void* ws, int64_t bs, int B, int H, int nv, int np, unsigned*, hipStream_t) {
+hipError_t launch_flash_attn_f32_split(const float* q, const float* k, const float* vT, float* ctx, void* ws, int64_t bs, int B, int H, int nv, int np, unsigned*, hipStream_t, int) {
     const size_t head = (size_t)np * 64;
     rd(q, ((size_t)(B - 1) * bs + H * head) * 4, "split attention q");
     rd(k, ((size_t)(B - 1) * bs + H * head) * 4, "split attention k");
@@ -158,7 +158,7 @@ hipError_t launch_flash_attn_f32_split(const float* q, const float* k, const flo
     wr(ctx, (size_t)B * np * H * 64 * 4, "split attention ctx");
     return hipSuccess;
 }
-hipError_t launch_flash_attn_split_planes(const void* q_hi, const void* k_hi, const void* v_hi, void* ctx3, int64_t bs, int64_t qk_lo, int64_t v_lo, int B, int H, int nv, int np, unsigned*, hipStream_t, int mx_out) {
+hipError_t launch_flash_attn_split_planes(const void* q_hi, const void* k_hi, const void* v_hi, void* ctx3, int64_t bs, int64_t qk_lo, int64_t v_lo, int B, int H, int nv, int np, unsigned*, hipStream_t, int mx_out, int) {
     const size_t head = (size_t)np * 64;
     for (int plane = 0; plane < 2; ++plane) {
         rd((const char*)q_hi + (size_t)plane * qk_lo * 2, ((size_t)(B - 1) * bs + H * head) * 2, "split attention q plane");
