@@ -636,7 +636,7 @@ def main():
             res["per_request"] = request_leg(sd, cfg, device)
             # north_star's tolerance (1e-3 on logits and maps) is met by the fp32 mode only: its throughput on the SAME shape,
             # stated next to `value` (which is BASELINE configs[1]'s own dtype, bf16)
-            res["value_1e3_mode"] = {"images_per_s": res["other_configs"][3]["images_per_s"], "dtype": "f32 (hi/lo-split f16 MFMAs, fp32 accumulate)",
+            res["value_1e3_mode"] = {"images_per_s": res["other_configs"][3]["images_per_s"], "dtype": "f32 (operands as f16 hi planes + correction planes: block-scaled e4m3 MFMAs for the GEMMs' and the attention's P V correction terms, f16 lo planes for the scores; fp32 accumulate)",
                                      "error_vs_reference": "not measured by this run: tests/test_gpu_model.py gates this mode at <= 1e-3 on every reference golden "
                                                            "(FP32_TOL); last recorded maxima in profiles/r02/fp32_split_accuracy.log"}
         if world == 1 and not args.no_cpu_baseline:

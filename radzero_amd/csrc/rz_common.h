@@ -128,6 +128,16 @@ __device__ __forceinline__ void split4_mx(const f32x4& v, f16x4& hi, uint32_t& l
     lo8 = cvt4_e4m3(clamp448((v[0] - (float)hi[0]) * il), clamp448((v[1] - (float)hi[1]) * il), clamp448((v[2] - (float)hi[2]) * il), clamp448((v[3] - (float)hi[3]) * il));
     hi8 = cvt4_e4m3(clamp448(v[0] * ih), clamp448(v[1] * ih), clamp448(v[2] * ih), clamp448(v[3] * ih));
 }
+// the two e4m3 words alone (hi = f16(v) already known, range already flagged): the second pass of the staged epilogues
+__device__ __forceinline__ void pair4_mx(const f32x4& v, const f16x4& hi, uint32_t& lo8, uint32_t& hi8, float inv_hi, float inv_lo) {
+    lo8 = cvt4_e4m3(clamp448((v[0] - (float)hi[0]) * inv_lo), clamp448((v[1] - (float)hi[1]) * inv_lo), clamp448((v[2] - (float)hi[2]) * inv_lo), clamp448((v[3] - (float)hi[3]) * inv_lo));
+    hi8 = cvt4_e4m3(clamp448(v[0] * inv_hi), clamp448(v[1] * inv_hi), clamp448(v[2] * inv_hi), clamp448(v[3] * inv_hi));
+}
+__device__ __forceinline__ void flag_mx_range(const f32x4& v, float hi_scale, unsigned* flag) {
+    const unsigned a = max(max(__float_as_uint(v[0]) & 0x7fffffffu, __float_as_uint(v[1]) & 0x7fffffffu),
+                           max(__float_as_uint(v[2]) & 0x7fffffffu, __float_as_uint(v[3]) & 0x7fffffffu));
+    if (a > __float_as_uint(fminf(448.f * hi_scale, 65504.f)) && flag) atomicOr(flag, 1u);
+}
 // byte offsets inside an MX operand row of K elements (row = 4 K bytes): element k
 __device__ __forceinline__ int64_t mx_pair_off(int K, int k) { return (int64_t)2 * K + (k >> 6) * 128 + (k & 63); }      // first byte plane of its 64-group; second = + 64
 typedef int i32x4 __attribute__((ext_vector_type(4)));
