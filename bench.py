@@ -35,7 +35,7 @@ DTYPES = {"bf16": torch.bfloat16, "f16": torch.float16, "f32": torch.float32}
 def pmc_traffic(kernel, batch, side, dtype):
     """HBM bytes per launch of `kernel` from the committed PMC passes (a separate rocprofv3 --pmc run cannot happen inside
     this process); null unless the passes were taken on exactly this workload."""
-    for rnd in ("r03", "r02", "r01"):
+    for rnd in ("r04", "r03", "r02", "r01"):
         try:
             rec = json.load(open(os.path.join(ROOT, "profiles", rnd, "hbm_traffic_pmc.json")))
             c = rec["config"]
@@ -123,7 +123,7 @@ def cpu_baseline(cfg, sd, side, n_prompts, ids, mask):
         try:
             torch.set_num_threads(all_cpus)
             om = OracleModel(sd, cfg, attn_impl=best)
-            nimg = 4
+            nimg = 1
             px = torch.from_numpy(synthetic_pixels(nimg, side, 1234))
             with torch.no_grad():
                 tf = om.text_features(enc, split_rows=False)
@@ -131,7 +131,7 @@ def cpu_baseline(cfg, sd, side, n_prompts, ids, mask):
                 t0 = time.time()
                 om.compute_logits(px, [enc], text_features=tf)
                 dt_all = time.time() - t0
-            all_note = f"; ALL {all_cpus} logical CPUs of the host, {best}: {nimg / dt_all:.4f} images/s (one pass of {nimg} images, {dt_all:.1f} s)"
+            all_note = f"; ALL {all_cpus} logical CPUs of the host, {best}: {nimg / dt_all:.4f} images/s (one pass of {nimg} image, {dt_all:.1f} s)"
         except Exception as e:           # never lose the bench line to the optional leg
             all_note = f"; all-{all_cpus}-CPU pass failed: {type(e).__name__}"
         finally:
