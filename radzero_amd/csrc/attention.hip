@@ -896,25 +896,38 @@ __global__ __launch_bounds__(256, 2) void flash_attn_split_kernel(const f16_t* _
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) voff[kk] = l15 * 128 + (((kk * 4 + lg) ^ sw) << 4);
 
+    // staging: a wave's 8 loads per tile as (uniform 64-bit base of the tile) + (32-bit lane offset, fixed for the whole kernel): the saddr form of
+    // global_load_lds, no per-tile 64-bit vector address arithmetic
+    uint32_t kofs[2], vofs[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int r = (wave * 2 + i) * 8 + (lane >> 3);
+        kofs[i] = (uint32_t)(r * 128 + (((lane & 7) ^ swz_k(r)) << 4));
+        vofs[i] = (uint32_t)(r * (int)v_ld + (((lane & 7) ^ swz_std(r)) << 4));
+    }
     auto stage = [&](int t, int buf) {
         char* sk = lds + buf * 2 * TILE;
         char* sv = lds + 4 * TILE + buf * 2 * TILE;
-        const int key0 = t * FA_KEYS;
+        const char* kt = kbase + (int64_t)t * (FA_KEYS * k_ld);
+        const char* vt = vbase + (int64_t)t * (FA_KEYS * ES);
 #pragma unroll
         for (int pl = 0; pl < 2; ++pl)
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
                 const int row8 = (wave * 2 + i) * 8;
-                glds_rows8<1>(sk + pl * TILE + row8 * 128, kbase + pl * k_lo_b + (int64_t)key0 * k_ld, k_ld, row8, lane);
-                glds_rows8(sv + pl * TILE + row8 * 128, vbase + pl * v_lo_b + (int64_t)key0 * ES, v_ld, row8, lane);
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(kt + pl * k_lo_b + kofs[i]),
+                                                 (__attribute__((address_space(3))) void*)(sk + pl * TILE + row8 * 128), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(vt + pl * v_lo_b + vofs[i]),
+                                                 (__attribute__((address_space(3))) void*)(sv + pl * TILE + row8 * 128), 16, 0, 0);
             }
     };
 
     f32x4 oacc[2][4], cinit[2];
-    float mrow[2], lrow[2];
+    float mrow[2];
+    f32x2 lrow2[2];                  // two lane-partial running sums per query row (packed adds)
 #pragma unroll
     for (int a = 0; a < 2; ++a) {
-        mrow[a] = 0.f; lrow[a] = 0.f;
+        mrow[a] = 0.f; lrow2[a] = (f32x2){0.f, 0.f};
         cinit[a] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int c = 0; c < 4; ++c) oacc[a][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -989,12 +1002,15 @@ __global__ __launch_bounds__(256, 2) void flash_attn_split_kernel(const f16_t* _
         }
         float mx[2];
 #pragma unroll
-        for (int qt = 0; qt < 2; ++qt) {
-            float m0 = fmaxf(fmaxf(sacc[qt][0][0], sacc[qt][0][1]), fmaxf(sacc[qt][0][2], sacc[qt][0][3]));
-#pragma unroll
-            for (int kt = 1; kt < 4; ++kt)
-                m0 = fmaxf(m0, fmaxf(fmaxf(sacc[qt][kt][0], sacc[qt][kt][1]), fmaxf(sacc[qt][kt][2], sacc[qt][kt][3])));
-            mx[qt] = m0;
+        for (int qt = 0; qt < 2; ++qt) {       // max(max(a, b), c) chains: v_max3_f32 (as flash_attn_workgroup)
+            float m0 = fmaxf(fmaxf(sacc[qt][0][0], sacc[qt][0][1]), sacc[qt][0][2]);
+            m0 = fmaxf(fmaxf(m0, sacc[qt][0][3]), sacc[qt][1][0]);
+            m0 = fmaxf(fmaxf(m0, sacc[qt][1][1]), sacc[qt][1][2]);
+            m0 = fmaxf(fmaxf(m0, sacc[qt][1][3]), sacc[qt][2][0]);
+            m0 = fmaxf(fmaxf(m0, sacc[qt][2][1]), sacc[qt][2][2]);
+            m0 = fmaxf(fmaxf(m0, sacc[qt][2][3]), sacc[qt][3][0]);
+            m0 = fmaxf(fmaxf(m0, sacc[qt][3][1]), sacc[qt][3][2]);
+            mx[qt] = fmaxf(m0, sacc[qt][3][3]);
         }
         auto row_max = [&](float m0) {
             m0 = fmaxf(m0, __shfl_xor(m0, 16, 64));
@@ -1017,7 +1033,7 @@ __global__ __launch_bounds__(256, 2) void flash_attn_split_kernel(const f16_t* _
                 const float alpha = __builtin_amdgcn_exp2f(-delta);
                 mrow[qt] += delta;
                 cinit[qt] -= delta;
-                lrow[qt] *= alpha;
+                lrow2[qt] *= alpha;
 #pragma unroll
                 for (int kt = 0; kt < 4; ++kt) sacc[qt][kt] -= delta;
 #pragma unroll
@@ -1026,26 +1042,30 @@ __global__ __launch_bounds__(256, 2) void flash_attn_split_kernel(const f16_t* _
             asm volatile("" ::: "memory");
         }
         // ---- P = 2^S' (fp32), row sums, split into planes ----
+        // VALU budget (the loop is bound by the SIMD's vector issue port, profiles/NOTEBOOK.md round 4): per 8 probabilities 8 v_exp_f32, 4 v_pk_add_f32
+        // (row sums, two lane-partial sums per row), 4 v_cvt_pk_f16_f32, 8 v_fma_mix_f32 (p - f16(p) straight from the packed halves: the -1 is kept
+        // opaque so that hipcc does not turn the fma back into convert + subtract) and, MXA, 4 + 4 fp8 converts, the 2^11 of the lo plane folded
+        // into v_cvt_scalef32_pk_fp8_f32's scale operand.
+        float m1 = -1.0f;
+        asm("" : "+s"(m1));
         frag_t ph[2][2], pl[2][2];       // MXA: pl[qt][0] = [p_lo8 of the lane's 16 keys], pl[qt][1] = [p_hi8 ...] (16 bytes each)
 #pragma unroll
         for (int qt = 0; qt < 2; ++qt) {
-            float psum = 0.f;
             uint32_t w8[2][4];           // MXA: [lo8 | hi8][kk * 2 + half]
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk) {
                 float pv[8], pr[8];
 #pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    pv[i] = __builtin_amdgcn_exp2f(sacc[qt][2 * kk + (i >> 2)][i & 3]);
-                    psum += pv[i];
-                }
+                for (int i = 0; i < 8; ++i) pv[i] = __builtin_amdgcn_exp2f(sacc[qt][2 * kk + (i >> 2)][i & 3]);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) lrow2[qt] += (f32x2){pv[2 * i], pv[2 * i + 1]};
                 ph[qt][kk] = pack8<f16_t>(pv[0], pv[1], pv[2], pv[3], pv[4], pv[5], pv[6], pv[7]);
 #pragma unroll
-                for (int i = 0; i < 8; ++i) pr[i] = pv[i] - (float)ph[qt][kk][i];
+                for (int i = 0; i < 8; ++i) pr[i] = __builtin_fmaf((float)ph[qt][kk][i], m1, pv[i]);
                 if constexpr (MXA) {
                     // P <= 2^8 (FA_DEFER): hi8 = e4m3(p) with scale 1, lo8 = e4m3((p - f16(p)) 2^11) with scale 2^-11: both within +-448
-                    w8[0][kk * 2 + 0] = cvt4_e4m3(pr[0] * 2048.f, pr[1] * 2048.f, pr[2] * 2048.f, pr[3] * 2048.f);
-                    w8[0][kk * 2 + 1] = cvt4_e4m3(pr[4] * 2048.f, pr[5] * 2048.f, pr[6] * 2048.f, pr[7] * 2048.f);
+                    w8[0][kk * 2 + 0] = cvt4_e4m3_scaled(pr[0], pr[1], pr[2], pr[3], MX_CVT_SCALE_2P11);
+                    w8[0][kk * 2 + 1] = cvt4_e4m3_scaled(pr[4], pr[5], pr[6], pr[7], MX_CVT_SCALE_2P11);
                     w8[1][kk * 2 + 0] = cvt4_e4m3(pv[0], pv[1], pv[2], pv[3]);
                     w8[1][kk * 2 + 1] = cvt4_e4m3(pv[4], pv[5], pv[6], pv[7]);
                 } else {
@@ -1056,7 +1076,6 @@ __global__ __launch_bounds__(256, 2) void flash_attn_split_kernel(const f16_t* _
                 pl[qt][0] = __builtin_bit_cast(frag_t, (u32x4){w8[0][0], w8[0][1], w8[0][2], w8[0][3]});
                 pl[qt][1] = __builtin_bit_cast(frag_t, (u32x4){w8[1][0], w8[1][1], w8[1][2], w8[1][3]});
             }
-            lrow[qt] += psum;
         }
         // ---- O^T += V^T P^T:  vh.ph + vh.pl + vl.ph ----
         if constexpr (MXA) {
@@ -1124,7 +1143,7 @@ __global__ __launch_bounds__(256, 2) void flash_attn_split_kernel(const f16_t* _
 
 #pragma unroll
     for (int qt = 0; qt < 2; ++qt) {
-        float l = lrow[qt];
+        float l = lrow2[qt][0] + lrow2[qt][1];
         l += __shfl_xor(l, 16, 64);
         l += __shfl_xor(l, 32, 64);
         const float inv = 1.0f / l;

@@ -116,6 +116,16 @@ __device__ __forceinline__ uint32_t cvt4_e4m3(float a, float b, float c, float d
     w = __builtin_amdgcn_cvt_pk_fp8_f32(c, d, w, true);
     return (uint32_t)w;
 }
+// the same with gfx950's scaled convert (v_cvt_scalef32_pk_fp8_f32): e4m3(x * 2^11) without the multiply — the instruction DIVIDES by the power of two
+// of its scale operand (tools/mb_fp8_cvt_scale.hip), rounds to nearest even and saturates
+constexpr float MX_CVT_SCALE_2P11 = 1.0f / 2048.0f;
+__device__ __forceinline__ uint32_t cvt4_e4m3_scaled(float a, float b, float c, float d, float scale) {
+    typedef short s16x2 __attribute__((ext_vector_type(2)));
+    s16x2 w = {0, 0};
+    w = __builtin_amdgcn_cvt_scalef32_pk_fp8_f32(w, a, b, scale, false);
+    w = __builtin_amdgcn_cvt_scalef32_pk_fp8_f32(w, c, d, scale, true);
+    return __builtin_bit_cast(uint32_t, w);
+}
 __device__ __forceinline__ float clamp448(float x) { return fminf(fmaxf(x, -448.f), 448.f); }
 // hi = f16(v); lo8 = e4m3((v - hi) / lo_scale); hi8 = e4m3(clamp(v / hi_scale)); flags |v| beyond the hi8 range (or the f16 range, or NaN)
 __device__ __forceinline__ void split4_mx(const f32x4& v, f16x4& hi, uint32_t& lo8, uint32_t& hi8, float hi_scale, float lo_scale, unsigned* flag) {
