@@ -915,9 +915,13 @@ __global__ __launch_bounds__(256, 2) void flash_attn_split_kernel(const f16_t* _
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
                 const int row8 = (wave * 2 + i) * 8;
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(kt + pl * k_lo_b + kofs[i]),
+                const char* kp = kt + pl * k_lo_b;           // scalar; opaque so that the plane offset is not folded into a 64-bit vector offset
+                const char* vp = vt + pl * v_lo_b;
+                asm("" : "+s"(kp));
+                asm("" : "+s"(vp));
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(kp + kofs[i]),
                                                  (__attribute__((address_space(3))) void*)(sk + pl * TILE + row8 * 128), 16, 0, 0);
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(vt + pl * v_lo_b + vofs[i]),
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(vp + vofs[i]),
                                                  (__attribute__((address_space(3))) void*)(sv + pl * TILE + row8 * 128), 16, 0, 0);
             }
     };

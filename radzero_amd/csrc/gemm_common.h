@@ -514,7 +514,7 @@ __device__ __forceinline__ void gemm_epilogue_tile_split(const GemmArgs& g, f32x
                     const f16x4 hi = pack4<f16_t>(v[0], v[1], v[2], v[3]);
                     if (FORM == 2 && pass == 1) {
                         uint32_t lo8, hi8;
-                        pair4_mx(v, hi, lo8, hi8, 1.0f / MX_A_HI_SCALE, 1.0f / MX_A_LO_SCALE);
+                        pair4_mx(v, hi, lo8, hi8, MX_A_HI_SCALE, MX_A_LO_SCALE);
                         int c_first, byte;            // 16-byte chunk (of the row's 32) and byte in it of the FIRST 4-byte piece; the second is 4 chunks on
                         bool hi_first;
                         if constexpr (SWAP) {         // q|k: the wave's 64 columns are one head = one 128-byte pair row
@@ -530,7 +530,7 @@ __device__ __forceinline__ void gemm_epilogue_tile_split(const GemmArgs& g, f32x
                     } else if (FORM == 1 && pass == 1) {
                         // pair plane: 4 bytes lo8 at byte 128 wc + 16 j + 4 lg of the row's 512, 4 bytes hi8 64 bytes further
                         uint32_t lo8, hi8;
-                        pair4_mx(v, hi, lo8, hi8, 1.0f / MX_A_HI_SCALE, 1.0f / MX_A_LO_SCALE);
+                        pair4_mx(v, hi, lo8, hi8, MX_A_HI_SCALE, MX_A_LO_SCALE);
                         const int cl = wc * 8 + j, ch = cl + 4;
                         *reinterpret_cast<uint32_t*>(lds + row * 512 + ((cl ^ (row & 15)) << 4) + 4 * lg) = lo8;
                         *reinterpret_cast<uint32_t*>(lds + row * 512 + ((ch ^ (row & 15)) << 4) + 4 * lg) = hi8;

@@ -92,7 +92,10 @@ __device__ __forceinline__ void flag_f16_range(const f32x4& v, unsigned* flag) {
 __device__ __forceinline__ void split4(const f32x4& v, f16x4& hi, f16x4& lo, unsigned* flag = nullptr) {
     flag_f16_range(v, flag);
     hi = pack4<f16_t>(v[0], v[1], v[2], v[3]);
-    lo = pack4<f16_t>(v[0] - (float)hi[0], v[1] - (float)hi[1], v[2] - (float)hi[2], v[3] - (float)hi[3]);
+    float m1 = -1.0f;                // opaque: v - f16(v) as one v_fma_mix_f32 on the packed half (hipcc would split it into convert + subtract)
+    asm("" : "+s"(m1));
+    lo = pack4<f16_t>(__builtin_fmaf((float)hi[0], m1, v[0]), __builtin_fmaf((float)hi[1], m1, v[1]), __builtin_fmaf((float)hi[2], m1, v[2]),
+                      __builtin_fmaf((float)hi[3], m1, v[3]));
 }
 
 // ---- fp32 mode, MX form (round 4): a product a b = a_hi b_hi + (a_lo b_hi + a_hi b_lo); the two correction terms sit 2^-11 below the main
@@ -111,22 +114,27 @@ constexpr float MX_A_HI_SCALE = 4.0f, MX_A_LO_SCALE = 4.0f / 2048.0f;          /
 constexpr float MX_W_HI_SCALE = 1.0f / 16.0f, MX_W_LO_SCALE = 1.0f / 32768.0f; // weights: hi8 covers |w| <= 28
 constexpr int MX_E8_A_HI = 129, MX_E8_A_LO = 118, MX_E8_W_HI = 123, MX_E8_W_LO = 112;      // E8M0 = 127 + log2(scale)
 __device__ __forceinline__ uint32_t cvt4_e4m3(float a, float b, float c, float d) {
-    int w = 0;
+    int w = __builtin_bit_cast(int, a);          // "old" word of the first (tied) convert: a value that dies here, not a fresh zero (a v_mov per word)
     w = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, w, false);
     w = __builtin_amdgcn_cvt_pk_fp8_f32(c, d, w, true);
     return (uint32_t)w;
 }
-// the same with gfx950's scaled convert (v_cvt_scalef32_pk_fp8_f32): e4m3(x * 2^11) without the multiply — the instruction DIVIDES by the power of two
-// of its scale operand (tools/mb_fp8_cvt_scale.hip), rounds to nearest even and saturates
+// the same through gfx950's scaled convert: v_cvt_scalef32_pk_fp8_f32 DIVIDES by the power of two of its scale operand (the mantissa is ignored),
+// rounds to nearest even, and gives NaN beyond +-448 like the plain convert (tools/mb_fp8_cvt_scale.hip) — e4m3(x / scale) without the multiply
 constexpr float MX_CVT_SCALE_2P11 = 1.0f / 2048.0f;
 __device__ __forceinline__ uint32_t cvt4_e4m3_scaled(float a, float b, float c, float d, float scale) {
     typedef short s16x2 __attribute__((ext_vector_type(2)));
-    s16x2 w = {0, 0};
+    s16x2 w = __builtin_bit_cast(s16x2, a);      // "old" word of the first (tied) convert: a value that dies here, not a fresh zero
     w = __builtin_amdgcn_cvt_scalef32_pk_fp8_f32(w, a, b, scale, false);
     w = __builtin_amdgcn_cvt_scalef32_pk_fp8_f32(w, c, d, scale, true);
     return __builtin_bit_cast(uint32_t, w);
 }
+// x - f16(x) from the packed half itself: one v_fma_mix_f32 (the -1 is kept opaque, or hipcc turns the fma back into convert + subtract)
+__device__ __forceinline__ float opaque_minus_one() { float m = -1.0f; asm("" : "+s"(m)); return m; }
+__device__ __forceinline__ float minus_f16(float x, f16_t h, float m1) { return __builtin_fmaf((float)h, m1, x); }
+__device__ __forceinline__ float clamp_abs(float x, float lim) { return fminf(fmaxf(x, -lim), lim); }
 __device__ __forceinline__ float clamp448(float x) { return fminf(fmaxf(x, -448.f), 448.f); }
+__device__ __forceinline__ void pair4_mx(const f32x4& v, const f16x4& hi, uint32_t& lo8, uint32_t& hi8, float hi_scale, float lo_scale);
 // hi = f16(v); lo8 = e4m3((v - hi) / lo_scale); hi8 = e4m3(clamp(v / hi_scale)); flags |v| beyond the hi8 range (or the f16 range, or NaN)
 __device__ __forceinline__ void split4_mx(const f32x4& v, f16x4& hi, uint32_t& lo8, uint32_t& hi8, float hi_scale, float lo_scale, unsigned* flag) {
     const float lim = 448.f * hi_scale;
@@ -134,14 +142,16 @@ __device__ __forceinline__ void split4_mx(const f32x4& v, f16x4& hi, uint32_t& l
                            max(__float_as_uint(v[2]) & 0x7fffffffu, __float_as_uint(v[3]) & 0x7fffffffu));
     if (a > __float_as_uint(fminf(lim, 65504.f)) && flag) atomicOr(flag, 1u);
     hi = pack4<f16_t>(v[0], v[1], v[2], v[3]);
-    const float il = 1.0f / lo_scale, ih = 1.0f / hi_scale;
-    lo8 = cvt4_e4m3(clamp448((v[0] - (float)hi[0]) * il), clamp448((v[1] - (float)hi[1]) * il), clamp448((v[2] - (float)hi[2]) * il), clamp448((v[3] - (float)hi[3]) * il));
-    hi8 = cvt4_e4m3(clamp448(v[0] * ih), clamp448(v[1] * ih), clamp448(v[2] * ih), clamp448(v[3] * ih));
+    pair4_mx(v, hi, lo8, hi8, hi_scale, lo_scale);
 }
-// the two e4m3 words alone (hi = f16(v) already known, range already flagged): the second pass of the staged epilogues
-__device__ __forceinline__ void pair4_mx(const f32x4& v, const f16x4& hi, uint32_t& lo8, uint32_t& hi8, float inv_hi, float inv_lo) {
-    lo8 = cvt4_e4m3(clamp448((v[0] - (float)hi[0]) * inv_lo), clamp448((v[1] - (float)hi[1]) * inv_lo), clamp448((v[2] - (float)hi[2]) * inv_lo), clamp448((v[3] - (float)hi[3]) * inv_lo));
-    hi8 = cvt4_e4m3(clamp448(v[0] * inv_hi), clamp448(v[1] * inv_hi), clamp448(v[2] * inv_hi), clamp448(v[3] * inv_hi));
+// the two e4m3 words alone (hi = f16(v) already known, range already flagged): 3 + 2 vector instructions per value (fma_mix, clamp, half a scaled
+// convert; clamp, half a scaled convert)
+__device__ __forceinline__ void pair4_mx(const f32x4& v, const f16x4& hi, uint32_t& lo8, uint32_t& hi8, float hi_scale, float lo_scale) {
+    const float m1 = opaque_minus_one();
+    const float ll = 448.f * lo_scale, lh = 448.f * hi_scale;
+    lo8 = cvt4_e4m3_scaled(clamp_abs(minus_f16(v[0], hi[0], m1), ll), clamp_abs(minus_f16(v[1], hi[1], m1), ll), clamp_abs(minus_f16(v[2], hi[2], m1), ll),
+                           clamp_abs(minus_f16(v[3], hi[3], m1), ll), lo_scale);
+    hi8 = cvt4_e4m3_scaled(clamp_abs(v[0], lh), clamp_abs(v[1], lh), clamp_abs(v[2], lh), clamp_abs(v[3], lh), hi_scale);
 }
 __device__ __forceinline__ void flag_mx_range(const f32x4& v, float hi_scale, unsigned* flag) {
     const unsigned a = max(max(__float_as_uint(v[0]) & 0x7fffffffu, __float_as_uint(v[1]) & 0x7fffffffu),
