@@ -906,15 +906,34 @@ static int vision_forward_once(rz_handle_t m, const float* px, int B, int C, int
             ProfScope ps(m, RZ_PROF_ROWOPS, s);
             RZ_HIP(launch_im2col(m->dt, pxc, mid, Bc, C, Himg, Wimg, P, gh, gw, np, m->KPAD, s));
         }
-        if ((rc = gemm(m, EPI_PATCH, mid, m->KPAD, m->patch_w.p, m->KPAD, M, D, m->KPAD, nullptr, h, D,
-                       (const float*)it->second.buf.p, nullptr, 0, np, 0, s, A_F32, false, 0, mx))) return rc;
-
         const int nblocks = (int)m->blocks.size();
         // LayerNorm fused into the GEMMs either side of it (gemm8.hip): every block of this chunk or none
         const bool fused = m->o_ln_fused() && nblocks > 0 && gemm_ln_fused_ok(m->dt, M, D, F, m->o_gemm_variant());
         float* part = fused ? (float*)m->lnpart.p + row0 * 24 : nullptr;
         float* stat = fused ? (float*)m->lnstat.p + row0 * 2 : nullptr;
         float* lnmu = fused ? (float*)m->lnmu.p + row0 : nullptr;
+        // block 0's LayerNorm inputs (T copy of the embeddings times its gain, row statistics) straight from the patch GEMM's epilogue where the
+        // persistent kernel runs it; otherwise the ln_prepare row kernel below
+        bool patch_ln = false;
+        if (fused && m->cfg.vit_layers > 0) {
+            GemmArgs g;
+            g.A = mid; g.lda = m->KPAD; g.W = m->patch_w.p; g.ldw = m->KPAD; g.M = M; g.N = D; g.K = m->KPAD; g.bias = nullptr; g.out = h; g.ldo = D;
+            g.scale = (const float*)it->second.buf.p; g.resid = nullptr; g.ldr = 0; g.rows_per_image = np; g.heads_total = 0;
+            g.ln_part = part; g.ln_hb = xn; g.ln_gamma = (const float*)m->blocks[0].ln1_g.p;
+            g.variant = m->o_gemm_variant(); g.raster = m->o_gemm_raster();
+            if (gemm_patch_ln_ok(m->dt, g)) {
+                patch_ln = true;
+                {
+                    ProfScope ps(m, RZ_PROF_GEMM, s);
+                    RZ_HIP(launch_gemm(m->dt, EPI_PATCH_LN, g, s));
+                }
+                ProfScope ps(m, RZ_PROF_ROWOPS, s);
+                RZ_HIP(hipMemsetAsync(lnmu, 0, (size_t)M * sizeof(float), s));          // the epilogue centred with 0
+                RZ_HIP(launch_ln_finalize(part, lnmu, stat, eps, M, s));
+            }
+        }
+        if (!patch_ln && (rc = gemm(m, EPI_PATCH, mid, m->KPAD, m->patch_w.p, m->KPAD, M, D, m->KPAD, nullptr, h, D,
+                                    (const float*)it->second.buf.p, nullptr, 0, np, 0, s, A_F32, false, 0, mx))) return rc;
         if (fused) {
             for (auto& b : m->blocks)
                 if ((rc = fold_block(m, b))) return rc;
@@ -924,7 +943,7 @@ static int vision_forward_once(rz_handle_t m, const float* px, int B, int C, int
             ProfScope ps(m, RZ_PROF_ROWOPS, s);
             if (fused) RZ_HIP(launch_ln_prepare(m->dt, h, (const float*)m->vit_ln_g.p, (const float*)m->vit_ln_b.p, eps, h, (const float*)m->blocks[0].ln1_g.p, xn, lnmu, stat, eps, M, D, s));
             else RZ_HIP(launch_layernorm(m->dt, h, (const float*)m->vit_ln_g.p, (const float*)m->vit_ln_b.p, eps, nullptr, h, M, D, s));
-        } else if (fused) {                   // block 0 reads the patch-embedding output: copy + statistics by the row kernel
+        } else if (fused && !patch_ln) {      // block 0 reads the patch-embedding output: copy + statistics by the row kernel
             ProfScope ps(m, RZ_PROF_ROWOPS, s);
             RZ_HIP(launch_ln_prepare(m->dt, h, nullptr, nullptr, 0.f, nullptr, (const float*)m->blocks[0].ln1_g.p, xn, lnmu, stat, eps, M, D, s));
         }

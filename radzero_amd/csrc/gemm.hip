@@ -226,6 +226,12 @@ bool gemm_qkv_fused_ok(int dtype, const GemmArgs& g) {
     return (g.variant == 0 || persistent_variant(g.variant)) && gemm_v8_ok(dtype, EPI_QKV, g) && (g.variant != 0 || big_tiles_pay(g));
 }
 
+// EPI_PATCH_LN: the persistent kernel or the 128x128 kernel (bit-identical arithmetic, as for the other fused-LayerNorm epilogues)
+bool gemm_patch_ln_ok(int dtype, const GemmArgs& g) {
+    return dtype != DT_F32 && (g.variant == 0 || g.variant == 1 || persistent_variant(g.variant)) && g.M > 0 && g.M % BM == 0 && g.N == 768 && g.K % 64 == 0 &&
+           g.ln_part && g.ln_hb && g.ln_gamma && g.scale && g.out && g.rows_per_image > 0;
+}
+
 // May a Dinov2 block run with its LayerNorms fused into the GEMMs (EPI_*_LN)?  Every 16-bit shape does: the persistent kernel
 // takes the large ones, the 128x128 kernel the rest, with bit-identical arithmetic (gemm_common.h::gemm_epilogue_ln).
 bool gemm_ln_fused_ok(int dtype, int M, int D, int F, int variant) {
@@ -296,6 +302,7 @@ static hipError_t launch_gemm_t(int epi, const GemmArgs& g, hipStream_t s) {
         RZ_CASE1(EPI_GELU_LN)
         RZ_CASE1(EPI_HEADS_LN)
         RZ_CASE1(EPI_VT_LN)
+        RZ_CASE1(EPI_PATCH_LN)
         default: return hipErrorInvalidValue;
     }
 #undef RZ_CASE

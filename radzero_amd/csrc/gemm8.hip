@@ -349,6 +349,7 @@ static hipError_t launch_v8_t(int epi, const GemmArgs& g_in, hipStream_t s) {
         RZ_CASE8(EPI_RESID_SCALE_LN)
         RZ_CASE8(EPI_QKV_LN)
         RZ_CASE8(EPI_GELU_LN)
+        RZ_CASE8(EPI_PATCH_LN)
         default: return hipErrorInvalidValue;
     }
 #undef RZ_CASE8
@@ -363,6 +364,7 @@ bool gemm_v8_ok(int dtype, int epi, const GemmArgs& g) {
     if ((epi == EPI_QKV || epi == EPI_QKV_LN) && (g.split_n % V8_BN || g.split_n <= 0 || g.split_n >= g.N || !g.out2)) return false;
     if ((epi == EPI_QKV_LN || epi == EPI_GELU_LN) && (!g.ln_stat || !g.scale || !g.bias)) return false;
     if (epi == EPI_RESID_SCALE_LN && (g.N != 768 || !g.ln_part || !g.ln_hb || !g.ln_gamma || !g.ln_mu || !g.scale || !g.resid)) return false;
+    if (epi == EPI_PATCH_LN && (g.N != 768 || !g.ln_part || !g.ln_hb || !g.ln_gamma || !g.scale || !g.out || g.rows_per_image <= 0)) return false;
     return true;
 }
 

@@ -114,7 +114,9 @@ __device__ __forceinline__ void v8_epilogue16(const GemmArgs& g, void* out, int 
 // EPI_RESID_SCALE_LN: resid += scale * (acc + bias) as gemm_epilogue_rmw does it, plus what the next LayerNorm needs of
 // the new residual v: its copy in T (staged through the wave's LDS region like the 16-bit epilogue) and, per output row,
 // (mean, M2) of this wave's 64 columns -> ln_part[m][3 * (n0 / 256) ... ], slice index = column / 64.
-template <typename T>
+// PATCH (EPI_PATCH_LN): the same for the patch embedding: v = acc + table[token][n] (g.scale = table [rows_per_image][N]) -> g.out (fp32), centring
+// constant 0 (there is no earlier mean; |mean| << sigma is this path's standing assumption), no bias / LayerScale.
+template <typename T, bool PATCH = false>
 __device__ __forceinline__ void v8_epilogue_resid_ln(const GemmArgs& g, const f32x4 (&acc)[2][4][4], char* wl, int mw, int nw, int lane) {
     typedef typename Traits<T>::vec4 vec4_t;
     typedef typename Traits<T>::frag frag_t;
@@ -125,7 +127,7 @@ __device__ __forceinline__ void v8_epilogue_resid_ln(const GemmArgs& g, const f3
     float* vec = reinterpret_cast<float*>(wl + 2048);                 // [0,64) bias  [64,128) scale  [128,192) gamma
     if (lane < 48) {
         const int which = lane >> 4, c4 = (lane & 15) * 4;
-        const float* src = which == 0 ? g.bias : which == 1 ? g.scale : g.ln_gamma;
+        const float* src = which == 0 ? g.bias : which == 1 ? (PATCH ? nullptr : g.scale) : g.ln_gamma;
         const f32x4 v = src ? *reinterpret_cast<const f32x4*>(src + nw + c4) : (f32x4){0.f, 0.f, 0.f, 0.f};
         *reinterpret_cast<f32x4*>(vec + which * 64 + c4) = v;
     }
@@ -145,10 +147,11 @@ __device__ __forceinline__ void v8_epilogue_resid_ln(const GemmArgs& g, const f3
 #pragma unroll
         for (int ii = 0; ii < 2; ++ii) {
             const int m = mw + a * 64 + (ih * 2 + ii) * 16 + l15;
-            const float* src = g.resid + (int64_t)m * g.ldr + nw + 4 * lg;
+            const float* src = PATCH ? g.scale + (int64_t)(m % g.rows_per_image) * g.N + nw + 4 * lg : g.resid + (int64_t)m * g.ldr + nw + 4 * lg;
 #pragma unroll
             for (int j = 0; j < 4; ++j) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(hv[ii][j]) : "v"(src + j * 16) : "memory");
-            asm volatile("global_load_dword %0, %1, off" : "=v"(cm[ii]) : "v"(g.ln_mu + m) : "memory");
+            if constexpr (PATCH) cm[ii] = 0.f;
+            else asm volatile("global_load_dword %0, %1, off" : "=v"(cm[ii]) : "v"(g.ln_mu + m) : "memory");
         }
     };
     request(0, hvb[0], cmb[0]);
@@ -159,9 +162,16 @@ __device__ __forceinline__ void v8_epilogue_resid_ln(const GemmArgs& g, const f3
         float (&cmv)[2] = cmb[grp & 1];
         float* dst[2];
 #pragma unroll
-        for (int ii = 0; ii < 2; ++ii) dst[ii] = g.resid + (int64_t)(mw + a * 64 + (ih * 2 + ii) * 16 + l15) * g.ldr + nw + 4 * lg;
+        for (int ii = 0; ii < 2; ++ii) {
+            const int64_t mrow = mw + a * 64 + (ih * 2 + ii) * 16 + l15;
+            dst[ii] = (PATCH ? reinterpret_cast<float*>(g.out) + mrow * g.ldo : g.resid + mrow * g.ldr) + nw + 4 * lg;
+        }
         if (grp < 3) {
             request(grp + 1, hvb[(grp + 1) & 1], cmb[(grp + 1) & 1]);
+            if constexpr (PATCH)             // 8 loads per batch (no centring constants)
+                asm volatile("s_waitcnt vmcnt(8)"
+                             : "+v"(hv[0][0]), "+v"(hv[0][1]), "+v"(hv[0][2]), "+v"(hv[0][3]), "+v"(hv[1][0]), "+v"(hv[1][1]), "+v"(hv[1][2]), "+v"(hv[1][3]) :: "memory");
+            else
             asm volatile("s_waitcnt vmcnt(10)"
                          : "+v"(hv[0][0]), "+v"(hv[0][1]), "+v"(hv[0][2]), "+v"(hv[0][3]), "+v"(hv[1][0]), "+v"(hv[1][1]), "+v"(hv[1][2]), "+v"(hv[1][3]),
                            "+v"(cmv[0]), "+v"(cmv[1]) :: "memory");
@@ -178,7 +188,8 @@ __device__ __forceinline__ void v8_epilogue_resid_ln(const GemmArgs& g, const f3
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const f32x4 b4 = *reinterpret_cast<const f32x4*>(vec + j * 16 + 4 * lg), s4 = *reinterpret_cast<const f32x4*>(vec + 64 + j * 16 + 4 * lg);
-                hv[ii][j] = hv[ii][j] + s4 * (acc[a][i][j] + b4);                 // the new residual
+                if constexpr (PATCH) hv[ii][j] = hv[ii][j] + acc[a][i][j];        // table + patch projection
+                else hv[ii][j] = hv[ii][j] + s4 * (acc[a][i][j] + b4);            // the new residual
                 *reinterpret_cast<f32x4*>(dst[ii] + j * 16) = hv[ii][j];
                 sum += (hv[ii][j][0] + hv[ii][j][1]) + (hv[ii][j][2] + hv[ii][j][3]);
             }
@@ -232,7 +243,7 @@ __device__ __forceinline__ void v8_prefetch_ln(const GemmArgs& g, char* wl, int 
 
 template <int EPI> struct V8Epi {
     // 16-byte stores a wave issues LAST in this epilogue (nothing but stores after them), halved: see header
-    static constexpr int kExtra = (EPI == EPI_RESID_SCALE || EPI == EPI_RESID_SCALE_LN || EPI == EPI_RESID_ADD || EPI == EPI_PATCH || EPI == EPI_STORE_F32) ? 16 : 8;
+    static constexpr int kExtra = (EPI == EPI_RESID_SCALE || EPI == EPI_RESID_SCALE_LN || EPI == EPI_PATCH_LN || EPI == EPI_RESID_ADD || EPI == EPI_PATCH || EPI == EPI_STORE_F32) ? 16 : 8;
 };
 
 template <typename T, int EPI, bool SWAP>
@@ -246,6 +257,8 @@ __device__ __forceinline__ void v8_epilogue(const GemmArgs& g, const f32x4 (&acc
         v8_epilogue16<T, EPI_GELU, true>(g, g.out, g.heads_total, 0, acc, wl, mw, nw, lane);
     } else if constexpr (EPI == EPI_RESID_SCALE_LN) {
         v8_epilogue_resid_ln<T>(g, acc, wl, mw, nw, lane);
+    } else if constexpr (EPI == EPI_PATCH_LN) {
+        v8_epilogue_resid_ln<T, true>(g, acc, wl, mw, nw, lane);
     } else if constexpr (EPI == EPI_STORE || EPI == EPI_GELU || EPI == EPI_HEADS || EPI == EPI_VT) {
         v8_epilogue16<T, EPI>(g, g.out, g.heads_total, 0, acc, wl, mw, nw, lane);
     } else {

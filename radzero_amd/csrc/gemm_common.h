@@ -81,13 +81,14 @@ __device__ __forceinline__ void gemm_epilogue_rmw(const GemmArgs& g, const f32x4
 template <typename T, int EPI>
 __device__ __forceinline__ void gemm_epilogue_ln(const GemmArgs& g, const f32x4 (&acc)[4][4], int mw, int nw, int l15, int lg) {
     typedef typename Traits<T>::vec4 vec4_t;
-    if constexpr (EPI == EPI_RESID_SCALE_LN) {
+    if constexpr (EPI == EPI_RESID_SCALE_LN || EPI == EPI_PATCH_LN) {
+        constexpr bool PATCH = (EPI == EPI_PATCH_LN);      // v = acc + table[token][n] -> g.out, centring constant 0 (v8_epilogue_resid_ln<T, true>)
         f32x4 b4[4], s4[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int n = nw + j * 16 + 4 * lg;
-            b4[j] = g.bias ? *reinterpret_cast<const f32x4*>(g.bias + n) : (f32x4){0.f, 0.f, 0.f, 0.f};
-            s4[j] = *reinterpret_cast<const f32x4*>(g.scale + n);
+            b4[j] = (!PATCH && g.bias) ? *reinterpret_cast<const f32x4*>(g.bias + n) : (f32x4){0.f, 0.f, 0.f, 0.f};
+            s4[j] = PATCH ? (f32x4){0.f, 0.f, 0.f, 0.f} : *reinterpret_cast<const f32x4*>(g.scale + n);
         }
         const int slice = nw >> 6;
 #pragma unroll
@@ -97,9 +98,16 @@ __device__ __forceinline__ void gemm_epilogue_ln(const GemmArgs& g, const f32x4 
 #pragma unroll
             for (int ii = 0; ii < 2; ++ii) {
                 const int m = mw + (ih * 2 + ii) * 16 + l15;
-                dst[ii] = g.resid + (int64_t)m * g.ldr + nw + 4 * lg;
+                const float* src;
+                if constexpr (PATCH) {
+                    src = g.scale + (int64_t)(m % g.rows_per_image) * g.N + nw + 4 * lg;
+                    dst[ii] = reinterpret_cast<float*>(g.out) + (int64_t)m * g.ldo + nw + 4 * lg;
+                } else {
+                    dst[ii] = g.resid + (int64_t)m * g.ldr + nw + 4 * lg;
+                    src = dst[ii];
+                }
 #pragma unroll
-                for (int j = 0; j < 4; ++j) hv[ii][j] = *reinterpret_cast<const f32x4*>(dst[ii] + j * 16);
+                for (int j = 0; j < 4; ++j) hv[ii][j] = *reinterpret_cast<const f32x4*>(src + j * 16);
             }
 #pragma unroll
             for (int ii = 0; ii < 2; ++ii) {
@@ -108,7 +116,8 @@ __device__ __forceinline__ void gemm_epilogue_ln(const GemmArgs& g, const f32x4 
                 float sum = 0.f;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    hv[ii][j] = hv[ii][j] + s4[j] * (acc[i][j] + b4[j]);
+                    if constexpr (PATCH) hv[ii][j] = hv[ii][j] + acc[i][j];
+                    else hv[ii][j] = hv[ii][j] + s4[j] * (acc[i][j] + b4[j]);
                     *reinterpret_cast<f32x4*>(dst[ii] + j * 16) = hv[ii][j];
                     sum += (hv[ii][j][0] + hv[ii][j][1]) + (hv[ii][j][2] + hv[ii][j][3]);
                 }
@@ -124,7 +133,7 @@ __device__ __forceinline__ void gemm_epilogue_ln(const GemmArgs& g, const f32x4 
                 m2 += __shfl_xor(m2, 16, 64);
                 m2 += __shfl_xor(m2, 32, 64);
                 if (lg == 0) *reinterpret_cast<f32x2*>(g.ln_part + ((int64_t)m * 12 + slice) * 2) = (f32x2){mean, m2};
-                const float cm = g.ln_mu[m];
+                const float cm = PATCH ? 0.f : g.ln_mu[m];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const f32x4 gv = (hv[ii][j] - cm) * *reinterpret_cast<const f32x4*>(g.ln_gamma + nw + j * 16 + 4 * lg);
@@ -184,7 +193,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, const f32x4 (&a
         gemm_epilogue_rmw<T, EPI>(g, acc, mw, nw, l15, lg);
         return;
     }
-    if constexpr (EPI == EPI_RESID_SCALE_LN || EPI == EPI_HEADS_LN || EPI == EPI_VT_LN || EPI == EPI_GELU_LN) {
+    if constexpr (EPI == EPI_RESID_SCALE_LN || EPI == EPI_PATCH_LN || EPI == EPI_HEADS_LN || EPI == EPI_VT_LN || EPI == EPI_GELU_LN) {
         gemm_epilogue_ln<T, EPI>(g, acc, mw, nw, l15, lg);
         return;
     }

@@ -21,6 +21,7 @@ enum Epilogue : int {
     EPI_GELU_LN = 11,         // EPI_GELU likewise
     EPI_HEADS_LN = 12,        // EPI_HEADS / EPI_VT likewise: the two halves of EPI_QKV_LN as separate launches of the 128x128 kernel
     EPI_VT_LN = 13,           //   (small batches, where the persistent 256x256 kernel would leave CUs idle)
+    EPI_PATCH_LN = 14,        // EPI_PATCH + the first LayerNorm's inputs as EPI_RESID_SCALE_LN writes them (centring constant 0; out = fp32 [M][N], ln_mu unused): gemm8.hip only
 };
 
 struct GemmArgs {
@@ -54,6 +55,7 @@ void gemm_v8_set_stamp_buffer(void* dev_u64);   // diagnostic build: non-null =>
 bool gemm_v7_ok(int dtype, const GemmArgs& g);
 bool gemm_v8_ok(int dtype, int epi, const GemmArgs& g);
 bool gemm_qkv_fused_ok(int dtype, const GemmArgs& g);
+bool gemm_patch_ln_ok(int dtype, const GemmArgs& g);                  // may the patch-embedding GEMM write block 0's LayerNorm inputs itself (EPI_PATCH_LN)
 bool gemm_ln_fused_ok(int dtype, int M, int D, int F, int variant);   // may a Dinov2 block of M token rows use the fused-LayerNorm epilogues
 // fp32 mode on the f16 matrix pipe: operands split into f16 planes along K (gemm.hip)
 hipError_t launch_gemm_split_f32out(int epi, const GemmArgs& g, hipStream_t s, bool split_out = false);
