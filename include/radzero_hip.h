@@ -204,6 +204,16 @@ int rz_text_attention(int dtype, const void* qkv_dev, const float* rel_bias_dev,
                       int n_prompts, int len, int heads, void* stream);
 /* masked mean pool (modeling.py:148-156): out[t] = sum_i h[t][i] mask[t][i] / max(sum_i mask[t][i], 1e-9); h_dev fp32 (n_prompts, len, dim) */
 int rz_masked_meanpool(const float* h_dev, const int64_t* attention_mask_dev, float* out_dev, int n_prompts, int len, int dim, void* stream);
+/* The alignment heads beside VL-CABS — compute_logits_type "cls_alignment" / "global_alignment" (modeling.py:330-353: `image_cls_token @
+ * key_features.T`, `image_features @ key_features.T`, einsum("ind,jd->ijn", image_patch_tokens, key_features[:, hidden:])) and the text
+ * projector's nn.Linear (modeling.py:70-73, :199-200) — as one strided fp32 product, fixed summation order:
+ *   out[(m / rows_per_group) * out_group_stride + (m % rows_per_group) * out_row_stride + n * out_col_stride] = sum_k a[m][k] b[n][k] (+ bias[n])
+ * a_dev fp32 (M rows, leading dimension lda), b_dev fp32 (N rows, ldb), bias_dev fp32 (N) or NULL; K, lda, ldb multiples of 4. */
+int rz_rows_dot(const float* a_dev, int64_t lda, const float* b_dev, int64_t ldb, const float* bias_dev, float* out_dev, int M, int N, int K,
+                int rows_per_group, int64_t out_group_stride, int64_t out_row_stride, int64_t out_col_stride, void* stream);
+/* image_features (modeling.py:113-117): F.normalize(cat([cls_token, patch_tokens.mean(dim=1)], dim=1), p=2, dim=1).  tokens_dev fp32, image b at
+ * row b * image_stride_rows, row 0 = cls, rows 1 .. n_tokens-1 = patches, `dim` columns (multiple of 64); out_dev fp32 (batch, 2 * dim). */
+int rz_image_features(const float* tokens_dev, int64_t image_stride_rows, int batch, int n_tokens, int dim, float* out_dev, void* stream);
 /* Dinov2PatchEmbeddings + cls token + position embeddings (TF:dinov2/modeling_dinov2.py:97-149) as im2col + GEMM with the table epilogue:
  * pixel_values_dev fp32 (batch, channels, height, width); weight_dev `dtype` (768, k_pad) = the conv kernel flattened (c, ky, kx) and zero
  * padded to k_pad = round_up(channels*patch*patch, 64); table_dev fp32 (n_pad, 768) = row 0: cls + pos[0], rows 1..grid_h*grid_w: conv

@@ -293,6 +293,8 @@ class OracleModel:
         tok = mpnet_forward(ids, mask, self.P, cfg.text_layers, cfg.num_attention_heads,
                             cfg.text_layer_norm_eps, self.attn_impl)
         feat = masked_mean_pool(tok, mask)
+        if "text_projector.weight" in self.P:                   # modeling.py:70-73, :199-200: nn.Linear(text_dim, 2 * hidden)
+            feat = feat @ self.P["text_projector.weight"].T + self.P["text_projector.bias"]
         return {"text_features_wo_l2_norm": feat, "text_features": l2_normalize(feat)}
 
     def text_features(self, encoded, split_rows=True):
@@ -308,6 +310,14 @@ class OracleModel:
     # modeling.py:278-328, compute_logits_type == "radzero"
     def compute_logits(self, pixel_values, encoded_key_phrases, text_features=None, **kwargs):
         P, cfg = self.P, self.cfg
+        kind = getattr(cfg, "compute_logits_type", "radzero")
+        if kind in ("cls_alignment", "global_alignment"):       # modeling.py:330-353: the groups' features concatenated, whole groups encoded at once
+            vo = self.forward_vision_model(pixel_values)
+            key = torch.cat([self.forward_text_model(kp)["text_features"] for kp in encoded_key_phrases], dim=0)
+            if kind == "cls_alignment":
+                return {"logits": vo["image_cls_token"] @ key.T}
+            sim = torch.einsum("ind,jd->ijn", vo["image_patch_tokens"], key[:, cfg.hidden_size:])
+            return {"logits": vo["image_features"] @ key.T, "similarity_scores": sim}
         vt = self.forward_vision_model(pixel_values)["vision_tokens"]
         if text_features is None:
             text_features = self.text_features(encoded_key_phrases[0])

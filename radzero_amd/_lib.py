@@ -149,6 +149,8 @@ SYMBOLS = {
     "rz_text_embed_ln": (_I, [_I, _P, _P, _P, _P, _P, _F, _P, _P, _I, _I, _I, _I, _I, _P]),
     "rz_text_attention": (_I, [_I, _P, _P, _P, _P, _I, _I, _I, _P]),
     "rz_masked_meanpool": (_I, [_P, _P, _P, _I, _I, _I, _P]),
+    "rz_rows_dot": (_I, [_P, _L, _P, _L, _P, _P, _I, _I, _I, _I, _L, _L, _L, _P]),
+    "rz_image_features": (_I, [_P, _L, _I, _I, _I, _P, _P]),
     "rz_patch_embed": (_I, [_I, _P, _I, _I, _I, _I, _I, _P, _I, _P, _I, _P, _P, _P]),
     "rz_set_option": (_I, [ctypes.c_char_p, _I]),
     "rz_set_model_option": (_I, [_P, ctypes.c_char_p, _I]),

@@ -169,8 +169,8 @@ def config_from_hf(path_or_dict, state_dict=None) -> RadZeroConfig:
     cfg = RadZeroConfig(**fields)
     if a.get("use_layer_norm"):
         raise NotImplementedError("align_transformer_config.use_layer_norm=True is not part of the released model")
-    if t.get("use_text_projection"):
-        raise NotImplementedError("text_config.use_text_projection=True is not part of the released model")
-    if (extra.get("compute_logits_type") or "radzero") != "radzero":
-        raise NotImplementedError("only compute_logits_type == 'radzero' is implemented")
+    cfg.use_text_projection = bool(t.get("use_text_projection"))
+    cfg.compute_logits_type = extra.get("compute_logits_type") or "radzero"
+    if cfg.compute_logits_type not in ("radzero", "cls_alignment", "global_alignment"):
+        raise NotImplementedError(f"compute_logits_type {cfg.compute_logits_type!r} (modeling.py:288-353 knows radzero / cls_alignment / global_alignment)")
     return cfg

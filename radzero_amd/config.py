@@ -41,6 +41,9 @@ class RadZeroConfig:
     use_vision_cls_token: bool = True
     sim_op: str = "cos"                     # "cos" (released radzero.yaml:44) | "dot" (RadZeroLoss's constructor default, losses.py:45, :214-215)
     attn_temperature: float | None = None   # losses.py:57-63: a separate temperature for the score softmax ("cos" only); None = the loss temperature
+    # --- which logits compute_logits returns (modeling.py:288 / :330 / :340; the released radzero.yaml:48 says "radzero") ---
+    compute_logits_type: str = "radzero"    # "radzero" (VL-CABS) | "cls_alignment" | "global_alignment"
+    use_text_projection: bool = False       # text_projector = nn.Linear(768, 2 * 768) (modeling.py:70-73): what "global_alignment" needs
 
     @property
     def head_dim(self) -> int:

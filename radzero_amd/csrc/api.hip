@@ -1386,6 +1386,21 @@ int rz_masked_meanpool(const float* h, const int64_t* mask, float* out, int T, i
     return 0;
 }
 
+int rz_rows_dot(const float* a, int64_t lda, const float* b, int64_t ldb, const float* bias, float* out, int M, int N, int K, int rows_per_group,
+                int64_t out_group_stride, int64_t out_row_stride, int64_t out_col_stride, void* stream) {
+    if (!a || !b || !out || M <= 0 || N <= 0 || K <= 0 || K % 4 || lda % 4 || ldb % 4 || lda < K || ldb < K || rows_per_group <= 0)
+        return fail(RZ_ERR_INVALID, "rz_rows_dot: bad argument (K and the leading dimensions must be multiples of 4)");
+    RZ_HIP(launch_rows_dot(a, lda, b, ldb, bias, out, M, N, K, rows_per_group, out_group_stride, out_row_stride, out_col_stride, (hipStream_t)stream));
+    return 0;
+}
+
+int rz_image_features(const float* tokens, int64_t image_stride_rows, int batch, int n_tokens, int dim, float* out, void* stream) {
+    if (!tokens || !out || batch <= 0 || n_tokens < 2 || dim <= 0 || dim % 64 || image_stride_rows < n_tokens)
+        return fail(RZ_ERR_INVALID, "rz_image_features: bad argument (dim must be a multiple of 64, n_tokens >= 2)");
+    RZ_HIP(launch_image_features(tokens, image_stride_rows, batch, n_tokens, dim, out, (hipStream_t)stream));
+    return 0;
+}
+
 int rz_patch_embed(int dtype, const float* px, int B, int C, int Himg, int Wimg, int P, const void* weight, int k_pad, const float* table,
                    int n_pad, void* ws, float* out, void* stream) {
     if (!px || !weight || !table || !ws || !out) return fail(RZ_ERR_INVALID, "rz_patch_embed: null argument");

@@ -395,6 +395,73 @@ hipError_t launch_masked_meanpool(const float* h, const int64_t* mask, float* ou
     return hipGetLastError();
 }
 
+// ---- the alignment heads beside VL-CABS (exp/cxr_pt/model/modeling.py:330-353, :115-117): small fp32 products on tensors the library already
+// holds.  Not a hot path (the released configuration computes "radzero" logits): plain wave-per-row kernels, no matrix pipe.
+// rows_dot: out[(m / rpg) * og + (m % rpg) * orow + n * ocol] = sum_k a[m][k] b[n][k] (+ bias[n]), K % 4 == 0, fixed summation order.
+__global__ __launch_bounds__(256) void rows_dot_kernel(const float* __restrict__ a, int64_t lda, const float* __restrict__ b, int64_t ldb,
+                                                       const float* __restrict__ bias, float* __restrict__ out, int M, int N, int K, int rpg,
+                                                       int64_t og, int64_t orow, int64_t ocol) {
+    const int lane = threadIdx.x & 63;
+    const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (m >= M) return;
+    const f32x4* a4 = reinterpret_cast<const f32x4*>(a + (int64_t)m * lda);
+    float* o = out + (int64_t)(m / rpg) * og + (int64_t)(m % rpg) * orow;
+    const int K4 = K >> 2;
+    for (int n = 0; n < N; ++n) {
+        const f32x4* b4 = reinterpret_cast<const f32x4*>(b + (int64_t)n * ldb);
+        float acc = 0.f;
+        for (int i = lane; i < K4; i += 64) {
+            const f32x4 x = a4[i], y = b4[i];
+            acc += (x[0] * y[0] + x[1] * y[1]) + (x[2] * y[2] + x[3] * y[3]);
+        }
+        acc = wave_sum(acc);
+        if (lane == 0) o[(int64_t)n * ocol] = acc + (bias ? bias[n] : 0.f);
+    }
+}
+
+hipError_t launch_rows_dot(const float* a, int64_t lda, const float* b, int64_t ldb, const float* bias, float* out, int M, int N, int K,
+                           int rows_per_group, int64_t out_group_stride, int64_t out_row_stride, int64_t out_col_stride, hipStream_t s) {
+    if (M <= 0 || N <= 0 || K <= 0 || K % 4 || lda % 4 || ldb % 4 || rows_per_group <= 0) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(rows_dot_kernel, dim3((M + 3) / 4), dim3(256), 0, s, a, lda, b, ldb, bias, out, M, N, K, rows_per_group, out_group_stride,
+                       out_row_stride, out_col_stride);
+    return hipGetLastError();
+}
+
+// image_features (modeling.py:115-117): l2norm([cls | mean over the patch tokens]) per image; tokens [B][image_stride rows of D], row 0 = cls,
+// rows 1..n_tokens-1 = patches.  Pass 1: column means of the patch rows (one workgroup per image and 64-column slab); pass 2: concatenate + normalise.
+__global__ __launch_bounds__(256) void patch_mean_kernel(const float* __restrict__ tokens, int64_t image_stride, int n_tokens, int D, float* __restrict__ feat) {
+    __shared__ float red[4][64];
+    const int b = blockIdx.y, c = blockIdx.x * 64 + (threadIdx.x & 63), rg = threadIdx.x >> 6;
+    const float* base = tokens + (int64_t)b * image_stride * D + c;
+    float acc = 0.f;
+    for (int r = 1 + rg; r < n_tokens; r += 4) acc += base[(int64_t)r * D];
+    red[rg][threadIdx.x & 63] = acc;
+    __syncthreads();
+    if (rg == 0) {
+        const float sum = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+        feat[(int64_t)b * 2 * D + D + c] = sum / (float)(n_tokens - 1);
+        feat[(int64_t)b * 2 * D + c] = tokens[(int64_t)b * image_stride * D + c];          // the cls token
+    }
+}
+__global__ __launch_bounds__(256) void l2norm_rows_kernel(float* __restrict__ x, int len) {
+    __shared__ float red[4];
+    float* row = x + (int64_t)blockIdx.x * len;
+    float q = 0.f;
+    for (int i = threadIdx.x; i < len; i += 256) q += row[i] * row[i];
+    q = wave_sum(q);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = q;
+    __syncthreads();
+    const float inv = 1.0f / fmaxf(sqrtf((red[0] + red[1]) + (red[2] + red[3])), 1e-12f);     // F.normalize: x / max(||x||, eps)
+    for (int i = threadIdx.x; i < len; i += 256) row[i] *= inv;
+}
+
+hipError_t launch_image_features(const float* tokens, int64_t image_stride, int B, int n_tokens, int D, float* out, hipStream_t s) {
+    if (B <= 0 || n_tokens < 2 || D <= 0 || D % 64 || image_stride < n_tokens) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(patch_mean_kernel, dim3(D / 64, B), dim3(256), 0, s, tokens, image_stride, n_tokens, D, out);
+    hipLaunchKernelGGL(l2norm_rows_kernel, dim3(B), dim3(256), 0, s, out, 2 * D);
+    return hipGetLastError();
+}
+
 // ---- compact copy of the valid tokens: [B][Npad][D] -> [B][N][D] ----
 __global__ __launch_bounds__(256) void copy_tokens_kernel(const float* __restrict__ src, float* __restrict__ dst, int n_valid,
                                                           int n_pad, int D4) {

@@ -101,6 +101,12 @@ hipError_t launch_ln_finalize(const float* part, float* mu_inout, float* stat, f
 hipError_t launch_ln_prepare(int dtype, const float* in, const float* gamma, const float* beta, float eps_in, float* out_f32,
                              const float* copy_gain, void* copy_t, float* mu_out, float* stat, float eps_stat, int64_t rows, int D, hipStream_t s);
 
+// Alignment heads beside VL-CABS (modeling.py:330-353, :115-117), fp32: out[(m / rpg) * og + (m % rpg) * orow + n * ocol] = a[m] . b[n] (+ bias[n]);
+// image_features = l2norm([cls | mean of the patch tokens]) -> out [B][2 D]
+hipError_t launch_rows_dot(const float* a, int64_t lda, const float* b, int64_t ldb, const float* bias, float* out, int M, int N, int K,
+                           int rows_per_group, int64_t out_group_stride, int64_t out_row_stride, int64_t out_col_stride, hipStream_t s);
+hipError_t launch_image_features(const float* tokens, int64_t image_stride, int B, int n_tokens, int D, float* out, hipStream_t s);
+
 // LayerNorm over rows of 768: fp32 in; writes T-typed normalized copy (out_t, may be null) and/or
 // fp32 (out_f32, may alias in).
 hipError_t launch_layernorm_split3(const float* in, const float* gamma, const float* beta, float eps, void* out3, int64_t rows, int D, unsigned* ovf_flag, hipStream_t s, int mx = 0);   // mx: the MX form (rz_common.h), 4 D bytes per row

@@ -109,6 +109,11 @@ class RadZeroModel:
         self.config = config or RadZeroConfig()
         if self.config.sim_op not in ("cos", "dot"):
             raise NotImplementedError(f"sim_op {self.config.sim_op!r}: SimilarityLogit knows 'cos' and 'dot' (losses.py:207-217)")
+        if self.config.compute_logits_type not in ("radzero", "cls_alignment", "global_alignment"):
+            raise NotImplementedError(f"compute_logits_type {self.config.compute_logits_type!r} (modeling.py:288-353)")
+        if self.config.use_text_projection and self.config.compute_logits_type == "radzero":
+            # the reference would hand 2 * hidden text features to a VL-CABS head built for hidden (modeling.py:70-73 vs losses.py:35-69)
+            raise NotImplementedError("use_text_projection with compute_logits_type 'radzero': the reference's head cannot take projected text features")
         self.dtype = torch_dtype
         if torch.device(device).type != "cuda":
             raise RuntimeError("RadZeroModel runs on an AMD GPU through libradzero_hip.so; there is no CPU path")
@@ -120,6 +125,7 @@ class RadZeroModel:
         self._state_dict = None
         self._pos_embed = None
         self._rel_weight = None
+        self._text_proj = None                    # (weight (2 D, D), bias (2 D)) fp32 on the device when config.use_text_projection
         self._grids = set()
         self._rel_bias_cache: Dict[int, torch.Tensor] = {}
         self._text_cache: Dict[bytes, torch.Tensor] = {}
@@ -190,6 +196,7 @@ class RadZeroModel:
     def load_state_dict(self, state_dict, strict: bool = True):
         """Accepts the reference checkpoint's names (numpy arrays or torch tensors, any float dtype)."""
         self._state_dict = state_dict
+        proj = {}
         with torch.cuda.device(self._device):
             for name, value in state_dict.items():
                 a = value.detach().float().cpu().numpy() if isinstance(value, torch.Tensor) else np.asarray(value, np.float32)
@@ -198,12 +205,21 @@ class RadZeroModel:
                     self._pos_embed = torch.from_numpy(a.copy())
                 elif name == "text_model.encoder.relative_attention_bias.weight":
                     self._rel_weight = torch.from_numpy(a.copy())
+                elif name in ("text_projector.weight", "text_projector.bias"):      # modeling.py:70-73: applied on the Python side of the C-ABI (rz_rows_dot)
+                    if not self.config.use_text_projection:
+                        raise KeyError(f"{name} in the checkpoint but config.use_text_projection is False")
+                    proj[name] = torch.from_numpy(a.copy()).to(self._device)
+                    continue
                 _lib.check(self._lib.rz_load_weight(self._h, name.encode(), a.ctypes.data_as(ctypes.c_void_p), a.size),
                            f"rz_load_weight({name})")
             if strict:
                 _lib.check(self._lib.rz_weights_ready(self._h), "rz_weights_ready")
                 if self._pos_embed is None or self._rel_weight is None:
                     raise _lib.RzError("checkpoint lacks position_embeddings / relative_attention_bias")
+                if self.config.use_text_projection and len(proj) != 2:
+                    raise _lib.RzError("config.use_text_projection but the checkpoint lacks text_projector.weight / .bias")
+        if proj:
+            self._text_proj = (proj["text_projector.weight"].contiguous(), proj["text_projector.bias"].contiguous())
         self._grids.clear()
         self._rel_bias_cache.clear()
         self._text_cache.clear()
@@ -292,7 +308,10 @@ class RadZeroModel:
         tokens, _ = self._vision(pixel_values, want_tokens=True)
         cls_token = tokens[:, 0]
         patch_tokens = tokens[:, 1:]
-        image_features = F.normalize(torch.cat([cls_token, patch_tokens.mean(dim=1)], dim=1), p=2, dim=1)
+        b, n, d = tokens.shape
+        with torch.cuda.device(self._device):
+            image_features = torch.empty((b, 2 * d), dtype=torch.float32, device=self._device)
+            _lib.check(self._lib.rz_image_features(_ptr(tokens), n, b, n, d, _ptr(image_features), self._stream()), "rz_image_features")
         return {"vision_tokens": tokens, "image_cls_token": cls_token, "image_patch_tokens": patch_tokens,
                 "image_features": image_features}
 
@@ -322,8 +341,27 @@ class RadZeroModel:
         if not torch.cuda.is_current_stream_capturing():
             lo, hi = torch.stack([ids.min(), ids.max()]).tolist()      # ONE device->host copy for both bounds
             self._check_ids(int(lo), int(hi))
-        feat = self._text_forward_raw(ids, mask)
+        feat = self._project_text(self._text_forward_raw(ids, mask))
         return {"text_features_wo_l2_norm": feat, "text_features": F.normalize(feat, p=2, dim=1)}
+
+    def _rows_dot(self, a: torch.Tensor, b: torch.Tensor, bias: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None,
+                  rows_per_group: int = 0, strides=None) -> torch.Tensor:
+        """out[m][n] = a[m] . b[n] (+ bias[n]) in fp32 through rz_rows_dot; `strides` = (group, row, column) strides of `out` for a transposed result."""
+        m, k = a.shape
+        nb = b.shape[0]
+        with torch.cuda.device(self._device):
+            if out is None:
+                out = torch.empty((m, nb), dtype=torch.float32, device=self._device)
+                rows_per_group, strides = m, (0, nb, 1)
+            _lib.check(self._lib.rz_rows_dot(_ptr(a), a.stride(0), _ptr(b), b.stride(0), _ptr(bias), _ptr(out), m, nb, k, rows_per_group,
+                                             strides[0], strides[1], strides[2], self._stream()), "rz_rows_dot")
+        return out
+
+    def _project_text(self, feat: torch.Tensor) -> torch.Tensor:
+        """text_projector (modeling.py:199-200) when the configuration has one."""
+        if self._text_proj is None:
+            return feat
+        return self._rows_dot(feat.contiguous(), self._text_proj[0], self._text_proj[1])
 
     def _cache_put(self, key: bytes, feat: torch.Tensor):
         self._text_cache[key] = feat
@@ -413,6 +451,8 @@ class RadZeroModel:
     def compute_logits(self, pixel_values, encoded_key_phrases, text_features: Optional[torch.Tensor] = None, **kwargs):
         """kwargs (encoded_negative_phrases, use_negative_logits, ...) are accepted and ignored, as in the
         reference (modeling.py:282).  `text_features` lets a data-parallel driver pass all-gathered embeddings."""
+        if self.config.compute_logits_type != "radzero":
+            return self._compute_alignment_logits(pixel_values, encoded_key_phrases)
         pending = None
         if text_features is None:
             enc = encoded_key_phrases[0]
@@ -445,6 +485,30 @@ class RadZeroModel:
         outputs["t2i_logits"] = t2i_sq
         lg = logits.squeeze()
         outputs["logits"] = lg if lg.dim() > 0 else lg.reshape(1)     # / exp((1,)-param) makes a 0-d result (1,)
+        return outputs
+
+    # ---- compute_logits_type "cls_alignment" / "global_alignment" (modeling.py:330-353) --------
+    def _compute_alignment_logits(self, pixel_values, encoded_key_phrases):
+        tokens, (b, n) = self._vision(pixel_values, want_tokens=True)
+        key_features = torch.cat([self.forward_text_model(kp)["text_features"] for kp in encoded_key_phrases], dim=0).contiguous()     # (N_total, D')
+        t, d = key_features.shape[0], self.config.hidden_size
+        outputs = {}
+        if self.config.compute_logits_type == "cls_alignment":
+            if key_features.shape[1] != d:
+                raise RuntimeError(f"mat1 and mat2 shapes cannot be multiplied ({b}x{d} and {key_features.shape[1]}x{t})")     # torch's error in the reference
+            outputs["logits"] = self._rows_dot(tokens[:, 0], key_features)                      # image_cls_token @ key_features.T
+            return outputs
+        if key_features.shape[1] != 2 * d:
+            raise RuntimeError(f"mat1 and mat2 shapes cannot be multiplied ({b}x{2 * d} and {key_features.shape[1]}x{t})")
+        with torch.cuda.device(self._device):
+            image_features = torch.empty((b, 2 * d), dtype=torch.float32, device=self._device)
+            _lib.check(self._lib.rz_image_features(_ptr(tokens), n, b, n, d, _ptr(image_features), self._stream()), "rz_image_features")
+            outputs["logits"] = self._rows_dot(image_features, key_features)                    # image_features @ key_features.T
+            # einsum("ind,jd->ijn", image_patch_tokens, key_features[:, hidden:]) -> (B, N_total, L): rows = every token of every image (the cls
+            # row lands in column 0 of a (B, T, 1 + L) buffer and is sliced off: patch rows are not contiguous across images)
+            sim = torch.empty((b, t, n), dtype=torch.float32, device=self._device)
+            self._rows_dot(tokens.reshape(b * n, d), key_features[:, d:], out=sim, rows_per_group=n, strides=(t * n, 1, n))
+        outputs["similarity_scores"] = sim[:, :, 1:]
         return outputs
 
     # ---- similarity-map post-processing (segmentation_utils.py:62-70, attention_map_base.py:57) ---

@@ -96,6 +96,9 @@ def checkpoint_spec(cfg: RadZeroConfig) -> "OrderedDict[str, tuple]":
         (cfg.relative_attention_num_buckets, cfg.num_attention_heads), "relbias")
     spec["text_model.pooler.dense.weight"] = ((d, d), "lin_w")     # computed-but-unused by the path
     spec["text_model.pooler.dense.bias"] = ((d,), "bias")
+    if getattr(cfg, "use_text_projection", False):                 # text_projector = nn.Linear(text_dim, 2 * hidden) (modeling.py:70-73)
+        spec["text_projector.weight"] = ((2 * d, d), "lin_w")
+        spec["text_projector.bias"] = ((2 * d,), "bias")
     # --- loss_fns.RadZeroLoss (losses.py:51-56) ---
     spec["loss_fns.RadZeroLoss.layer_norm.weight"] = ((d,), "ln_w")
     spec["loss_fns.RadZeroLoss.layer_norm.bias"] = ((d,), "ln_b")

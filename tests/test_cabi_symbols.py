@@ -131,14 +131,17 @@ def test_encode_prompts_cache_under_inference_mode():
     import torch
     from radzero_amd.modeling import RadZeroModel
     m = RadZeroModel.__new__(RadZeroModel)
+    from radzero_amd.config import RadZeroConfig
+    m.config = RadZeroConfig()            # token ids are range-checked before the content key is built
     m.text_cache_enabled = True
     m._text_cache, m._text_ident_cache = {}, {}
     calls = []
 
-    def fake_text(enc):
+    def fake_text(ids, mask):            # stands in for rz_text_forward (the content-keyed level calls the raw encoder)
         calls.append(1)
-        return {"text_features_wo_l2_norm": enc["input_ids"].float().sum(1, keepdim=True)}
-    m.forward_text_model = fake_text
+        return ids.float().sum(1, keepdim=True)
+    m._text_forward_raw = fake_text
+    m._device = torch.device("cpu")
     with torch.inference_mode():
         ids = torch.arange(12).reshape(3, 4).clone()
         mask = torch.ones_like(ids)

@@ -157,3 +157,31 @@ def test_oracle_head_variants_match_reference(name, over, cfg):
     for key in ("logits", "similarity_scores", "t2i_logits"):
         assert np.abs(out[key].numpy() - g[key]).max() <= TOL, (name, key)
     assert np.array_equal(np.argmax(out["logits"].numpy(), 1), np.argmax(g["logits"], 1))
+
+
+ALIGNMENT_CASES = [("g12_cls_alignment_s224_b2_t5", dict(compute_logits_type="cls_alignment")),
+                   ("g13_global_alignment_s266_b2_t5", dict(compute_logits_type="global_alignment", use_text_projection=True))]
+
+
+@pytest.mark.parametrize("name,over", ALIGNMENT_CASES)
+def test_oracle_alignment_heads_match_reference(name, over, cfg):
+    """G12 / G13 (round 4): the reference run with compute_logits_type "cls_alignment" / "global_alignment" (modeling.py:330-353; the latter with
+    the text projector of modeling.py:70-73), two encoded key-phrase groups of different padded length (tools/make_goldens_alignment.py)."""
+    import dataclasses
+    from oracle.radzero_oracle import OracleModel
+    from radzero_amd.weights import make_state_dict
+    g = load_golden(name)
+    c2 = dataclasses.replace(cfg, **over)
+    sd = make_state_dict(c2, int(g["weights_seed"]))
+    assert state_dict_digest(sd) == str(g["weights_digest"])
+    assert ("text_projector.weight" in sd) == bool(over.get("use_text_projection"))
+    px = synthetic_pixels(int(g["batch"]), int(g["side"]), int(g["px_seed"]))
+    encs = [{"input_ids": torch.from_numpy(g[f"input_ids_{k}"]), "attention_mask": torch.from_numpy(g[f"attention_mask_{k}"])} for k in "ab"]
+    with torch.no_grad():
+        m = OracleModel(sd, c2, attn_impl="eager")
+        out = m.compute_logits(px, encs)
+        vo = m.forward_vision_model(px)
+    assert set(out.keys()) == ({"logits", "similarity_scores"} if "similarity_scores" in g else {"logits"})
+    for key in out:
+        assert out[key].shape == g[key].shape and np.abs(out[key].numpy() - g[key]).max() <= TOL, (name, key)
+    assert np.abs(vo["image_features"].numpy() - g["image_features"]).max() <= TOL

@@ -4,6 +4,7 @@
 // So a workspace that rz_reserve sized too small, a weight buffer packed with the wrong leading dimension or a stale pointer after a
 // reload is reported on the CPU box with a stack trace, without a GPU.  Outputs are filled with a finite pattern so that host code
 // reading results back (overflow-guard words, profile counters) sees defined data.
+#include <algorithm>
 #include <sanitizer/asan_interface.h>
 
 #include <cstdio>
@@ -56,9 +57,15 @@ static void gemm_ranges(int dtype, int epi, const GemmArgs& g, size_t out_es) {
         case EPI_RESID_ADD:
             rd(g.resid, ((size_t)(g.M - 1) * g.ldr + g.N) * 4, "gemm resid");
             wr(g.out, ((size_t)(g.M - 1) * g.ldo + g.N) * 4, "gemm out (fp32)"); break;
-        case EPI_PATCH:
+        case EPI_PATCH: case EPI_PATCH_LN:
             rd(g.scale, (size_t)g.rows_per_image * g.N * 4, "gemm patch table");
-            wr(g.out, ((size_t)(g.M - 1) * g.ldo + g.N) * 4, "gemm out (fp32)"); break;
+            wr(g.out, ((size_t)(g.M - 1) * g.ldo + g.N) * 4, "gemm out (fp32)");
+            if (epi == EPI_PATCH_LN) {
+                rd(g.ln_gamma, (size_t)g.N * 4, "gemm ln_gamma");
+                wr(g.ln_part, (size_t)g.M * 12 * 2 * 4, "gemm ln_part");
+                wr(g.ln_hb, (size_t)g.M * g.N * es, "gemm ln_hb");
+            }
+            break;
         case EPI_RESID_SCALE: case EPI_RESID_SCALE_LN:
             rd(g.scale, (size_t)g.N * 4, "gemm LayerScale");
             wr(g.resid, ((size_t)(g.M - 1) * g.ldr + g.N) * 4, "gemm residual stream");
@@ -136,6 +143,10 @@ static bool big_tiles_pay(const GemmArgs& g) {          // gemm.hip
 }
 bool gemm_v8_ok(int dtype, int, const GemmArgs& g) { return dtype != DT_F32 && g.M % 256 == 0 && g.N % 256 == 0 && g.K % 128 == 0 && g.K >= 256; }
 bool gemm_qkv_fused_ok(int dtype, const GemmArgs& g) { return (g.variant == 0 || g.variant == 8) && gemm_v8_ok(dtype, EPI_QKV, g) && (g.variant != 0 || big_tiles_pay(g)); }
+bool gemm_patch_ln_ok(int dtype, const GemmArgs& g) {
+    return dtype != DT_F32 && (g.variant == 0 || g.variant == 1 || g.variant == 8) && g.M > 0 && g.M % 128 == 0 && g.N == 768 && g.K % 64 == 0 && g.ln_part && g.ln_hb &&
+           g.ln_gamma && g.scale && g.out && g.rows_per_image > 0;
+}
 bool gemm_ln_fused_ok(int dtype, int M, int D, int F, int variant) { return dtype != DT_F32 && (variant == 0 || variant == 1 || variant == 8) && M > 0 && M % 128 == 0 && D == 768 && F % 128 == 0; }
 
 // ---- attention (attention.hip) -----------------------------------------------------------------------------------------------
@@ -211,6 +222,18 @@ hipError_t launch_text_embed(int dtype, const int64_t* ids, const float* we, con
 }
 hipError_t launch_masked_meanpool(const float* h, const int64_t* mask, float* out, int T, int L, int D, hipStream_t) {
     rd(h, (size_t)T * L * D * 4, "meanpool h"); rd(mask, (size_t)T * L * 8, "meanpool mask"); wr(out, (size_t)T * D * 4, "meanpool out");
+    return hipSuccess;
+}
+hipError_t launch_rows_dot(const float* a, int64_t lda, const float* b, int64_t ldb, const float* bias, float* out, int M, int N, int K, int rpg, int64_t og, int64_t orow,
+                           int64_t ocol, hipStream_t) {
+    rd(a, ((size_t)(M - 1) * lda + K) * 4, "rows_dot a"); rd(b, ((size_t)(N - 1) * ldb + K) * 4, "rows_dot b");
+    if (bias) rd(bias, (size_t)N * 4, "rows_dot bias");
+    const size_t last = (size_t)((M - 1) / rpg) * og + (size_t)std::min(M - 1, rpg - 1) * orow + (size_t)(N - 1) * ocol;
+    wr(out, (last + 1) * 4, "rows_dot out");
+    return hipSuccess;
+}
+hipError_t launch_image_features(const float* tokens, int64_t image_stride, int B, int n_tokens, int D, float* out, hipStream_t) {
+    rd(tokens, ((size_t)(B - 1) * image_stride + n_tokens) * D * 4, "image_features tokens"); wr(out, (size_t)B * 2 * D * 4, "image_features out");
     return hipSuccess;
 }
 hipError_t launch_ln_l2norm(const float* in, int64_t ld, const float* g, const float* b, float, float* out, int64_t rows, int D, int, hipStream_t) {

@@ -23,7 +23,7 @@ def _pkg(name, path=None):
     return m
 
 
-def load_reference_model(cfg, state_dict=None, attn_implementation="eager"):
+def load_reference_model(cfg, state_dict=None, attn_implementation="eager"):      # cfg.compute_logits_type / cfg.use_text_projection select the alignment heads
     """Build the reference `CxrAlignModel` (fp32, eval) for `cfg` (radzero_amd.config.RadZeroConfig)."""
     import logging
 
@@ -98,7 +98,7 @@ def load_reference_model(cfg, state_dict=None, attn_implementation="eager"):
     model_config = dict(
         vision_config=dict(model_type="dinov2",
                            pretrained_name_or_path="StanfordAIMI/dinov2-base-xray-224", img_size=518),
-        text_config=dict(use_text_projection=False, model_type="mpnet",
+        text_config=dict(use_text_projection=bool(getattr(cfg, "use_text_projection", False)), model_type="mpnet",
                          pretrained_name_or_path="sentence-transformers/all-mpnet-base-v2",
                          pretrained_tokenizer_name_or_path="sentence-transformers/all-mpnet-base-v2",
                          use_cls_token=False),
@@ -109,7 +109,7 @@ def load_reference_model(cfg, state_dict=None, attn_implementation="eager"):
                   RadZeroLoss=dict(hidden_dim=cfg.hidden_size, mpnce_row_sum=False, mpnce_col_sum=False,
                                    attn_temperature=getattr(cfg, "attn_temperature", None), loss_temperature=cfg.loss_temperature,
                                    text_features_l2_norm=False, sim_op=cfg.sim_op)),
-        compute_logits_type="radzero",
+        compute_logits_type=getattr(cfg, "compute_logits_type", "radzero"),
         pretrained_dir="/data/pretrained",          # exp/cxr_pt/configs/paths.yaml:11 (only read for m3ae)
     )
     rcfg = configuration.CxrAlignConfig(**model_config)
