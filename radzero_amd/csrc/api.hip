@@ -928,8 +928,7 @@ static int vision_forward_once(rz_handle_t m, const float* px, int B, int C, int
                     RZ_HIP(launch_gemm(m->dt, EPI_PATCH_LN, g, s));
                 }
                 ProfScope ps(m, RZ_PROF_ROWOPS, s);
-                RZ_HIP(hipMemsetAsync(lnmu, 0, (size_t)M * sizeof(float), s));          // the epilogue centred with 0
-                RZ_HIP(launch_ln_finalize(part, lnmu, stat, eps, M, s));
+                RZ_HIP(launch_ln_finalize(part, lnmu, stat, eps, M, s, true));          // the epilogue centred with 0 (no memset: one would not replay inside a captured graph)
             }
         }
         if (!patch_ln && (rc = gemm(m, EPI_PATCH, mid, m->KPAD, m->patch_w.p, m->KPAD, M, D, m->KPAD, nullptr, h, D,

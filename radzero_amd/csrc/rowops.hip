@@ -128,7 +128,7 @@ hipError_t launch_layernorm(int dtype, const float* in, const float* gamma, cons
 // ---- fused-LayerNorm support (gemm8.hip "Fused LayerNorm") ----
 // ln_finalize: one thread per row merges the 12 (mean, M2) partials of 64 columns each that EPI_RESID_SCALE_LN wrote
 // (equal counts: mean = average of means, M2 = sum M2_p + 64 * sum (mean_p - mean)^2 — Chan et al., exact) into (mean, rstd).
-__global__ __launch_bounds__(256) void ln_finalize_kernel(const float* __restrict__ part, float* __restrict__ mu_inout, float* __restrict__ stat, float eps, int64_t rows) {
+__global__ __launch_bounds__(256) void ln_finalize_kernel(const float* __restrict__ part, float* __restrict__ mu_inout, float* __restrict__ stat, float eps, int64_t rows, int mu_is_zero) {
     const int64_t row = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (row >= rows) return;
     const f32x4* p = reinterpret_cast<const f32x4*>(part + row * 24);
@@ -148,13 +148,14 @@ __global__ __launch_bounds__(256) void ln_finalize_kernel(const float* __restric
     }
     const float var = (m2 + 64.0f * dev) * (1.0f / 768.0f);
     // the producer centred its T copy with the row's previous mean: consumers subtract only the remainder
-    *reinterpret_cast<f32x2*>(stat + row * 2) = (f32x2){mean - mu_inout[row], rsqrtf(var + eps)};
+    // (mu_is_zero: the producer had no earlier mean — EPI_PATCH_LN centres with 0 — and mu_inout holds nothing yet)
+    *reinterpret_cast<f32x2*>(stat + row * 2) = (f32x2){mean - (mu_is_zero ? 0.f : mu_inout[row]), rsqrtf(var + eps)};
     mu_inout[row] = mean;
 }
 
-hipError_t launch_ln_finalize(const float* part, float* mu_inout, float* stat, float eps, int64_t rows, hipStream_t s) {
+hipError_t launch_ln_finalize(const float* part, float* mu_inout, float* stat, float eps, int64_t rows, hipStream_t s, bool mu_is_zero) {
     if (rows <= 0 || !mu_inout) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(ln_finalize_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, s, part, mu_inout, stat, eps, rows);
+    hipLaunchKernelGGL(ln_finalize_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, s, part, mu_inout, stat, eps, rows, mu_is_zero ? 1 : 0);
     return hipGetLastError();
 }
 

@@ -97,7 +97,7 @@ hipError_t launch_text_attn(int dtype, const void* qkv, const float* rel_bias, c
 // EPI_RESID_SCALE_LN writes them) + the constant that producer used (mu_inout) -> stat, and mu_inout = the new mean.  ln_prepare: rows of 768 fp32 -> T copy + stat; with
 // gamma/beta != nullptr the row is first LayerNorm'ed in place (out_f32, may alias in) and copy / stat describe the result.
 // The T copy is multiplied by `copy_gain` (the gain of the LayerNorm that will consume it).
-hipError_t launch_ln_finalize(const float* part, float* mu_inout, float* stat, float eps, int64_t rows, hipStream_t s);
+hipError_t launch_ln_finalize(const float* part, float* mu_inout, float* stat, float eps, int64_t rows, hipStream_t s, bool mu_is_zero = false);
 hipError_t launch_ln_prepare(int dtype, const float* in, const float* gamma, const float* beta, float eps_in, float* out_f32,
                              const float* copy_gain, void* copy_t, float* mu_out, float* stat, float eps_stat, int64_t rows, int D, hipStream_t s);
 

@@ -188,7 +188,7 @@ hipError_t launch_text_attn(int dtype, const void* qkv, const float* rel_bias, c
 }
 
 // ---- row kernels (rowops.hip) ------------------------------------------------------------------------------------------------
-hipError_t launch_ln_finalize(const float* part, float* mu, float* stat, float, int64_t rows, hipStream_t) {
+hipError_t launch_ln_finalize(const float* part, float* mu, float* stat, float, int64_t rows, hipStream_t, bool) {
     rd(part, (size_t)rows * 24 * 4, "ln_finalize partials"); wr(mu, (size_t)rows * 4, "ln_finalize mu"); wr(stat, (size_t)rows * 8, "ln_finalize stat");
     return hipSuccess;
 }
