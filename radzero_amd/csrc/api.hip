@@ -928,7 +928,10 @@ static int vision_forward_once(rz_handle_t m, const float* px, int B, int C, int
                     RZ_HIP(launch_gemm(m->dt, EPI_PATCH_LN, g, s));
                 }
                 ProfScope ps(m, RZ_PROF_ROWOPS, s);
-                RZ_HIP(launch_ln_finalize(part, lnmu, stat, eps, M, s, true));          // the epilogue centred with 0 (no memset: one would not replay inside a captured graph)
+// the epilogue centred with 0: told to the merge kernel, NOT a hipMemsetAsync of lnmu — inside a captured graph (torch.cuda.graph) a memset
+                // placed between the kernels that write and read lnmu was not ordered with them on replay (first replay right, later ones wrong:
+                // tests/test_gpu_fullsize.py::test_graph_replay_equals_eager_at_full_size); a plain capture of memset -> kernel replays correctly
+                RZ_HIP(launch_ln_finalize(part, lnmu, stat, eps, M, s, true));
             }
         }
         if (!patch_ln && (rc = gemm(m, EPI_PATCH, mid, m->KPAD, m->patch_w.p, m->KPAD, M, D, m->KPAD, nullptr, h, D,
