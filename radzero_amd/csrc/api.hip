@@ -928,7 +928,7 @@ static int vision_forward_once(rz_handle_t m, const float* px, int B, int C, int
                     RZ_HIP(launch_gemm(m->dt, EPI_PATCH_LN, g, s));
                 }
                 ProfScope ps(m, RZ_PROF_ROWOPS, s);
-// the epilogue centred with 0: told to the merge kernel, NOT a hipMemsetAsync of lnmu — inside a captured graph (torch.cuda.graph) a memset
+                // the epilogue centred with 0: told to the merge kernel, NOT a hipMemsetAsync of lnmu — inside a captured graph (torch.cuda.graph) a memset
                 // placed between the kernels that write and read lnmu was not ordered with them on replay (first replay right, later ones wrong:
                 // tests/test_gpu_fullsize.py::test_graph_replay_equals_eager_at_full_size); a plain capture of memset -> kernel replays correctly
                 RZ_HIP(launch_ln_finalize(part, lnmu, stat, eps, M, s, true));
