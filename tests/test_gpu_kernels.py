@@ -530,7 +530,7 @@ def test_text_embed_ln_vs_pytorch(lib, dt, T, L):
 
 
 @pytest.mark.parametrize("dt", ["f32", "bf16", "f16"])
-@pytest.mark.parametrize("T,L", [(4, 12), (2, 1), (3, 77)])
+@pytest.mark.parametrize("T,L", [(4, 12), (2, 1), (3, 77), (3, 32), (2, 33)])          # L <= 32: the one-workgroup-per-(prompt, head) kernel; above: one thread per query
 def test_text_attention_vs_pytorch(lib, dt, T, L):
     """MPNet self-attention with the additive relative-position bias and the key-padding mask as HF applies it (additive -FLT_MAX: a
     fully masked row becomes uniform, not NaN), against softmax in fp32 on the same (rounded) operands."""
