@@ -71,11 +71,13 @@ template <int N> __device__ __forceinline__ void v8_wait_vm() {
 // and the kernel drains them before it ends.  extra (wave-uniform, run time): this is the first K tile after an epilogue
 // (see header); one scalar branch per phase selects the wait.  ONE copy of this body exists in the kernel, inside one
 // simple loop: with one inlined variant per case hipcc renamed the accumulators between the copies and spilled them.
-template <typename T, bool SWAP, int EXTRA>
+// MX: this K tile is a 128-byte fp8 pair block of the fp32 mode's MX form (rz_common.h; gemm7.hip v7_tile): ONE block-scaled MFMA per accumulator
+// tile with the fragments of both k-halves as its 32-byte operands; sa / sw = this lane's E8M0 scale bytes for the A rows / the W rows.
+template <typename T, bool SWAP, int EXTRA, bool MX = false>
 __device__ __forceinline__ void v8_tile(f32x4 (&acc)[2][4][4], char* cur, char* nxt, unsigned a_rd, unsigned b_rd,
                                         const char* a1, const char* w1, const char* a2, const char* w2,
                                         const unsigned (&a_off)[2], const unsigned (&w_off)[2], int64_t a_sub, int64_t w_sub,
-                                        unsigned a_dst, unsigned w_dst, bool extra) {
+                                        unsigned a_dst, unsigned w_dst, bool extra, int sa = 0, int sw = 0) {
     typedef typename Traits<T>::frag frag_t;
     frag_t fa[2][4], fb0[2][2], fb1[2][2];          // [k-half][fragment]
 #pragma unroll
@@ -113,13 +115,28 @@ __device__ __forceinline__ void v8_tile(f32x4 (&acc)[2][4][4], char* cur, char* 
         // ---- MFMA part: quadrant (mi, ni) = (0,0) (0,1) (1,1) (1,0)
         const int mi = u >> 1, ni = (u == 1 || u == 2) ? 1 : 0;
         __builtin_amdgcn_s_setprio(1);
+        if constexpr (MX) {
+            if constexpr (std::is_same<T, f16_t>::value) {
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
+                for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+                    for (int j = 0; j < 2; ++j) {
+                        f32x4& c = acc[mi][i][ni * 2 + j];
+                        const frag_t& b0 = ni ? fb1[0][j] : fb0[0][j];
+                        const frag_t& b1 = ni ? fb1[1][j] : fb0[1][j];
+                        if constexpr (SWAP) c = mma_mx(b0, b1, fa[0][i], fa[1][i], c, sw, sa);
+                        else c = mma_mx(fa[0][i], fa[1][i], b0, b1, c, sa, sw);
+                    }
+            }
+        } else {
 #pragma unroll
-                for (int j = 0; j < 2; ++j)
-                    v8_mma<T, SWAP>(acc[mi][i][ni * 2 + j], fa[ks][i], ni ? fb1[ks][j] : fb0[ks][j]);
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        v8_mma<T, SWAP>(acc[mi][i][ni * 2 + j], fa[ks][i], ni ? fb1[ks][j] : fb0[ks][j]);
+        }
         __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_sched_barrier(0);
         // everything issued three or more phases ago must have landed: the three youngest units (6 instructions) may stay
@@ -135,7 +152,9 @@ __device__ __forceinline__ void v8_tile(f32x4 (&acc)[2][4][4], char* cur, char* 
 // STAMP: diagnostic build (tools/kstamp8.py, compiled only with -DRZ_EXPERIMENTS; never launched by the model): every wave sums the 100 MHz real-time ticks it
 // spends in K loops and in epilogues and stores them, with the absolute time of its first 24 epilogue starts, into the
 // buffer passed as g.out2 — memory no other code of the kernel reads.
-template <typename T, int EPI, bool STAMP = false>
+// MXK: the fp32 mode's MX form (gemm7.hip gemm_kernel_v7 "MXK"): operand rows are [K f16 | 2 K fp8 bytes], g.K = 2 K counts 128-byte K tiles x 64,
+// the first half of a tile's K tiles runs the f16 MFMAs (a_hi b_hi), the second half the block-scaled fp8 MFMA (the two correction terms).
+template <typename T, int EPI, bool STAMP = false, bool MXK = false>
 __global__ __launch_bounds__(512, 2) void gemm_kernel_v8(GemmArgs g) {
     static_assert(sizeof(T) == 2, "v8 is for 16-bit operands");
     __shared__ __attribute__((aligned(1024))) char lds[2 * V8_STAGE + 8 * V8_WAVE_LDS];     // 160 KB: one workgroup per CU
@@ -235,11 +254,12 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel_v8(GemmArgs g) {
             // K tile 0 apart (its waits may allow the epilogue's stores: run-time flag), then the steady loop with the flag a
             // compile-time false: no branch between the MFMAs and the counted wait.  The merged q|k|v kernels hold both operand
             // orders of this loop; a second call site each made hipcc spill, so they keep the flag inside one loop.
-            constexpr bool PEEL = !(EPI == EPI_QKV || EPI == EPI_QKV_LN);
+            constexpr bool PEEL = !(EPI == EPI_QKV || EPI == EPI_QKV_LN) && !MXK;      // MXK: two loop bodies already (f16 tiles, fp8 tiles)
             if constexpr (PEEL)
                 v8_tile<T, SWAP, EXTRA>(acc, lds, lds + V8_STAGE, a_rd, b_rd, Ab + 128, Wb + 128, Ab + 256, Wb + 256, a_off, w_off, a_sub,
                                         w_sub, a_dst, w_dst, after_epilogue);
-            for (int kt = PEEL ? 1 : 0; kt < nk; ++kt) {
+            const int nkh = MXK ? nk / 2 : nk;
+            for (int kt = PEEL ? 1 : 0; kt < nkh; ++kt) {
                 char* cur = lds + (kt & 1) * V8_STAGE;
                 char* nxt = lds + ((kt + 1) & 1) * V8_STAGE;
                 const bool in1 = kt + 1 < nk, in2 = kt + 2 < nk;
@@ -249,6 +269,20 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel_v8(GemmArgs g) {
                 const char* w2 = in2 ? Wb + (int64_t)(kt + 2) * 128 : Wn + (int64_t)(kt + 2 - nk) * 128;
                 v8_tile<T, SWAP, EXTRA>(acc, cur, nxt, a_rd, b_rd, a1, w1, a2, w2, a_off, w_off, a_sub, w_sub, a_dst, w_dst,
                                         PEEL ? false : (kt == 0 && after_epilogue));
+            }
+            if constexpr (MXK) {
+                // E8M0 scale byte of this lane's 32-element block (block index = lane >> 4): A rows = [lo8 | hi8], W rows = [hi8 | lo8]
+                const int sa = lg < 2 ? MX_E8_A_LO : MX_E8_A_HI, sw = lg < 2 ? MX_E8_W_HI : MX_E8_W_LO;
+                for (int kt = nkh; kt < nk; ++kt) {
+                    char* cur = lds + (kt & 1) * V8_STAGE;
+                    char* nxt = lds + ((kt + 1) & 1) * V8_STAGE;
+                    const bool in1 = kt + 1 < nk, in2 = kt + 2 < nk;
+                    const char* a1 = in1 ? Ab + (int64_t)(kt + 1) * 128 : An + (int64_t)(kt + 1 - nk) * 128;
+                    const char* w1 = in1 ? Wb + (int64_t)(kt + 1) * 128 : Wn + (int64_t)(kt + 1 - nk) * 128;
+                    const char* a2 = in2 ? Ab + (int64_t)(kt + 2) * 128 : An + (int64_t)(kt + 2 - nk) * 128;
+                    const char* w2 = in2 ? Wb + (int64_t)(kt + 2) * 128 : Wn + (int64_t)(kt + 2 - nk) * 128;
+                    v8_tile<T, SWAP, EXTRA, true>(acc, cur, nxt, a_rd, b_rd, a1, w1, a2, w2, a_off, w_off, a_sub, w_sub, a_dst, w_dst, false, sa, sw);
+                }
             }
         };
         const int mw = m0 + wr * 128, nw = n0 + wc * 64;
@@ -366,6 +400,19 @@ bool gemm_v8_ok(int dtype, int epi, const GemmArgs& g) {
     if (epi == EPI_RESID_SCALE_LN && (g.N != 768 || !g.ln_part || !g.ln_hb || !g.ln_gamma || !g.ln_mu || !g.scale || !g.resid)) return false;
     if (epi == EPI_PATCH_LN && (g.N != 768 || !g.ln_part || !g.ln_hb || !g.ln_gamma || !g.scale || !g.out || g.rows_per_image <= 0)) return false;
     return true;
+}
+
+// fp32 mode, MX form on the persistent loop (g as for launch_gemm_v7_mx: operand rows of 2 K f16-element units, g.K = 2 K): the epilogues that
+// work straight from the accumulators (out_kind 0: EPI_RESID_SCALE, EPI_PATCH)
+bool gemm_v8_mx_ok(int epi, const GemmArgs& g) {
+    return (epi == EPI_RESID_SCALE || epi == EPI_PATCH) && gemm_v8_ok(DT_F16, epi, g);
+}
+hipError_t launch_gemm_v8_mx(int epi, const GemmArgs& g, hipStream_t s) {
+    if (!gemm_v8_mx_ok(epi, g)) return hipErrorInvalidValue;
+    dim3 grid(v8_grid()), block(512);
+    if (epi == EPI_RESID_SCALE) hipLaunchKernelGGL((gemm_kernel_v8<f16_t, EPI_RESID_SCALE, false, true>), grid, block, 0, s, g);
+    else hipLaunchKernelGGL((gemm_kernel_v8<f16_t, EPI_PATCH, false, true>), grid, block, 0, s, g);
+    return hipGetLastError();
 }
 
 hipError_t launch_gemm_v8(int dtype, int epi, const GemmArgs& g, hipStream_t s) {
