@@ -443,7 +443,7 @@ int gemm_f32_split(rz_model* m, int epi, GemmArgs g, int a_mode, bool out_split,
                              ((epi == EPI_VT && (mx & 2)) || (epi == EPI_HEADS && (mx & 4))) ? 3 : 1;       // 3: hi f16 + e4m3 pair planes (MX attention)
         if ((out_kind != 0) != out_split) return fail(RZ_ERR_STATE, "MX GEMM: output form mismatch");
         g.variant = m->o_gemm_variant();
-        if (out_kind == 0 && g.variant != 7 && gemm_v8_mx_ok(epi, g)) RZ_HIP(launch_gemm_v8_mx(epi, g, s));       // persistent loop: the epilogue's stores under the next tile's K loop
+        if (g.variant != 7 && gemm_v8_mx_ok(epi, out_kind, g)) RZ_HIP(launch_gemm_v8_mx(epi, out_kind, g, s));       // persistent loop: the epilogue's stores under the next tile's K loop
         else RZ_HIP(launch_gemm_v7_mx(epi, g, out_kind, s));
         *done = true;
         return 0;

@@ -154,11 +154,12 @@ __device__ __forceinline__ void v8_tile(f32x4 (&acc)[2][4][4], char* cur, char* 
 // buffer passed as g.out2 — memory no other code of the kernel reads.
 // MXK: the fp32 mode's MX form (gemm7.hip gemm_kernel_v7 "MXK"): operand rows are [K f16 | 2 K fp8 bytes], g.K = 2 K counts 128-byte K tiles x 64,
 // the first half of a tile's K tiles runs the f16 MFMAs (a_hi b_hi), the second half the block-scaled fp8 MFMA (the two correction terms).
-template <typename T, int EPI, bool STAMP = false, bool MXK = false>
+// FORM >= 0 (with MXK): the outputs leave in one of the fp32 mode's split forms (gemm8_epilogue.h v8_epilogue_split).
+template <typename T, int EPI, bool STAMP = false, bool MXK = false, int FORM = -1>
 __global__ __launch_bounds__(512, 2) void gemm_kernel_v8(GemmArgs g) {
     static_assert(sizeof(T) == 2, "v8 is for 16-bit operands");
     __shared__ __attribute__((aligned(1024))) char lds[2 * V8_STAGE + 8 * V8_WAVE_LDS];     // 160 KB: one workgroup per CU
-    constexpr int EXTRA = V8Epi<(EPI == EPI_QKV || EPI == EPI_QKV_LN || EPI == EPI_GELU_LN) ? EPI_HEADS : EPI>::kExtra;
+    constexpr int EXTRA = FORM >= 0 ? 8 : V8Epi<(EPI == EPI_QKV || EPI == EPI_QKV_LN || EPI == EPI_GELU_LN) ? EPI_HEADS : EPI>::kExtra;     // split epilogues: 32 stores per lane, the last 16 nothing but stores
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -290,7 +291,8 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel_v8(GemmArgs g) {
             if constexpr (EPI == EPI_VT || EPI == EPI_QKV || EPI == EPI_QKV_LN) {
                 k_loop(std::integral_constant<bool, false>{});
                 __builtin_amdgcn_sched_barrier(0);
-                v8_epilogue<T, EPI, false>(g, acc, wl, mw, nw, lane);
+                if constexpr (FORM >= 0) v8_epilogue_split<EPI, FORM>(g, acc, wl, mw, nw, lane);
+                else v8_epilogue<T, EPI, false>(g, acc, wl, mw, nw, lane);
             }
         } else {
             if constexpr (EPI != EPI_VT) {
@@ -305,7 +307,8 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel_v8(GemmArgs g) {
                     st_t = t1;
                     __builtin_amdgcn_sched_barrier(0);
                 }
-                v8_epilogue<T, EPI, true>(g, acc, wl, mw, nw, lane);
+                if constexpr (FORM >= 0) v8_epilogue_split<EPI, FORM>(g, acc, wl, mw, nw, lane);
+                else v8_epilogue<T, EPI, true>(g, acc, wl, mw, nw, lane);
                 if constexpr (STAMP) {
                     __builtin_amdgcn_sched_barrier(0);
                     const unsigned long long t2 = __builtin_amdgcn_s_memrealtime();
@@ -404,14 +407,21 @@ bool gemm_v8_ok(int dtype, int epi, const GemmArgs& g) {
 
 // fp32 mode, MX form on the persistent loop (g as for launch_gemm_v7_mx: operand rows of 2 K f16-element units, g.K = 2 K): the epilogues that
 // work straight from the accumulators (out_kind 0: EPI_RESID_SCALE, EPI_PATCH)
-bool gemm_v8_mx_ok(int epi, const GemmArgs& g) {
-    return (epi == EPI_RESID_SCALE || epi == EPI_PATCH) && gemm_v8_ok(DT_F16, epi, g);
+// out_kind as launch_gemm_v7_mx: 0 = fp32 read-modify-write / table epilogues, 1 = EPI_HEADS -> hi / lo f16 planes, 2 = EPI_GELU -> the MX form,
+// 3 = EPI_VT -> hi f16 plane + e4m3 pair plane (the default forms of the fp32 mode; the others stay on gemm7.hip)
+bool gemm_v8_mx_ok(int epi, int out_kind, const GemmArgs& g) {
+    const bool form = (out_kind == 0 && (epi == EPI_RESID_SCALE || epi == EPI_PATCH)) || (out_kind == 1 && epi == EPI_HEADS) || (out_kind == 2 && epi == EPI_GELU) ||
+                      (out_kind == 3 && epi == EPI_VT);
+    return form && gemm_v8_ok(DT_F16, epi, g);
 }
-hipError_t launch_gemm_v8_mx(int epi, const GemmArgs& g, hipStream_t s) {
-    if (!gemm_v8_mx_ok(epi, g)) return hipErrorInvalidValue;
+hipError_t launch_gemm_v8_mx(int epi, int out_kind, const GemmArgs& g, hipStream_t s) {
+    if (!gemm_v8_mx_ok(epi, out_kind, g)) return hipErrorInvalidValue;
     dim3 grid(v8_grid()), block(512);
     if (epi == EPI_RESID_SCALE) hipLaunchKernelGGL((gemm_kernel_v8<f16_t, EPI_RESID_SCALE, false, true>), grid, block, 0, s, g);
-    else hipLaunchKernelGGL((gemm_kernel_v8<f16_t, EPI_PATCH, false, true>), grid, block, 0, s, g);
+    else if (epi == EPI_PATCH) hipLaunchKernelGGL((gemm_kernel_v8<f16_t, EPI_PATCH, false, true>), grid, block, 0, s, g);
+    else if (epi == EPI_HEADS) hipLaunchKernelGGL((gemm_kernel_v8<f16_t, EPI_HEADS, false, true, 0>), grid, block, 0, s, g);
+    else if (epi == EPI_GELU) hipLaunchKernelGGL((gemm_kernel_v8<f16_t, EPI_GELU, false, true, 1>), grid, block, 0, s, g);
+    else hipLaunchKernelGGL((gemm_kernel_v8<f16_t, EPI_VT, false, true, 2>), grid, block, 0, s, g);
     return hipGetLastError();
 }
 

@@ -111,6 +111,106 @@ __device__ __forceinline__ void v8_epilogue16(const GemmArgs& g, void* out, int 
     }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Wave-private epilogues for the fp32 mode's SPLIT outputs (gemm_common.h gemm_epilogue_tile_split is the whole-tile version of the one-tile-
+// per-workgroup kernel: same values, same bytes, same destinations).  Each of the eight 16 x 64 groups of v8_epilogue16 leaves as TWO planes
+// through the wave's two 2 KB images — plane 0 = f16(v), plane 1 by FORM:
+//   FORM 0  EPI_HEADS (q | k): lo = f16(v - hi), `plane_off` elements behind the hi plane
+//   FORM 1  EPI_GELU (fc1 -> fc2's A operand in the MX form, rz_common.h): the group's 64 columns are ONE 128-byte pair block [lo8 x 64 | hi8 x 64]
+//           at byte 2 ldo + (column / 64) * 128 of the output row
+//   FORM 2  EPI_VT (V^T for the MX attention): per (feature, 64-token block) 128 bytes [hi8 x 64 | lo8 x 64], `plane_off` elements behind the hi plane,
+//           the block's tokens in the order the attention's score accumulators hand keys to a lane (attention.hip "MXA")
+// Values are formed once per group (bias, exact-erf GELU) and kept in registers for both planes.  32 global stores per lane.
+// ---------------------------------------------------------------------------------------------------
+template <int EPI, int FORM>
+__device__ __forceinline__ void v8_epilogue_split(const GemmArgs& g, const f32x4 (&acc)[2][4][4], char* wl, int mw, int nw, int lane) {
+    static_assert((EPI == EPI_HEADS && FORM == 0) || (EPI == EPI_GELU && FORM == 1) || (EPI == EPI_VT && FORM == 2), "the fp32 mode's default output forms");
+    constexpr bool SWAP = (EPI != EPI_VT);
+    const int l15 = lane & 15, lg = lane >> 4;
+    f32x4 b4[4];
+    float bv[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        b4[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        bv[j] = 0.f;
+        if (g.bias) {
+            if constexpr (SWAP) b4[j] = *reinterpret_cast<const f32x4*>(g.bias + nw + j * 16 + 4 * lg);
+            else bv[j] = g.bias[nw + j * 16 + l15];
+        }
+    }
+    const unsigned wr_off = (unsigned)(l15 * 128 + (lg & 1) * 8);
+#pragma unroll
+    for (int grp = 0; grp < 8; ++grp) {
+        const int a = SWAP ? (grp >> 2) : (grp & 1);
+        const int x = SWAP ? (grp & 3) : (grp >> 1);          // SWAP: i (row block);  VT: j (feature block)
+        f32x4 v[4];
+        f16x4 hi[4];
+#pragma unroll
+        for (int y = 0; y < 4; ++y) {                        // SWAP: j (column block); VT: i (token block)
+            v[y] = SWAP ? acc[a][x][y] : acc[a][y][x];
+            if constexpr (SWAP) v[y] += b4[y]; else v[y] += bv[x];
+            if constexpr (EPI == EPI_GELU) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[y][e] = gelu_erf(v[y][e]);
+            }
+            if constexpr (FORM == 0) flag_f16_range(v[y], g.ovf_flag); else flag_mx_range(v[y], MX_A_HI_SCALE, g.ovf_flag);
+            hi[y] = pack4<f16_t>(v[y][0], v[y][1], v[y][2], v[y][3]);
+        }
+#pragma unroll
+        for (int pass = 0; pass < 2; ++pass) {
+            char* img = wl + pass * 2048;
+#pragma unroll
+            for (int y = 0; y < 4; ++y) {
+                if (pass == 0) {
+                    const int c = y * 2 + (lg >> 1);             // 16-byte chunk along inner
+                    *reinterpret_cast<f16x4*>(img + wr_off + ((c ^ (l15 & 7)) << 4)) = hi[y];
+                } else if constexpr (FORM == 0) {
+                    f16x4 d, lo;
+                    split4(v[y], d, lo);
+                    const int c = y * 2 + (lg >> 1);
+                    *reinterpret_cast<f16x4*>(img + wr_off + ((c ^ (l15 & 7)) << 4)) = lo;
+                } else {
+                    uint32_t lo8, hi8;
+                    pair4_mx(v[y], hi[y], lo8, hi8, MX_A_HI_SCALE, MX_A_LO_SCALE);
+                    int c_lo, c_hi, byte;                        // 16-byte chunks of the row's 128 bytes and the byte inside them
+                    if constexpr (FORM == 1) { c_lo = y; c_hi = y + 4; byte = 4 * lg; }                 // [lo8 x 64 | hi8 x 64], columns 16 y + 4 lg ..
+                    else {                                                                              // [hi8 x 64 | lo8 x 64], tokens in the attention's order
+                        const int kq = y * 16 + 4 * lg, pos = 16 * ((kq & 31) >> 3) + 8 * (kq >> 5) + (kq & 7);
+                        c_hi = pos >> 4; c_lo = c_hi + 4; byte = pos & 15;
+                    }
+                    *reinterpret_cast<uint32_t*>(img + l15 * 128 + ((c_lo ^ (l15 & 7)) << 4) + byte) = lo8;
+                    *reinterpret_cast<uint32_t*>(img + l15 * 128 + ((c_hi ^ (l15 & 7)) << 4) + byte) = hi8;
+                }
+            }
+            asm volatile("" ::: "memory");
+#pragma unroll
+            for (int it = 0; it < 2; ++it) {
+                const int q = it * 64 + lane;
+                const int row = q >> 3, c = q & 7;
+                const f16x8 o8 = *reinterpret_cast<const f16x8*>(img + row * 128 + ((c ^ (row & 7)) << 4));
+                if constexpr (EPI == EPI_GELU) {
+                    char* rowp = reinterpret_cast<char*>(g.out) + (int64_t)(mw + a * 64 + x * 16 + row) * 4 * g.ldo;
+                    if (pass == 0) *reinterpret_cast<f16x8*>(rowp + 2 * (nw + c * 8)) = o8;
+                    else *reinterpret_cast<f16x8*>(rowp + 2 * g.ldo + (nw >> 6) * 128 + c * 16) = o8;
+                } else {
+                    f16_t* o;
+                    if constexpr (EPI == EPI_VT) {
+                        const int n = nw + x * 16 + row, m = mw + a * 64 + c * 8;
+                        const int b = m / g.rows_per_image, tok = m - b * g.rows_per_image;
+                        o = reinterpret_cast<f16_t*>(g.out) + (((int64_t)b * g.heads_total + (n >> 6)) * 64 + (n & 63)) * g.rows_per_image + tok;
+                    } else {
+                        const int m = mw + a * 64 + x * 16 + row, n = nw + c * 8;
+                        const int b = m / g.rows_per_image, tok = m - b * g.rows_per_image;
+                        o = reinterpret_cast<f16_t*>(g.out) + (((int64_t)b * g.heads_total + (n >> 6)) * g.rows_per_image + tok) * 64 + (n & 63);
+                    }
+                    *reinterpret_cast<f16x8*>(pass == 0 ? o : o + g.plane_off) = o8;
+                }
+            }
+            asm volatile("" ::: "memory");
+        }
+    }
+}
+
 // EPI_RESID_SCALE_LN: resid += scale * (acc + bias) as gemm_epilogue_rmw does it, plus what the next LayerNorm needs of
 // the new residual v: its copy in T (staged through the wave's LDS region like the 16-bit epilogue) and, per output row,
 // (mean, M2) of this wave's 64 columns -> ln_part[m][3 * (n0 / 256) ... ], slice index = column / 64.

@@ -54,8 +54,8 @@ void gemm_v8_set_stamp_buffer(void* dev_u64);   // diagnostic build: non-null =>
 #endif
 bool gemm_v7_ok(int dtype, const GemmArgs& g);
 bool gemm_v8_ok(int dtype, int epi, const GemmArgs& g);
-bool gemm_v8_mx_ok(int epi, const GemmArgs& g);                        // fp32 mode's MX form on the persistent kernel (gemm8.hip): which epilogues / shapes
-hipError_t launch_gemm_v8_mx(int epi, const GemmArgs& g, hipStream_t s);
+bool gemm_v8_mx_ok(int epi, int out_kind, const GemmArgs& g);          // fp32 mode's MX form on the persistent kernel (gemm8.hip): which epilogues / output forms / shapes
+hipError_t launch_gemm_v8_mx(int epi, int out_kind, const GemmArgs& g, hipStream_t s);
 bool gemm_qkv_fused_ok(int dtype, const GemmArgs& g);
 bool gemm_patch_ln_ok(int dtype, const GemmArgs& g);                  // may the patch-embedding GEMM write block 0's LayerNorm inputs itself (EPI_PATCH_LN)
 bool gemm_ln_fused_ok(int dtype, int M, int D, int F, int variant);   // may a Dinov2 block of M token rows use the fused-LayerNorm epilogues

@@ -136,14 +136,17 @@ hipError_t launch_gemm_v7_mx(int epi, const GemmArgs& g, int out_kind, hipStream
     }
     return hipSuccess;
 }
-hipError_t launch_gemm_v8_mx(int epi, const GemmArgs& g, hipStream_t s) { return launch_gemm_v7_mx(epi, g, 0, s); }      // same operands, same outputs (out_kind 0)
+hipError_t launch_gemm_v8_mx(int epi, int out_kind, const GemmArgs& g, hipStream_t s) { return launch_gemm_v7_mx(epi, g, out_kind, s); }      // same operands, same outputs
 static bool big_tiles_pay(const GemmArgs& g) {          // gemm.hip
     if (g.M % 256 || g.M < 1024 || g.N % 256) return false;
     const int64_t t = (int64_t)(g.M / 256) * (g.N / 256);
     return t >= 128 && (double)t / (double)(((t + 255) / 256) * 256) >= 0.55;
 }
 bool gemm_v8_ok(int dtype, int, const GemmArgs& g) { return dtype != DT_F32 && g.M % 256 == 0 && g.N % 256 == 0 && g.K % 128 == 0 && g.K >= 256; }
-bool gemm_v8_mx_ok(int epi, const GemmArgs& g) { return (epi == EPI_RESID_SCALE || epi == EPI_PATCH) && gemm_v8_ok(DT_F16, epi, g); }
+bool gemm_v8_mx_ok(int epi, int out_kind, const GemmArgs& g) {
+    const bool form = (out_kind == 0 && (epi == EPI_RESID_SCALE || epi == EPI_PATCH)) || (out_kind == 1 && epi == EPI_HEADS) || (out_kind == 2 && epi == EPI_GELU) || (out_kind == 3 && epi == EPI_VT);
+    return form && gemm_v8_ok(DT_F16, epi, g);
+}
 bool gemm_qkv_fused_ok(int dtype, const GemmArgs& g) { return (g.variant == 0 || g.variant == 8) && gemm_v8_ok(dtype, EPI_QKV, g) && (g.variant != 0 || big_tiles_pay(g)); }
 bool gemm_patch_ln_ok(int dtype, const GemmArgs& g) {
     return dtype != DT_F32 && (g.variant == 0 || g.variant == 1 || g.variant == 8) && g.M > 0 && g.M % 128 == 0 && g.N == 768 && g.K % 64 == 0 && g.ln_part && g.ln_hb &&
