@@ -431,17 +431,21 @@ hipError_t launch_rows_dot(const float* a, int64_t lda, const float* b, int64_t 
 // image_features (modeling.py:115-117): l2norm([cls | mean over the patch tokens]) per image; tokens [B][image_stride rows of D], row 0 = cls,
 // rows 1..n_tokens-1 = patches.  Pass 1: column means of the patch rows (one workgroup per image and 64-column slab); pass 2: concatenate + normalise.
 __global__ __launch_bounds__(256) void patch_mean_kernel(const float* __restrict__ tokens, int64_t image_stride, int n_tokens, int D, float* __restrict__ feat) {
-    __shared__ float red[4][64];
-    const int b = blockIdx.y, c = blockIdx.x * 64 + (threadIdx.x & 63), rg = threadIdx.x >> 6;
+    // 16 row groups x 16 lanes of four columns: a workgroup reads 16 rows x 256 contiguous bytes per step
+    __shared__ f32x4 red[16][16];
+    const int b = blockIdx.y, c4 = threadIdx.x & 15, rg = threadIdx.x >> 4;
+    const int c = blockIdx.x * 64 + c4 * 4;
     const float* base = tokens + (int64_t)b * image_stride * D + c;
-    float acc = 0.f;
-    for (int r = 1 + rg; r < n_tokens; r += 4) acc += base[(int64_t)r * D];
-    red[rg][threadIdx.x & 63] = acc;
+    f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int r = 1 + rg; r < n_tokens; r += 16) acc += *reinterpret_cast<const f32x4*>(base + (int64_t)r * D);
+    red[rg][c4] = acc;
     __syncthreads();
     if (rg == 0) {
-        const float sum = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
-        feat[(int64_t)b * 2 * D + D + c] = sum / (float)(n_tokens - 1);
-        feat[(int64_t)b * 2 * D + c] = tokens[(int64_t)b * image_stride * D + c];          // the cls token
+        f32x4 sum = red[0][c4];
+#pragma unroll
+        for (int i = 1; i < 16; ++i) sum += red[i][c4];
+        *reinterpret_cast<f32x4*>(feat + (int64_t)b * 2 * D + D + c) = sum * (1.0f / (float)(n_tokens - 1));
+        *reinterpret_cast<f32x4*>(feat + (int64_t)b * 2 * D + c) = *reinterpret_cast<const f32x4*>(base);          // the cls token
     }
 }
 __global__ __launch_bounds__(256) void l2norm_rows_kernel(float* __restrict__ x, int len) {

@@ -601,3 +601,34 @@ def test_patch_embed_vs_pytorch_conv(lib, dt, B, Himg, Wimg):
     assert (got[:, :nv] - ref).abs().max().item() <= {"f32": 2e-4, "bf16": 2e-3, "f16": 2e-3}[dt]
     assert float(got[:, nv:].abs().max()) == 0.0 if npad > nv else True          # pad rows: zero rows of the table, zero im2col rows
     assert lib.rz_patch_embed(code, P(d[0]), B, C, Himg, Wimg, Pp, P(d[1]), kpad, P(d[2]), npad - 1, P(ws), P(out), stream()) == 10001
+
+
+def test_rows_dot_and_image_features_vs_pytorch(lib):
+    """The alignment heads' two kernels (modeling.py:330-353, :113-117): strided fp32 row products with a transposed (batch, prompt, token) destination and an
+    optional bias, and l2norm([cls | mean of the patch tokens]) — against fp64."""
+    g = torch.Generator().manual_seed(11)
+    B, N, D, T = 3, 362, 768, 5
+    tokens = torch.randn(B, N, D, generator=g)
+    key = torch.randn(T, 2 * D, generator=g)
+    bias = torch.randn(T, generator=g)
+    td, kd, bd = tokens.cuda(), key.cuda(), bias.cuda()
+    # (1) cls rows (stride N * D) x the first half of the keys, + bias
+    out = torch.empty(B, T, device="cuda")
+    check(lib, lib.rz_rows_dot(P(td), N * D, P(kd), 2 * D, P(bd), P(out), B, T, D, B, 0, T, 1, stream()))
+    ref = tokens[:, 0].double() @ key[:, :D].double().T + bias.double()
+    assert (out.double().cpu() - ref).abs().max().item() <= 2e-4
+    # (2) every token x the second half of the keys into (B, T, N)
+    sim = torch.full((B, T, N), float("nan"), device="cuda")
+    k2 = kd[:, D:]
+    check(lib, lib.rz_rows_dot(P(td), D, P(k2), 2 * D, None, P(sim), B * N, T, D, N, T * N, 1, N, stream()))
+    ref2 = torch.einsum("ind,jd->ijn", tokens.double(), key[:, D:].double())
+    assert torch.isfinite(sim).all() and (sim.double().cpu() - ref2).abs().max().item() <= 2e-4
+    # (3) image features
+    feat = torch.empty(B, 2 * D, device="cuda")
+    check(lib, lib.rz_image_features(P(td), N, B, N, D, P(feat), stream()))
+    torch.cuda.synchronize()
+    rf = torch.nn.functional.normalize(torch.cat([tokens[:, 0], tokens[:, 1:].mean(1)], 1).double(), dim=1)
+    assert (feat.double().cpu() - rf).abs().max().item() <= 2e-6
+    # bad arguments are refused, not launched
+    assert lib.rz_rows_dot(P(td), D, P(k2), 2 * D, None, P(sim), B * N, T, D + 2, N, T * N, 1, N, stream()) != 0
+    assert lib.rz_image_features(P(td), N, B, 1, D, P(feat), stream()) != 0
