@@ -349,6 +349,10 @@ class RadZeroModel:
         """out[m][n] = a[m] . b[n] (+ bias[n]) in fp32 through rz_rows_dot; `strides` = (group, row, column) strides of `out` for a transposed result."""
         m, k = a.shape
         nb = b.shape[0]
+        if a.dtype != torch.float32 or b.dtype != torch.float32 or a.stride(1) != 1 or b.stride(1) != 1 or b.shape[1] < k or m == 0:
+            raise ValueError("_rows_dot: fp32 operands with contiguous rows, b at least as wide as a")
+        if a.shape[0] == 1:                  # a one-row view reports an arbitrary row stride
+            a = a.reshape(1, k).contiguous()
         with torch.cuda.device(self._device):
             if out is None:
                 out = torch.empty((m, nb), dtype=torch.float32, device=self._device)
