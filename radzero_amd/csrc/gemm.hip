@@ -253,6 +253,7 @@ static hipError_t launch_gemm_t(int epi, const GemmArgs& g, hipStream_t s) {
     if ((epi == EPI_QKV || epi == EPI_QKV_LN) && !persistent_variant(variant)) return hipErrorInvalidValue;     // merged projection: persistent kernels only
     if ((epi == EPI_HEADS_LN || epi == EPI_VT_LN) && persistent_variant(variant)) variant = 1;  // its two halves: 128x128 kernel only
     if (epi > EPI_QKV && !persistent_variant(variant)) variant = 1;                              // fused-LayerNorm epilogues: those kernels
+    if (epi == EPI_PATCH_LN && persistent_variant(variant)) variant = 8;                          // round 4's epilogue: gemm8 only (the retired experiments never got it)
 #ifdef RZ_EXPERIMENTS
     if (variant == 12) {
         if (gemm_v12_ok(Traits<T>::kDType, epi, g)) return launch_gemm_v12(Traits<T>::kDType, epi, g, s);
