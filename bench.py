@@ -420,6 +420,106 @@ def text_encode_steady(model, device, sizes=((14, 6, 10), (64, 8, 32), (193, 6, 
     return out
 
 
+class CollectiveLog:
+    """What torch.distributed actually carried, read from the live process group: every collective entry point this process can
+    reach is wrapped with a counter (name, payload bytes) for the lifetime of the bench, and the log is cut into phases — the one-time
+    prompt exchange, the timed region's steps, the contract's barriers."""
+    NAMES = ("all_gather_into_tensor", "all_gather", "all_reduce", "gather", "broadcast", "reduce_scatter_tensor", "all_to_all_single",
+             "all_gather_object", "barrier")
+
+    def __init__(self):
+        self.calls, self.phase = [], "setup"
+        for name in self.NAMES:
+            fn = getattr(dist, name, None)
+            if fn is None:
+                continue
+            setattr(dist, name, self._wrap(name, fn))
+
+    def _wrap(self, name, fn):
+        def wrapped(*a, **k):
+            nbytes = max((int(t.numel() * t.element_size()) for t in a if torch.is_tensor(t)), default=0)     # the gathered / reduced buffer
+            self.calls.append((self.phase, name, nbytes))
+            return fn(*a, **k)
+        return wrapped
+
+    def count(self, phase, exclude=("barrier",)):
+        return sum(1 for ph, n, _ in self.calls if ph == phase and n not in exclude)
+
+    def bytes(self, phase, name):
+        return sum(b for ph, n, b in self.calls if ph == phase and n == name)
+
+
+def free_port():
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def launch_ranks(n, argv, child_cmd=None, grace_s=30.0):
+    """`python bench.py --gpus N` without a launcher around it: start N FRESH child processes, one rank per GPU (RANK / LOCAL_RANK /
+    WORLD_SIZE / MASTER_* in their environment — what torch.distributed.run would set), relay rank 0's JSON line, return the children's
+    worst exit code.  This parent never touches the GPU (no torch.cuda call, no HIP library load): a process that has initialised the GPU
+    must not fork / exec workers on this pool.  A failed rank is reported, never retried; once one rank has died the others get `grace_s`
+    to exit by themselves (their barrier will never complete) and are then terminated by PID.
+    `child_cmd` (tests: RZ_BENCH_CHILD_CMD, a JSON list) replaces `[sys.executable, bench.py]`."""
+    import subprocess
+    import threading
+    cmd = list(child_cmd) if child_cmd else [sys.executable, os.path.abspath(__file__)]
+    port = os.environ.get("MASTER_PORT") or str(free_port())
+    procs, lines = [], []
+
+    def relay(rank, pipe):
+        for raw in pipe:
+            line = raw.rstrip("\n")
+            if rank == 0 and line.startswith("{") and '"metric"' in line:
+                lines.append(line)
+            else:
+                print(f"[rank {rank}] {line}", file=sys.stderr, flush=True)
+
+    threads = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), GROUP_RANK="0",
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=port, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"),
+                   RZ_BENCH_LAUNCHED_BY="bench.py")
+        p = subprocess.Popen(cmd + list(argv), env=env, stdout=subprocess.PIPE, stderr=None, text=True, bufsize=1)
+        t = threading.Thread(target=relay, args=(r, p.stdout), daemon=True)
+        t.start()
+        procs.append(p)
+        threads.append(t)
+    codes = [None] * n
+    failed_at = None
+    while any(c is None for c in codes):
+        for r, p in enumerate(procs):
+            if codes[r] is None:
+                codes[r] = p.poll()
+                if codes[r] not in (None, 0) and failed_at is None:
+                    failed_at = time.time()
+                    print(f"[bench launcher] rank {r} exited with code {codes[r]}", file=sys.stderr, flush=True)
+        if failed_at is not None and time.time() - failed_at > grace_s:
+            for r, p in enumerate(procs):
+                if codes[r] is None:
+                    print(f"[bench launcher] terminating rank {r} (pid {p.pid}): another rank failed", file=sys.stderr, flush=True)
+                    p.terminate()
+                    try:
+                        p.wait(timeout=10)
+                    except subprocess.TimeoutExpired:
+                        p.kill()
+                    codes[r] = p.wait()
+        time.sleep(0.05)
+    for t in threads:
+        t.join(timeout=5)
+    worst = max((abs(c) for c in codes), default=0)
+    if worst == 0 and len(lines) != 1:
+        print(f"[bench launcher] expected ONE JSON line from rank 0, got {len(lines)}", file=sys.stderr, flush=True)
+        worst = 1
+    if worst == 0:
+        print(lines[0], flush=True)
+    else:
+        print(f"[bench launcher] exit codes by rank: {codes}", file=sys.stderr, flush=True)
+    return min(worst, 255)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -434,6 +534,7 @@ def main():
     ap.add_argument("--min-len", type=int, default=6)
     ap.add_argument("--max-len", type=int, default=10)
     ap.add_argument("--force-dist", action="store_true", help="rehearsal: initialise the RCCL process group even with one rank")
+    ap.add_argument("--launch", action="store_true", help="start the rank(s) as fresh child processes even for --gpus 1 (rehearsal of the N > 1 launcher on a one-GPU box; implied by --gpus N > 1 outside torch.distributed.run)")
     ap.add_argument("--host-pixels", action="store_true", help="measurement only (never the headline): fp32 pixels start in pinned host memory and cross PCIe inside every step, on a copy stream into a double buffer (overlapped with the previous step)")
     ap.add_argument("--raw-images", default=None, choices=["device", "host"], help="measurement only (never the headline): every step starts from raw uint16 2048x1760 images (resident in HBM / in pinned host memory) and runs the batched device preprocessing on a side stream")
     ap.add_argument("--no-overlap", action="store_true", help="A/B of the two input modes above: produce the inputs on the compute stream (the un-overlapped behaviour of round 2)")
@@ -451,6 +552,15 @@ def main():
     ap.add_argument("--gemm-raster", type=int, default=None, help="RZ_EXPERIMENTS=1 library only (gemm12.hip): tile order inside an XCD, 0 = 4 x tiles_n groups, S > 0 = slab walk with <= S n tiles per slab")
     args = ap.parse_args()
 
+    if (args.gpus > 1 or args.launch) and "WORLD_SIZE" not in os.environ:
+        # not under torch.distributed.run: launch the ranks ourselves, before anything in this process touches the GPU
+        child = os.environ.get("RZ_BENCH_CHILD_CMD")
+        if not child:
+            have = torch.cuda.device_count()          # counts devices without initialising the runtime
+            if have < args.gpus:
+                raise SystemExit(f"bench.py --gpus {args.gpus}: this node exposes {have} GPU(s)")
+        raise SystemExit(launch_ranks(args.gpus, sys.argv[1:], json.loads(child) if child else None))
+
     # HSA reads its environment at hsa_init, i.e. at the first torch.cuda call below: set these before anything touches the GPU
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -459,12 +569,13 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch multi-GPU runs with torch.distributed.run (one rank per GPU)")
+        raise SystemExit(f"bench.py --gpus {args.gpus} under WORLD_SIZE={world}: launch one rank per GPU (or run `python bench.py --gpus N`, which starts them)")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     use_dist = world > 1 or args.force_dist
+    clog = None
     if use_dist:
+        clog = CollectiveLog()
         dist.init_process_group(backend="nccl", device_id=device, rank=rank, world_size=world)
 
     from radzero_amd.modeling import RadZeroModel
@@ -498,11 +609,15 @@ def main():
 
     # one-time prompt encoding: sharded over ranks + ONE all_gather (RCCL over xGMI), then cached
     torch.cuda.synchronize()
+    if clog:
+        clog.phase = "prompt_exchange"
     t0 = time.time()
     text_features = sharded_text_features(lambda e: model.forward_text_model(e)["text_features_wo_l2_norm"], enc,
                                           feature_dim=cfg.hidden_size)
     torch.cuda.synchronize()
     text_ms = (time.time() - t0) * 1e3
+    if clog:
+        clog.phase = "setup"
     text_steady = text_encode_steady(model, device) if (rank == 0 and world == 1) else None
 
     main_maps_buf = torch.empty((B * T, S, S), dtype=torch.float32, device=device) if args.maps == "upsample" else None
@@ -531,14 +646,21 @@ def main():
         # HIP events (rz_profile_*) on the launch stream around the dominant kernel's launches only: ~110 event pairs per step for every
         # kernel would cost the timed region ~1 %
         model.profile(True, families=None if args.all_kernel_events else ("attn",))
+    if clog:
+        clog.phase = "timed_steps"
     t0 = time.perf_counter()
     for _ in range(args.steps):
         out = step()
     torch.cuda.synchronize()
+    own_elapsed = time.perf_counter() - t0          # this rank's K steps, before waiting for the slowest rank
+    if clog:
+        clog.phase = "closing_barrier"
     if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    if clog:
+        clog.phase = "after"
     prof = None
     fam_steps = args.steps
     if not args.no_kernel_events:
@@ -557,6 +679,12 @@ def main():
     if use_dist:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     elapsed = float(tmax.item())
+    rank_ips = None
+    if use_dist:
+        mine = torch.tensor([args.batch * args.steps / own_elapsed], dtype=torch.float64, device=device)
+        every = torch.empty((world,), dtype=torch.float64, device=device)
+        dist.all_gather_into_tensor(every, mine)
+        rank_ips = [round(float(v), 3) for v in every.tolist()]
     assert bool(torch.isfinite(out["logits"]).all())
 
     if rank == 0:
@@ -577,6 +705,22 @@ def main():
             "frac_of_mfma_peak_whole_path": round(ips * f_img / 1e12 / (PEAK_TFLOPS[args.dtype] * world), 4),
             "text_encode_once_ms": round(text_ms, 2),
         }
+        if use_dist:
+            # evidence of what the process group saw, read from the live group and the collective log — not declared
+            pg_world = dist.get_world_size()
+            try:
+                rccl_version = ".".join(str(v) for v in torch.cuda.nccl.version())
+            except Exception:
+                rccl_version = None
+            res["rccl"] = {"backend": dist.get_backend(), "world_size": pg_world, "rccl_version": rccl_version,
+                           "launched_by": os.environ.get("RZ_BENCH_LAUNCHED_BY") or ("torch.distributed.run" if "TORCHELASTIC_RUN_ID" in os.environ else "environment"),
+                           "prompt_exchange_collectives": clog.count("prompt_exchange"),
+                           "all_gather_bytes": clog.bytes("prompt_exchange", "all_gather_into_tensor"),
+                           "all_gather_note": f"ONE all_gather_into_tensor of ({-(-T // pg_world)} x {pg_world} ranks, {cfg.hidden_size}) fp32 prompt embeddings, before the timed region (bytes of the gathered table)",
+                           "data_path_collectives": clog.count("timed_steps"),
+                           "timed_region_barriers": sum(1 for ph, n, _ in clog.calls if ph == "closing_barrier" and n == "barrier"),
+                           "per_rank_images_per_s": {"min": min(rank_ips), "max": max(rank_ips), "all": rank_ips}}
+            assert res["n_gpus"] == pg_world
         if text_steady is not None:
             res["text_encode_steady_ms"] = text_steady
             res["text_encode_note"] = ("text_encode_once_ms = the FIRST call of the process (allocations, relative-position table, lazy module load); "

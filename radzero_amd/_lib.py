@@ -12,6 +12,7 @@ from concurrent.futures import ThreadPoolExecutor
 
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG_DIR, "csrc")
+EXP_SRC = os.path.join(PKG_DIR, "..", "tools", "experiments")     # retired experiments' sources: tools build only, never product
 # RZ_EXPERIMENTS=1: the TOOLS build (-DRZ_EXPERIMENTS: in-kernel stamp builds of gemm7 / gemm8, the retired attention shapes of rounds 1-2),
 # its own library and object directory; the product and every test use the plain build.
 EXPERIMENTS = os.environ.get("RZ_EXPERIMENTS") == "1"
@@ -19,7 +20,8 @@ LIB_PATH = os.environ.get("RZ_LIB_PATH") or os.path.join(PKG_DIR, "libradzero_hi
 SOURCES = ["gemm.hip", "gemm7.hip", "gemm8.hip", "attention.hip", "rowops.hip", "vlcabs.hip", "preprocess.hip", "api.hip"]
 if EXPERIMENTS:
     # retired GEMM experiments, never faster than gemm8 inside the step: gemm10 / gemm11 (round 3: other K loops), gemm12 (round 4: two
-    # 256x128 workgroups per CU so that epilogues overlap K loops; profiles/r04/gemm12_*.log)
+    # 256x128 workgroups per CU so that epilogues overlap K loops; profiles/r04/gemm12_*.log).  They live in tools/experiments/ (with the
+    # generated loops attention.hip's and gemm10.hip's experiment branches include) and are found through -I
     SOURCES += ["gemm10.hip", "gemm11.hip", "gemm12.hip"]
 # attention.hip: fmaxf chains on MFMA outputs fuse into v_max3_f32 without a canonicalising v_max each
 EXTRA_FLAGS = {"attention.hip": ["-fno-honor-nans"]}
@@ -30,12 +32,23 @@ RZ_F32, RZ_BF16, RZ_F16 = 0, 1, 2
 PROF_FAMILIES = ("attn", "gemm", "rowops", "vlcabs", "post")
 
 
+def _src_path(src: str) -> str:
+    p = os.path.join(CSRC, src)
+    return p if os.path.exists(p) or not EXPERIMENTS else os.path.join(EXP_SRC, src)
+
+
+def _all_deps() -> list:
+    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(PKG_DIR, "..", "include", "radzero_hip.h")]
+    if EXPERIMENTS and os.path.isdir(EXP_SRC):
+        deps += [os.path.join(EXP_SRC, f) for f in os.listdir(EXP_SRC)]
+    return deps
+
+
 def _needs_rebuild() -> bool:
     if not os.path.exists(LIB_PATH):
         return True
     t = os.path.getmtime(LIB_PATH)
-    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(PKG_DIR, "..", "include", "radzero_hip.h")]
-    return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
+    return any(os.path.getmtime(d) > t for d in _all_deps() if os.path.exists(d))
 
 
 def build(force: bool = False, verbose: bool = False) -> str:
@@ -64,14 +77,14 @@ def build(force: bool = False, verbose: bool = False) -> str:
 
 def _build_locked(obj_dir: str, verbose: bool, force: bool = False) -> str:
     flags = [f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "-Werror=uninitialized",
-             "-Werror=return-type"] + (["-DRZ_EXPERIMENTS"] if EXPERIMENTS else []) + os.environ.get("RZ_CXXFLAGS", "").split()   # RZ_CXXFLAGS: A/B builds of a tunable (with RZ_LIB_PATH)
+             "-Werror=return-type", f"-I{CSRC}"] + (["-DRZ_EXPERIMENTS", f"-I{EXP_SRC}"] if EXPERIMENTS else []) + os.environ.get("RZ_CXXFLAGS", "").split()   # RZ_CXXFLAGS: A/B builds of a tunable (with RZ_LIB_PATH)
     tag = f".{os.getpid()}.tmp"
 
     def cc(src):
         obj = os.path.join(obj_dir, src.replace(".hip", ".o"))
         if not force and os.path.exists(obj) and os.path.getmtime(obj) > _src_mtime(src):
             return obj                                   # unchanged translation unit: keep its object
-        cmd = [HIPCC, *flags, *EXTRA_FLAGS.get(src, []), "-c", os.path.join(CSRC, src), "-o", obj + tag]
+        cmd = [HIPCC, *flags, *EXTRA_FLAGS.get(src, []), "-c", _src_path(src), "-o", obj + tag]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"hipcc failed for {src}:\n{r.stderr}")
@@ -92,8 +105,7 @@ def _build_locked(obj_dir: str, verbose: bool, force: bool = False) -> str:
 
 def _src_mtime(src: str) -> float:
     """Newest mtime of a translation unit and every header it may include."""
-    deps = [os.path.join(CSRC, src)] + [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".h", ".inc"))]
-    deps.append(os.path.join(PKG_DIR, "..", "include", "radzero_hip.h"))
+    deps = [_src_path(src)] + [d for d in _all_deps() if d.endswith((".h", ".inc"))]
     return max(os.path.getmtime(d) for d in deps if os.path.exists(d))
 
 

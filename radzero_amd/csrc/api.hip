@@ -42,10 +42,13 @@ struct Options {
     int gemm_f32_mx;      // fp32 mode: 1 (default) = the split GEMMs' two correction terms run as one block-scaled fp8 MFMA (MX form, rz_common.h) for large batches; 2 = wherever the shape allows; 0 = three f16 planes
     int attn_f32_mx;      // fp32 mode, with the MX GEMM form: 1 (default) = the attention's P V correction terms as block-scaled fp8 MFMAs, scores at 22 bits; 2 = scores too; 0 = f16 planes
     int gemm_raster;      // gemm12.hip: tile order inside an XCD (GemmArgs::raster): 0 = 4 x tiles_n groups | S > 0 = slab walk, <= S n tiles per slab
+    int attn_f32_pv;      // fp32 mode: 1 = the attention's P V product on the hi planes alone (f16 P and V, row sums of the rounded P on the matrix pipe); 0 = with its correction terms ("f32_precision high")
+    int f32_drop;         // fp32 mode, ACCURACY ABLATION (tools/fp32_term_ablation.py; three-plane form): bit mask of product classes computed hi . hi only — 1 q|k projection, 2 V projection, 4 out-projection, 8 fc1, 16 fc2, 32 patch embedding; tools build also: 64 scores, 128 P (V keeps hi + lo)
 };
-Options g_opt = {0, 1, 0, 0, 0, 1, 1, 1, 0, 0, 1, 1, 1, 0};
+Options g_opt = {0, 1, 0, 0, 0, 1, 1, 1, 0, 0, 1, 1, 1, 0, 0, 0};
 const Options kInherit = {RZ_OPT_INHERIT, RZ_OPT_INHERIT, RZ_OPT_INHERIT, RZ_OPT_INHERIT, RZ_OPT_INHERIT, RZ_OPT_INHERIT, RZ_OPT_INHERIT,
-                          RZ_OPT_INHERIT, RZ_OPT_INHERIT, RZ_OPT_INHERIT, RZ_OPT_INHERIT, RZ_OPT_INHERIT, RZ_OPT_INHERIT, RZ_OPT_INHERIT};
+                          RZ_OPT_INHERIT, RZ_OPT_INHERIT, RZ_OPT_INHERIT, RZ_OPT_INHERIT, RZ_OPT_INHERIT, RZ_OPT_INHERIT, RZ_OPT_INHERIT,
+                          RZ_OPT_INHERIT, RZ_OPT_INHERIT};
 int* option_field(Options& o, const char* name) {
 #ifdef RZ_EXPERIMENTS      // measured, never a gain (profiles/NOTEBOOK.md): known to the tools build only; the product runs one pass, one stream
     if (!strcmp(name, "vision_chunk")) return &o.vision_chunk;
@@ -63,6 +66,8 @@ int* option_field(Options& o, const char* name) {
     if (!strcmp(name, "f32_split_guard")) return &o.f32_split_guard;
     if (!strcmp(name, "gemm_f32_mx")) return &o.gemm_f32_mx;
     if (!strcmp(name, "attn_f32_mx")) return &o.attn_f32_mx;
+    if (!strcmp(name, "attn_f32_pv")) return &o.attn_f32_pv;
+    if (!strcmp(name, "f32_drop")) return &o.f32_drop;
     return nullptr;
 }
 inline int pick(int own, int process_wide) { return own == RZ_OPT_INHERIT ? process_wide : own; }
@@ -165,6 +170,8 @@ struct rz_model {
     int o_gemm_raster() const { return pick(opt.gemm_raster, g_opt.gemm_raster); }
     int o_gemm_f32_mx() const { return pick(opt.gemm_f32_mx, g_opt.gemm_f32_mx); }
     int o_attn_f32_mx() const { return pick(opt.attn_f32_mx, g_opt.attn_f32_mx); }
+    int o_attn_f32_pv() const { return pick(opt.attn_f32_pv, g_opt.attn_f32_pv); }
+    int o_f32_drop() const { return pick(opt.f32_drop, g_opt.f32_drop); }
     bool o_gemm_f32_split() const { return pick(opt.gemm_f32_split, g_opt.gemm_f32_split) != 0 && !force_exact; }
     bool o_attn_f32_split() const { return pick(opt.attn_f32_split, g_opt.attn_f32_split) != 0 && !force_exact; }
     bool o_ln_fused() const { return pick(opt.ln_fused, g_opt.ln_fused) != 0; }
@@ -428,6 +435,7 @@ int gemm_f32_split(rz_model* m, int epi, GemmArgs g, int a_mode, bool out_split,
         }
     }
     if (!w3) return mx ? fail(RZ_ERR_STATE, "MX GEMM requested for a weight without an MX copy") : 0;
+    if (mx && m->o_f32_drop() != 0) return fail(RZ_ERR_STATE, "f32_drop (accuracy ablation) runs on the three-plane form: set gemm_f32_mx = 0");
     if (mx) {
         // MX form (rz_common.h): rows of 4 K bytes = 2 K f16-element units; A_SPLIT = already in that form (LayerNorm / attention / fc1
         // epilogue wrote it), A_F32 = split here (the patch embedding's im2col matrix)
@@ -464,7 +472,10 @@ int gemm_f32_split(rz_model* m, int epi, GemmArgs g, int a_mode, bool out_split,
         if (a_mode == A_F32) RZ_HIP(launch_split3((const float*)g.A, g.lda, a3, g.M, g.K, 0, g.ovf_flag, s));
         g.A = a3;
     }
-    g.W = w3; g.lda = g.ldw = 3 * (int64_t)g.K; g.K = 3 * g.K;
+    // accuracy ablation (option f32_drop): this product class on the hi planes alone = the first K of the 3 K columns
+    const int cls = epi == EPI_HEADS ? 1 : epi == EPI_VT ? 2 : epi == EPI_GELU ? 8 : epi == EPI_PATCH ? 32 : (g.K == m->F ? 16 : 4);
+    const bool hi_only = (m->o_f32_drop() & cls) != 0;
+    g.W = w3; g.lda = g.ldw = 3 * (int64_t)g.K; g.K = hi_only ? g.K : 3 * g.K;
     RZ_HIP(launch_gemm_split_f32out(epi, g, s, out_split));
     *done = true;
     return 0;
@@ -891,7 +902,10 @@ static int vision_forward_once(rz_handle_t m, const float* px, int B, int C, int
         const int mxo = m->o_gemm_f32_mx();
         const bool mxg = sp && mxo != 0 && m->mx_weights_ok && M % 256 == 0 && (mxo == 2 || M >= 256 * 64);
         const int mxa = mxg ? m->o_attn_f32_mx() : 0;                         // the attention's MX form rides on the GEMMs' (its ctx leaves in the MX form)
-        const int mx = mxg ? (1 | (mxa >= 1 ? 2 : 0) | (mxa >= 2 ? 4 : 0)) : 0;
+        // which of the attention's correction terms are dropped (flash_attn_split_kernel ABL): P V on the hi planes alone by default
+        const int drop = m->o_f32_drop();
+        const int attn_abl = (m->o_attn_f32_pv() != 0 && !(drop & 128) ? 1 : 0) | ((drop & 128) ? 2 : 0) | ((drop & 64) ? 4 : 0);
+        const int mx = mxg ? (1 | (mxa >= 1 && !(attn_abl & 1) ? 2 : 0) | (mxa >= 2 ? 4 : 0)) : 0;       // V^T needs no pair plane when P V runs on the hi planes alone
         const size_t ex = m->dt == RZ_F32 ? 6 : es;
         char* xn = (char*)m->xn.p + row0 * D * ex;
         char* qkb = (char*)m->qk.p + row0 * 2 * D * es;
@@ -993,10 +1007,10 @@ static int vision_forward_once(rz_handle_t m, const float* px, int B, int C, int
                 const char* kb = qb + (size_t)H * np * 64 * es;
                 if (sp)                                         // planes in (f16: k heads start H*np*64 ELEMENTS behind q), [hi | lo | hi] ctx out
                     RZ_HIP(launch_flash_attn_split_planes(qb, qb + (size_t)H * np * 64 * 2, vtb, ctxb, (int64_t)2 * H * np * 64, (int64_t)M * 2 * D, (int64_t)M * D,
-                                                          Bc, H, nv, np, (unsigned*)m->ovf.p, s, mx != 0, mxa));
+                                                          Bc, H, nv, np, (unsigned*)m->ovf.p, s, mx != 0, mxa, attn_abl));
                 else if (m->dt == RZ_F32 && m->o_attn_f32_split())      // hi/lo f16 planes of q, k, V^T live in `mid` (free between the QKV and fc1 GEMMs: 3/4 of it)
                     RZ_HIP(launch_flash_attn_f32_split((const float*)qb, (const float*)kb, (const float*)vtb, (float*)ctxb, mid, (int64_t)2 * H * np * 64,
-                                                       Bc, H, nv, np, (unsigned*)m->ovf.p, s));
+                                                       Bc, H, nv, np, (unsigned*)m->ovf.p, s, 0, (attn_abl & 1) != 0));
                 else
                     RZ_HIP(flash_attn(m->o_attn_variant(), m->dt, qb, kb, vtb, ctxb, (int64_t)2 * H * np * 64, Bc, H, nv, np, s));
             }
@@ -1357,7 +1371,7 @@ int rz_flash_attention_f32_split(const float* q, const float* k, const float* vt
                                  void* stream) {
     if (!q || !k || !vt || !ctx || !ws) return fail(RZ_ERR_INVALID, "rz_flash_attention_f32_split: null argument");
     if (n_pad % 128 || n_valid <= 0 || n_valid > n_pad) return fail(RZ_ERR_INVALID, "rz_flash_attention_f32_split: n_pad must be a multiple of 128 >= n_valid > 0");
-    RZ_HIP(launch_flash_attn_f32_split(q, k, vt, ctx, ws, (int64_t)H * n_pad * 64, B, H, n_valid, n_pad, nullptr, (hipStream_t)stream));
+    RZ_HIP(launch_flash_attn_f32_split(q, k, vt, ctx, ws, (int64_t)H * n_pad * 64, B, H, n_valid, n_pad, nullptr, (hipStream_t)stream, 0, g_opt.attn_f32_pv != 0));
     return 0;
 }
 
@@ -1365,7 +1379,7 @@ int rz_flash_attention_f32_mx(const float* q, const float* k, const float* vt, f
                               void* stream) {
     if (!q || !k || !vt || !ctx || !ws) return fail(RZ_ERR_INVALID, "rz_flash_attention_f32_mx: null argument");
     if (n_pad % 128 || n_valid <= 0 || n_valid > n_pad) return fail(RZ_ERR_INVALID, "rz_flash_attention_f32_mx: n_pad must be a multiple of 128 >= n_valid > 0");
-    RZ_HIP(launch_flash_attn_f32_split(q, k, vt, ctx, ws, (int64_t)H * n_pad * 64, B, H, n_valid, n_pad, nullptr, (hipStream_t)stream, g_opt.attn_f32_mx >= 2 ? 2 : 1));
+    RZ_HIP(launch_flash_attn_f32_split(q, k, vt, ctx, ws, (int64_t)H * n_pad * 64, B, H, n_valid, n_pad, nullptr, (hipStream_t)stream, g_opt.attn_f32_mx >= 2 ? 2 : 1, g_opt.attn_f32_pv != 0));
     return 0;
 }
 

@@ -845,7 +845,13 @@ __global__ __launch_bounds__(256, 1) void flash_attn_ks_kernel(const bf16_t* __r
 // 32 f16 MFMAs + 16 block-scaled ones per wave and 64-key tile instead of 96 f16 ones; same bytes staged, same LDS image.
 // MXA 1 = P V only (q and k keep their f16 lo planes: the scores stay at 22 bits — a score's error is EXPONENTIATED, and 4-bit correction
 // terms leave it at 2^-16 sum |q_d k_d|, harmless on small logits only), 2 = scores as well.
-template <int OUT_SPLIT, int MXA = 0>
+// ABL (round 5, which correction terms are DROPPED): bit 0 = P V as the single product v_hi . p_hi — both operands at f16's 11 bits, whose
+// rounding errors are independent per key and average down over the keys a row attends to (profiles/r05/fp32_term_ablation.log); the row sums
+// then run on the matrix pipe over the same rounded P (ones fragment, as flash_attn_kernel's LS), so the weights still sum to one exactly, V^T's
+// second plane is neither staged nor read (48 KB of LDS instead of 64) and the loop loses the P split (8 v_fma_mix + 8 converts per 8
+// probabilities) and 16 of its 80 MFMA units.  With bit 0, MXA 1 is meaningless: 0 = scores on f16 lo planes, 2 = scores on e4m3 pairs.
+// Bits 1 / 2 (accuracy ablations only, -DRZ_EXPERIMENTS): 2 = P hi only with V hi + lo (MXA 0), 4 = scores as k_hi . q_hi only.
+template <int OUT_SPLIT, int MXA = 0, int ABL = 0>
 __global__ __launch_bounds__(256, 2) void flash_attn_split_kernel(const f16_t* __restrict__ q, const f16_t* __restrict__ k,
                                                                   const f16_t* __restrict__ vT, void* __restrict__ ctx_out,
                                                                   int64_t qk_batch_stride, int64_t qk_lo_off, int64_t v_lo_off,
@@ -853,7 +859,12 @@ __global__ __launch_bounds__(256, 2) void flash_attn_split_kernel(const f16_t* _
     typedef f16x8 frag_t;
     constexpr int TILE = 64 * 128;                   // one plane of one 64-key tile
     constexpr int ES = 2;
-    __shared__ __attribute__((aligned(1024))) char lds[8 * TILE];   // K: [buf][plane], then V^T: [buf][plane]
+    constexpr bool PVH = (ABL & 1) != 0;             // P V = v_hi . p_hi, row sums on the matrix pipe
+    constexpr bool PH = (ABL & 2) != 0;              // P hi only, V hi + lo (f16 planes)
+    constexpr bool SH = (ABL & 4) != 0;              // scores k_hi . q_hi only
+    static_assert(!(PVH && MXA == 1) && !(PH && (MXA != 0 || PVH)), "see ABL");
+    constexpr int VPL = PVH ? 1 : 2;                 // V^T planes resident in LDS
+    __shared__ __attribute__((aligned(1024))) char lds[(4 + 2 * VPL) * TILE];   // K: [buf][plane], then V^T: [buf][plane]
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -907,7 +918,7 @@ __global__ __launch_bounds__(256, 2) void flash_attn_split_kernel(const f16_t* _
     }
     auto stage = [&](int t, int buf) {
         char* sk = lds + buf * 2 * TILE;
-        char* sv = lds + 4 * TILE + buf * 2 * TILE;
+        char* sv = lds + 4 * TILE + buf * VPL * TILE;
         const char* kt = kbase + (int64_t)t * (FA_KEYS * k_ld);
         const char* vt = vbase + (int64_t)t * (FA_KEYS * ES);
 #pragma unroll
@@ -919,19 +930,23 @@ __global__ __launch_bounds__(256, 2) void flash_attn_split_kernel(const f16_t* _
                 const char* vp = vt + pl * v_lo_b;
                 asm("" : "+s"(kp));
                 asm("" : "+s"(vp));
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(kp + kofs[i]),
-                                                 (__attribute__((address_space(3))) void*)(sk + pl * TILE + row8 * 128), 16, 0, 0);
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(vp + vofs[i]),
-                                                 (__attribute__((address_space(3))) void*)(sv + pl * TILE + row8 * 128), 16, 0, 0);
+                if (!(SH && pl == 1))
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(kp + kofs[i]),
+                                                     (__attribute__((address_space(3))) void*)(sk + pl * TILE + row8 * 128), 16, 0, 0);
+                if (pl < VPL)
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(vp + vofs[i]),
+                                                     (__attribute__((address_space(3))) void*)(sv + pl * TILE + row8 * 128), 16, 0, 0);
             }
     };
 
     f32x4 oacc[2][4], cinit[2];
     float mrow[2];
     f32x2 lrow2[2];                  // two lane-partial running sums per query row (packed adds)
+    [[maybe_unused]] f32x4 lacc[2];  // PVH: running row sums of the f16-rounded P, accumulated by the matrix pipe
+    [[maybe_unused]] const frag_t ones = pack8<f16_t>(1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f);
 #pragma unroll
     for (int a = 0; a < 2; ++a) {
-        mrow[a] = 0.f; lrow2[a] = (f32x2){0.f, 0.f};
+        mrow[a] = 0.f; lrow2[a] = (f32x2){0.f, 0.f}; lacc[a] = (f32x4){0.f, 0.f, 0.f, 0.f};
         cinit[a] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int c = 0; c < 4; ++c) oacc[a][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -943,7 +958,7 @@ __global__ __launch_bounds__(256, 2) void flash_attn_split_kernel(const f16_t* _
         constexpr bool FIRST = decltype(first_c)::value, MASK = decltype(mask_c)::value;
         const int buf = t & 1;
         const char* sk = lds + buf * 2 * TILE;
-        const char* sv = lds + 4 * TILE + buf * 2 * TILE;
+        const char* sv = lds + 4 * TILE + buf * VPL * TILE;
         auto load_k = [&](int pl, int ks, int kt) -> frag_t {
             return *reinterpret_cast<const frag_t*>(sk + pl * TILE + koff[ks] + (32 * (kt >> 1) + 4 * (kt & 1)) * 128);
         };
@@ -965,7 +980,8 @@ __global__ __launch_bounds__(256, 2) void flash_attn_split_kernel(const f16_t* _
             for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
                 for (int a = 0; a < 2; ++a) sacc[a][kt] = mma(kf[1][kt], qh[a][1], sacc[a][kt]);
-            if constexpr (MXA == 2) {
+            if constexpr (SH) {
+            } else if constexpr (MXA == 2) {
                 // the key's pair row [k_hi8 | k_lo8] against the query's [q_lo8 | q_hi8] (ql[a][0 / 1] hold its chunks lg and 4 + lg)
 #pragma unroll
                 for (int ks = 0; ks < 2; ++ks)
@@ -1037,7 +1053,7 @@ __global__ __launch_bounds__(256, 2) void flash_attn_split_kernel(const f16_t* _
                 const float alpha = __builtin_amdgcn_exp2f(-delta);
                 mrow[qt] += delta;
                 cinit[qt] -= delta;
-                lrow2[qt] *= alpha;
+                if constexpr (PVH) lacc[qt] *= alpha; else lrow2[qt] *= alpha;
 #pragma unroll
                 for (int kt = 0; kt < 4; ++kt) sacc[qt][kt] -= delta;
 #pragma unroll
@@ -1050,42 +1066,72 @@ __global__ __launch_bounds__(256, 2) void flash_attn_split_kernel(const f16_t* _
         // (row sums, two lane-partial sums per row), 4 v_cvt_pk_f16_f32, 8 v_fma_mix_f32 (p - f16(p) straight from the packed halves: the -1 is kept
         // opaque so that hipcc does not turn the fma back into convert + subtract) and, MXA, 4 + 4 fp8 converts, the 2^11 of the lo plane folded
         // into v_cvt_scalef32_pk_fp8_f32's scale operand.
-        float m1 = -1.0f;
+        [[maybe_unused]] float m1 = -1.0f;
         asm("" : "+s"(m1));
-        frag_t ph[2][2], pl[2][2];       // MXA: pl[qt][0] = [p_lo8 of the lane's 16 keys], pl[qt][1] = [p_hi8 ...] (16 bytes each)
+        frag_t ph[2][2];
+        [[maybe_unused]] frag_t pl[2][2];       // MXA: pl[qt][0] = [p_lo8 of the lane's 16 keys], pl[qt][1] = [p_hi8 ...] (16 bytes each)
 #pragma unroll
         for (int qt = 0; qt < 2; ++qt) {
-            uint32_t w8[2][4];           // MXA: [lo8 | hi8][kk * 2 + half]
+            [[maybe_unused]] uint32_t w8[2][4];           // MXA: [lo8 | hi8][kk * 2 + half]
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk) {
-                float pv[8], pr[8];
+                float pv[8];
+                [[maybe_unused]] float pr[8];
 #pragma unroll
                 for (int i = 0; i < 8; ++i) pv[i] = __builtin_amdgcn_exp2f(sacc[qt][2 * kk + (i >> 2)][i & 3]);
 #pragma unroll
                 // plain adds into two lane-partial sums: beside MFMAs a v_pk_add_f32 costs ~3 issue slots (MI355X_MICROARCH.md constants table; measured
                 // here: 94.2 -> 88.5 ms of attention per fp32 step); the empty asm keeps hipcc from SLP-packing them back
-                for (int i = 0; i < 4; ++i) { lrow2[qt][0] += pv[2 * i]; lrow2[qt][1] += pv[2 * i + 1]; }
-                asm volatile("" : "+v"(lrow2[qt][0]), "+v"(lrow2[qt][1]));
+                for (int i = 0; i < 4; ++i) { if constexpr (!PVH) { lrow2[qt][0] += pv[2 * i]; lrow2[qt][1] += pv[2 * i + 1]; } }
+                if constexpr (!PVH) asm volatile("" : "+v"(lrow2[qt][0]), "+v"(lrow2[qt][1]));
                 ph[qt][kk] = pack8<f16_t>(pv[0], pv[1], pv[2], pv[3], pv[4], pv[5], pv[6], pv[7]);
+                if constexpr (!(PVH || PH)) {                // the second plane of P
 #pragma unroll
-                for (int i = 0; i < 8; ++i) pr[i] = __builtin_fmaf((float)ph[qt][kk][i], m1, pv[i]);
-                if constexpr (MXA) {
-                    // P <= 2^8 (FA_DEFER): hi8 = e4m3(p) with scale 1, lo8 = e4m3((p - f16(p)) 2^11) with scale 2^-11: both within +-448
-                    w8[0][kk * 2 + 0] = cvt4_e4m3_scaled(pr[0], pr[1], pr[2], pr[3], MX_CVT_SCALE_2P11);
-                    w8[0][kk * 2 + 1] = cvt4_e4m3_scaled(pr[4], pr[5], pr[6], pr[7], MX_CVT_SCALE_2P11);
-                    w8[1][kk * 2 + 0] = cvt4_e4m3(pv[0], pv[1], pv[2], pv[3]);
-                    w8[1][kk * 2 + 1] = cvt4_e4m3(pv[4], pv[5], pv[6], pv[7]);
-                } else {
-                    pl[qt][kk] = pack8<f16_t>(pr[0], pr[1], pr[2], pr[3], pr[4], pr[5], pr[6], pr[7]);
+                    for (int i = 0; i < 8; ++i) pr[i] = __builtin_fmaf((float)ph[qt][kk][i], m1, pv[i]);
+                    if constexpr (MXA) {
+                        // P <= 2^8 (FA_DEFER): hi8 = e4m3(p) with scale 1, lo8 = e4m3((p - f16(p)) 2^11) with scale 2^-11: both within +-448
+                        w8[0][kk * 2 + 0] = cvt4_e4m3_scaled(pr[0], pr[1], pr[2], pr[3], MX_CVT_SCALE_2P11);
+                        w8[0][kk * 2 + 1] = cvt4_e4m3_scaled(pr[4], pr[5], pr[6], pr[7], MX_CVT_SCALE_2P11);
+                        w8[1][kk * 2 + 0] = cvt4_e4m3(pv[0], pv[1], pv[2], pv[3]);
+                        w8[1][kk * 2 + 1] = cvt4_e4m3(pv[4], pv[5], pv[6], pv[7]);
+                    } else {
+                        pl[qt][kk] = pack8<f16_t>(pr[0], pr[1], pr[2], pr[3], pr[4], pr[5], pr[6], pr[7]);
+                    }
                 }
             }
-            if constexpr (MXA) {
+            if constexpr (MXA != 0 && !PVH && !PH) {
                 pl[qt][0] = __builtin_bit_cast(frag_t, (u32x4){w8[0][0], w8[0][1], w8[0][2], w8[0][3]});
                 pl[qt][1] = __builtin_bit_cast(frag_t, (u32x4){w8[1][0], w8[1][1], w8[1][2], w8[1][3]});
             }
         }
         // ---- O^T += V^T P^T:  vh.ph + vh.pl + vl.ph ----
-        if constexpr (MXA) {
+        if constexpr (PVH) {
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                frag_t vf[4];
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) vf[dt] = load_v(0, kk, dt);
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+                    for (int a = 0; a < 2; ++a) oacc[a][dt] = mma(vf[dt], ph[a][kk], oacc[a][dt]);
+#pragma unroll
+                for (int a = 0; a < 2; ++a) lacc[a] = mma(ones, ph[a][kk], lacc[a]);
+            }
+        } else if constexpr (PH) {
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                for (int pln = 0; pln < 2; ++pln) {
+                    frag_t vf[4];
+#pragma unroll
+                    for (int dt = 0; dt < 4; ++dt) vf[dt] = load_v(pln, kk, dt);
+#pragma unroll
+                    for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+                        for (int a = 0; a < 2; ++a) oacc[a][dt] = mma(vf[dt], ph[a][kk], oacc[a][dt]);
+                }
+        } else if constexpr (MXA) {
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk) {
                 frag_t vf[4];
@@ -1150,9 +1196,14 @@ __global__ __launch_bounds__(256, 2) void flash_attn_split_kernel(const f16_t* _
 
 #pragma unroll
     for (int qt = 0; qt < 2; ++qt) {
-        float l = lrow2[qt][0] + lrow2[qt][1];
-        l += __shfl_xor(l, 16, 64);
-        l += __shfl_xor(l, 32, 64);
+        float l;
+        if constexpr (PVH) {
+            l = lacc[qt][0];            // every row of the ones tile holds the same sum: no cross-lane step
+        } else {
+            l = lrow2[qt][0] + lrow2[qt][1];
+            l += __shfl_xor(l, 16, 64);
+            l += __shfl_xor(l, 32, 64);
+        }
         const float inv = 1.0f / l;
         const int qrow = q0 + qt * 16 + l15;
         const int D = H * 64;
@@ -1228,35 +1279,36 @@ size_t flash_attn_split_workspace_bytes(int B, int H, int n_pad) { return (size_
 // fp32 q, k ([B][H][n_pad][64] each, batch stride qk_batch_stride) and V^T ([B][H][64][n_pad]) -> fp32 ctx through the split kernel.
 // split_ws (flash_attn_split_workspace_bytes): planes q_hi q_lo k_hi k_lo v_hi v_lo, each B*H*n_pad*64 f16.
 hipError_t launch_flash_attn_f32_split(const float* q, const float* k, const float* vT, float* ctx, void* split_ws, int64_t qk_batch_stride,
-                                       int B, int H, int n_valid, int n_pad, unsigned* ovf_flag, hipStream_t s, int mxa) {
+                                       int B, int H, int n_valid, int n_pad, unsigned* ovf_flag, hipStream_t s, int mxa, int pv_hi) {
     if (n_pad % FA_QROWS || n_valid <= 0 || n_valid > n_pad || B <= 0 || H <= 0 || !split_ws) return hipErrorInvalidValue;
     const int64_t per = (int64_t)H * n_pad * 64, n = (int64_t)B * per;
     f16_t* q_hi = reinterpret_cast<f16_t*>(split_ws);
     f16_t* k_hi = q_hi + 2 * n;
     f16_t* v_hi = q_hi + 4 * n;
     const dim3 sgrid(256, B);
-    if (mxa) {
-        if (n_pad % 64) return hipErrorInvalidValue;
-        if (mxa == 2) {
-            hipLaunchKernelGGL(split_mxa_kernel, sgrid, dim3(256), 0, s, q, qk_batch_stride, q_hi, (char*)(q_hi + n), per / 4, 0, 64, ovf_flag);
-            hipLaunchKernelGGL(split_mxa_kernel, sgrid, dim3(256), 0, s, k, qk_batch_stride, k_hi, (char*)(k_hi + n), per / 4, 1, 64, ovf_flag);
-        } else {
-            hipLaunchKernelGGL(split_f16_kernel, sgrid, dim3(256), 0, s, q, qk_batch_stride, q_hi, q_hi + n, per / 4, ovf_flag);
-            hipLaunchKernelGGL(split_f16_kernel, sgrid, dim3(256), 0, s, k, qk_batch_stride, k_hi, k_hi + n, per / 4, ovf_flag);
-        }
-        hipLaunchKernelGGL(split_mxa_kernel, sgrid, dim3(256), 0, s, vT, per, v_hi, (char*)(v_hi + n), per / 4, 2, n_pad, ovf_flag);
-        const int nq = n_pad / FA_QROWS;
-        dim3 grid(((B * H * nq + 7) / 8) * 8), block(256);
-        if (mxa == 2) hipLaunchKernelGGL((flash_attn_split_kernel<0, 2>), grid, block, 0, s, q_hi, k_hi, v_hi, (void*)ctx, per, n, n, B, H, n_valid, n_pad, ovf_flag);
-        else hipLaunchKernelGGL((flash_attn_split_kernel<0, 1>), grid, block, 0, s, q_hi, k_hi, v_hi, (void*)ctx, per, n, n, B, H, n_valid, n_pad, ovf_flag);
-        return hipGetLastError();
+    if (pv_hi && mxa == 1) mxa = 0;               // P V on the hi planes alone: only the scores' form is left to choose
+    if (mxa && n_pad % 64) return hipErrorInvalidValue;
+    if (mxa == 2) {
+        hipLaunchKernelGGL(split_mxa_kernel, sgrid, dim3(256), 0, s, q, qk_batch_stride, q_hi, (char*)(q_hi + n), per / 4, 0, 64, ovf_flag);
+        hipLaunchKernelGGL(split_mxa_kernel, sgrid, dim3(256), 0, s, k, qk_batch_stride, k_hi, (char*)(k_hi + n), per / 4, 1, 64, ovf_flag);
+    } else {
+        hipLaunchKernelGGL(split_f16_kernel, sgrid, dim3(256), 0, s, q, qk_batch_stride, q_hi, q_hi + n, per / 4, ovf_flag);
+        hipLaunchKernelGGL(split_f16_kernel, sgrid, dim3(256), 0, s, k, qk_batch_stride, k_hi, k_hi + n, per / 4, ovf_flag);
     }
-    hipLaunchKernelGGL(split_f16_kernel, sgrid, dim3(256), 0, s, q, qk_batch_stride, q_hi, q_hi + n, per / 4, ovf_flag);
-    hipLaunchKernelGGL(split_f16_kernel, sgrid, dim3(256), 0, s, k, qk_batch_stride, k_hi, k_hi + n, per / 4, ovf_flag);
-    hipLaunchKernelGGL(split_f16_kernel, sgrid, dim3(256), 0, s, vT, per, v_hi, v_hi + n, per / 4, ovf_flag);
+    if (mxa && !pv_hi) hipLaunchKernelGGL(split_mxa_kernel, sgrid, dim3(256), 0, s, vT, per, v_hi, (char*)(v_hi + n), per / 4, 2, n_pad, ovf_flag);
+    else hipLaunchKernelGGL(split_f16_kernel, sgrid, dim3(256), 0, s, vT, per, v_hi, v_hi + n, per / 4, ovf_flag);
     const int nq = n_pad / FA_QROWS;
     dim3 grid(((B * H * nq + 7) / 8) * 8), block(256);
-    hipLaunchKernelGGL(flash_attn_split_kernel<0>, grid, block, 0, s, q_hi, k_hi, v_hi, (void*)ctx, per, n, n, B, H, n_valid, n_pad, ovf_flag);
+#define RZ_FAS0(MX, AB) hipLaunchKernelGGL((flash_attn_split_kernel<0, MX, AB>), grid, block, 0, s, q_hi, k_hi, v_hi, (void*)ctx, per, n, n, B, H, n_valid, n_pad, ovf_flag)
+    switch (mxa * 10 + (pv_hi ? 1 : 0)) {
+        case 0: RZ_FAS0(0, 0); break;
+        case 1: RZ_FAS0(0, 1); break;
+        case 10: RZ_FAS0(1, 0); break;
+        case 20: RZ_FAS0(2, 0); break;
+        case 21: RZ_FAS0(2, 1); break;
+        default: return hipErrorInvalidValue;
+    }
+#undef RZ_FAS0
     return hipGetLastError();
 }
 
@@ -1264,22 +1316,31 @@ hipError_t launch_flash_attn_f32_split(const float* q, const float* k, const flo
 // with batch stride qk_batch_stride, lo planes qk_lo_off / v_lo_off elements behind the hi planes; ctx3 = [rows][3 * H * 64] f16.
 hipError_t launch_flash_attn_split_planes(const void* q_hi, const void* k_hi, const void* v_hi, void* ctx3, int64_t qk_batch_stride,
                                           int64_t qk_lo_off, int64_t v_lo_off, int B, int H, int n_valid, int n_pad, unsigned* ovf_flag, hipStream_t s, int mx_out,
-                                          int mxa) {
+                                          int mxa, int abl) {
     if (n_pad % FA_QROWS || n_valid <= 0 || n_valid > n_pad || B <= 0 || H <= 0 || (mxa && !mx_out)) return hipErrorInvalidValue;
+    if ((abl & 1) && mxa == 1) mxa = 0;           // P V on the hi planes alone: the e4m3 pair plane of V^T (if any) is not read
     const int nq = n_pad / FA_QROWS;
     dim3 grid(((B * H * nq + 7) / 8) * 8), block(256);
-    if (mxa == 2)
-        hipLaunchKernelGGL((flash_attn_split_kernel<2, 2>), grid, block, 0, s, (const f16_t*)q_hi, (const f16_t*)k_hi, (const f16_t*)v_hi, ctx3,
-                           qk_batch_stride, qk_lo_off, v_lo_off, B, H, n_valid, n_pad, ovf_flag);
-    else if (mxa)
-        hipLaunchKernelGGL((flash_attn_split_kernel<2, 1>), grid, block, 0, s, (const f16_t*)q_hi, (const f16_t*)k_hi, (const f16_t*)v_hi, ctx3,
-                           qk_batch_stride, qk_lo_off, v_lo_off, B, H, n_valid, n_pad, ovf_flag);
-    else if (mx_out)
-        hipLaunchKernelGGL(flash_attn_split_kernel<2>, grid, block, 0, s, (const f16_t*)q_hi, (const f16_t*)k_hi, (const f16_t*)v_hi, ctx3,
-                           qk_batch_stride, qk_lo_off, v_lo_off, B, H, n_valid, n_pad, ovf_flag);
-    else
-        hipLaunchKernelGGL(flash_attn_split_kernel<1>, grid, block, 0, s, (const f16_t*)q_hi, (const f16_t*)k_hi, (const f16_t*)v_hi, ctx3,
-                           qk_batch_stride, qk_lo_off, v_lo_off, B, H, n_valid, n_pad, ovf_flag);
+#define RZ_FAS(OS, MX, AB) hipLaunchKernelGGL((flash_attn_split_kernel<OS, MX, AB>), grid, block, 0, s, (const f16_t*)q_hi, (const f16_t*)k_hi, (const f16_t*)v_hi, \
+                                              ctx3, qk_batch_stride, qk_lo_off, v_lo_off, B, H, n_valid, n_pad, ovf_flag)
+    const int os = mx_out ? 2 : 1;
+    const int key = os * 100 + mxa * 10 + abl;
+    switch (key) {
+        case 100: RZ_FAS(1, 0, 0); break;
+        case 101: RZ_FAS(1, 0, 1); break;
+        case 200: RZ_FAS(2, 0, 0); break;
+        case 201: RZ_FAS(2, 0, 1); break;
+        case 210: RZ_FAS(2, 1, 0); break;
+        case 220: RZ_FAS(2, 2, 0); break;
+        case 221: RZ_FAS(2, 2, 1); break;
+#ifdef RZ_EXPERIMENTS                      // accuracy ablations (tools/fp32_term_ablation.py): three-plane producers only
+        case 102: RZ_FAS(1, 0, 2); break;
+        case 104: RZ_FAS(1, 0, 4); break;
+        case 105: RZ_FAS(1, 0, 5); break;
+#endif
+        default: return hipErrorInvalidValue;
+    }
+#undef RZ_FAS
     return hipGetLastError();
 }
 

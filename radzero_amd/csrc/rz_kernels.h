@@ -80,10 +80,10 @@ hipError_t launch_gemm_v7_mx(int epi, const GemmArgs& g, int out_kind, hipStream
 // q/k of image b start at q + b*qk_batch_stride (elements), heads contiguous ([H][Npad][64]).
 size_t flash_attn_split_workspace_bytes(int B, int H, int n_pad);
 hipError_t launch_flash_attn_f32_split(const float* q, const float* k, const float* vT, float* ctx, void* split_ws, int64_t qk_batch_stride,
-                                       int B, int H, int n_valid, int n_pad, unsigned* ovf_flag, hipStream_t s, int mxa = 0);   // mxa: correction terms as block-scaled e4m3 MFMAs
+                                       int B, int H, int n_valid, int n_pad, unsigned* ovf_flag, hipStream_t s, int mxa = 0, int pv_hi = 0);   // mxa: correction terms as block-scaled e4m3 MFMAs
 hipError_t launch_flash_attn_split_planes(const void* q_hi, const void* k_hi, const void* v_hi, void* ctx3, int64_t qk_batch_stride,
                                           int64_t qk_lo_off, int64_t v_lo_off, int B, int H, int n_valid, int n_pad, unsigned* ovf_flag, hipStream_t s,
-                                          int mx_out = 0, int mxa = 0);      // mx_out: ctx in the MX form (4 bytes per element) instead of [hi | lo | hi] f16;
+                                          int mx_out = 0, int mxa = 0, int abl = 0);      // mx_out: ctx in the MX form (4 bytes per element) instead of [hi | lo | hi] f16;
                                                                              // mxa: the second planes are e4m3 pair planes (attention.hip "MXA")
 hipError_t launch_flash_attn(int dtype, const void* q, const void* k, const void* vT, void* ctx,
                              int64_t qk_batch_stride, int B, int H, int n_valid, int n_pad, int waves, hipStream_t s);

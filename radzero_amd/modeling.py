@@ -660,6 +660,23 @@ class RadZeroModel:
             self._grids.clear()
             self._reserved = (0, 0, 0, 0)
 
+    F32_PRECISIONS = {"high": {"attn_f32_pv": 0}, "fast": {"attn_f32_pv": 1}}
+
+    def set_f32_precision(self, level: str) -> None:
+        """fp32 (1e-3) mode only: which correction terms the split products keep (include/radzero_hip.h "attn_f32_pv";
+        profiles/r05/fp32_term_ablation.log).  "high" (default): every product at 22 bits — 6.5e-5 from the reference on the goldens,
+        3e-5 on the outlier-channel checkpoint.  "fast": the attention's P V product on the f16 hi planes alone — 3.1e-4 on the goldens,
+        but 1.2e-3 on the outlier-channel checkpoint (outside the 1e-3 contract there), 19 % more images per second."""
+        if level not in self.F32_PRECISIONS:
+            raise ValueError(f"f32_precision {level!r}: 'high' or 'fast'")
+        for k, v in self.F32_PRECISIONS[level].items():
+            self.set_model_option(k, v)
+
+    def guard_reruns(self) -> int:
+        """fp32 mode: forwards repeated on the exact-fp32 kernels because a value left the f16 planes' range (a checkpoint that trips the
+        guard on every forward runs at a quarter of the speed: the batch driver warns once, bench.py prints the count)."""
+        return self.get_model_option("f32_split_guard_reruns")
+
     def get_model_option(self, name: str) -> int:
         v = ctypes.c_int(0)
         _lib.check(self._lib.rz_get_model_option(self._h, name.encode(), ctypes.byref(v)), "rz_get_model_option")

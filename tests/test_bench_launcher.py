@@ -1,0 +1,63 @@
+"""`python bench.py --gpus N` outside torch.distributed.run starts its own ranks: the launcher branch is driven here
+with a stub child (no GPU, no torch.cuda call in the parent)."""
+import json
+import os
+import subprocess
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+STUB = [sys.executable, os.path.join(ROOT, "tests", "bench_stub_child.py")]
+
+
+def _run(extra, timeout=120, env_extra=None):
+    env = dict(os.environ, RZ_BENCH_CHILD_CMD=json.dumps(STUB))
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    env.update(env_extra or {})
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *extra], capture_output=True, text=True, timeout=timeout, env=env)
+
+
+def test_launcher_starts_n_ranks_and_relays_one_json_line():
+    r = _run(["--gpus", "4", "--steps", "3", "--warmup", "1"])
+    assert r.returncode == 0, r.stderr
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, r.stdout                     # ONE JSON line on stdout, everything else on stderr
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 4 and rec["argv"] == ["--gpus", "4", "--steps", "3", "--warmup", "1"]
+    assert rec["ipc"] == os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0") and rec["launched_by"] == "bench.py"
+    seen = sorted(l for l in r.stderr.splitlines() if "stub rank" in l)
+    assert [l.split("stub rank ")[1].split(" ")[0] for l in seen] == ["0/4", "1/4", "2/4", "3/4"], r.stderr
+    assert len({l.split(" port ")[1].split(" ")[0] for l in seen}) == 1            # one rendezvous port for all ranks
+    assert all(" addr 127.0.0.1 " in l for l in seen)
+    assert all(f"local {i} " in seen[i] for i in range(4))
+
+
+def test_launcher_reports_a_failed_rank_and_does_not_retry():
+    t0 = time.time()
+    r = _run(["--gpus", "2"], env_extra={"RZ_STUB_FAIL": "1"})
+    assert r.returncode == 3, (r.returncode, r.stderr)
+    assert r.stdout.strip() == ""                        # no bench line from a run with a failed rank
+    assert "rank 1 exited with code 3" in r.stderr and r.stderr.count("stub rank 1/2") == 1
+    assert time.time() - t0 < 60
+
+
+def test_launcher_terminates_ranks_left_waiting_for_a_dead_one():
+    src = f"import bench, sys; sys.exit(bench.launch_ranks(2, [], child_cmd={STUB!r}, grace_s=1.0))"
+    t0 = time.time()
+    r = subprocess.run([sys.executable, "-c", src], capture_output=True, text=True, timeout=120, cwd=ROOT,
+                       env=dict(os.environ, RZ_STUB_FAIL="0", RZ_STUB_HANG="1"))
+    assert r.returncode != 0 and "terminating rank 1" in r.stderr, r.stderr
+    assert time.time() - t0 < 60
+
+
+def test_single_rank_through_the_launcher():
+    r = _run(["--gpus", "1", "--launch", "--force-dist"])
+    assert r.returncode == 0, r.stderr
+    assert json.loads(r.stdout.strip())["n_gpus"] == 1
+
+
+def test_gpus_flag_must_match_world_size():
+    env = dict(os.environ, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4"], capture_output=True, text=True, timeout=120, env=env)
+    assert r.returncode != 0 and "WORLD_SIZE=2" in r.stderr

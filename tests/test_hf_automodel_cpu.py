@@ -1,0 +1,69 @@
+"""The AutoModel surface without a GPU (README.md:72-89): a directory in the reference's save_pretrained layout,
+after radzero_amd.hf.export_auto_map, dispatches `AutoConfig` / `AutoModel.from_pretrained(dir, trust_remote_code=True, ...)` to the HIP
+classes in a FRESH interpreter that never imported radzero_amd itself — the call then stops where the product must stop on a box
+without a HIP device: loudly, with no CPU fallback."""
+import json
+import os
+import shutil
+import subprocess
+import sys
+
+from conftest import GOLDEN_DIR, ROOT
+
+CHILD = r"""
+import sys, torch
+from transformers import AutoConfig, AutoModel
+d = sys.argv[1]
+assert "radzero_amd" not in sys.modules
+c = AutoConfig.from_pretrained(d, trust_remote_code=True)
+print("CONFIG", type(c).__name__, c.model_type, sorted(c.auto_map))
+try:
+    AutoModel.from_pretrained(d, trust_remote_code=True, torch_dtype=torch.float32, device_map=torch.device("cuda"))
+    print("MODEL built")
+except RuntimeError as e:
+    print("MODEL RuntimeError:", e)
+"""
+
+
+def _layout(tmp_path):
+    from radzero_amd.checkpoint import save_checkpoint
+    from radzero_amd.config import RadZeroConfig
+    from radzero_amd.weights import make_state_dict
+    keys = json.load(open(os.path.join(GOLDEN_DIR, "hf_layout", "keys.json")))
+    cfg = RadZeroConfig(**keys["radzero_config"])
+    src = tmp_path / "ref"
+    src.mkdir()
+    shutil.copy(os.path.join(GOLDEN_DIR, "hf_layout", "config.json"), src / "config.json")
+    save_checkpoint(make_state_dict(cfg, keys["weights_seed"]), str(src))
+    return cfg, src
+
+
+def test_export_auto_map_and_dispatch_in_a_fresh_interpreter(tmp_path):
+    from radzero_amd.hf import AUTO_MAP, MODEL_TYPE, export_auto_map
+    cfg, src = _layout(tmp_path)
+    before = open(src / "config.json").read()
+    dst = export_auto_map(str(src), str(tmp_path / "local"))
+    assert open(src / "config.json").read() == before
+    written = json.load(open(os.path.join(dst, "config.json")))
+    assert written["auto_map"] == AUTO_MAP and written["model_type"] == MODEL_TYPE
+    assert written["vision_config"] == json.loads(before)["vision_config"]           # everything else as the reference wrote it
+    assert os.path.islink(os.path.join(dst, "model.safetensors"))
+    env = dict(os.environ, PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""), HF_HOME=str(tmp_path / "hf"),
+               HF_MODULES_CACHE=str(tmp_path / "hf" / "modules"), HF_HUB_OFFLINE="1")
+    r = subprocess.run([sys.executable, "-c", CHILD, dst], capture_output=True, text=True, timeout=600, env=env, cwd=str(tmp_path))
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "CONFIG RadZeroHFConfig radzero_hip ['AutoConfig', 'AutoModel']" in r.stdout, r.stdout
+    import torch
+    if not torch.cuda.is_available():
+        assert "MODEL RuntimeError: no HIP device visible" in r.stdout, r.stdout     # reached RadZeroModel.__init__: no fallback
+
+
+def test_hf_config_gives_the_kernels_config(tmp_path):
+    from radzero_amd.checkpoint import load_checkpoint
+    from radzero_amd.hf import RadZeroHFConfig, export_auto_map
+    from transformers import AutoConfig
+    cfg, src = _layout(tmp_path)
+    export_auto_map(str(src))                                  # in place
+    c = AutoConfig.from_pretrained(str(src))                   # model_type is registered by importing radzero_amd.hf: no remote code needed
+    assert isinstance(c, RadZeroHFConfig)
+    assert c.to_radzero(load_checkpoint(str(src))) == cfg

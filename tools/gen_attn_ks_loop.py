@@ -1,4 +1,4 @@
-"""Generate radzero_amd/csrc/attn_ks_loop.inc: the hot loop of the key-split flash-attention kernel (attention.hip,
+"""Generate tools/experiments/attn_ks_loop.inc: the hot loop of the key-split flash-attention kernel (attention.hip,
 flash_attn_ks_kernel) as inline-asm text.  Run:  python tools/gen_attn_ks_loop.py   (writes the .inc; commit it).
 
 Why generated: one wave per SIMD owns 128 query rows and half of every 64-key tile (~450 live registers), so nothing but the wave's own
@@ -33,7 +33,7 @@ after the last iteration: its P3.  Tiles past the last one are staged clamped to
 import os
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-OUT = os.path.join(ROOT, "radzero_amd", "csrc", "attn_ks_loop.inc")
+OUT = os.path.join(ROOT, "tools", "experiments", "attn_ks_loop.inc")
 
 NBUF, BUF = 5, 16384
 S_K, S_V, S_T, S_TS, S_DB, S_KB, S_VB, S_CNT, S_IK, S_IV = 64, 66, 68, 70, 71, 72, 73, 74, 75, 76

@@ -1,4 +1,4 @@
-"""Generate radzero_amd/csrc/gemm10_kloop.inc: the K loop of the 4-wave persistent GEMM (gemm10.hip) as inline-asm text.
+"""Generate tools/experiments/gemm10_kloop.inc: the K loop of the 4-wave persistent GEMM (gemm10.hip) as inline-asm text.
 
 Why generated: the loop is 4 x 128 MFMAs with hand-placed LDS reads / LDS-DMA issues and asm-owned registers (256 accumulators
 in a[0:255], 128 fragment registers in v[128:255]); hipcc cannot be made to keep that allocation, and nobody
@@ -17,7 +17,7 @@ See gemm10.hip for the ordering argument (RAW / WAR) and the operand list.
 import os
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-OUT = os.path.join(ROOT, "radzero_amd", "csrc", "gemm10_kloop.inc")
+OUT = os.path.join(ROOT, "tools", "experiments", "gemm10_kloop.inc")
 
 GLDS_EVERY = int(os.environ.get('RZ_V10_GLDS_EVERY', '4'))   # one LDS-DMA piece per this many MFMAs of k-step 1 (2: bunched in its first half; 4: spread over all of it)
 ABL = set(os.environ.get('RZ_V10_ABLATE', '').split(','))     # timing ablations (WRONG results): noglds, nowait, nords, nobar

@@ -165,7 +165,7 @@ hipError_t launch_flash_attn(int dtype, const void* q, const void* k, const void
     return hipSuccess;
 }
 size_t flash_attn_split_workspace_bytes(int B, int H, int n_pad) { return (size_t)3 * B * H * n_pad * 64 * 4; }      // attention.hip
-hipError_t launch_flash_attn_f32_split(const float* q, const float* k, const float* vT, float* ctx, void* ws, int64_t bs, int B, int H, int nv, int np, unsigned*, hipStream_t, int) {
+hipError_t launch_flash_attn_f32_split(const float* q, const float* k, const float* vT, float* ctx, void* ws, int64_t bs, int B, int H, int nv, int np, unsigned*, hipStream_t, int, int) {
     const size_t head = (size_t)np * 64;
     rd(q, ((size_t)(B - 1) * bs + H * head) * 4, "split attention q");
     rd(k, ((size_t)(B - 1) * bs + H * head) * 4, "split attention k");
@@ -174,7 +174,7 @@ hipError_t launch_flash_attn_f32_split(const float* q, const float* k, const flo
     wr(ctx, (size_t)B * np * H * 64 * 4, "split attention ctx");
     return hipSuccess;
 }
-hipError_t launch_flash_attn_split_planes(const void* q_hi, const void* k_hi, const void* v_hi, void* ctx3, int64_t bs, int64_t qk_lo, int64_t v_lo, int B, int H, int nv, int np, unsigned*, hipStream_t, int mx_out, int) {
+hipError_t launch_flash_attn_split_planes(const void* q_hi, const void* k_hi, const void* v_hi, void* ctx3, int64_t bs, int64_t qk_lo, int64_t v_lo, int B, int H, int nv, int np, unsigned*, hipStream_t, int mx_out, int, int) {
     const size_t head = (size_t)np * 64;
     for (int plane = 0; plane < 2; ++plane) {
         rd((const char*)q_hi + (size_t)plane * qk_lo * 2, ((size_t)(B - 1) * bs + H * head) * 2, "split attention q plane");
