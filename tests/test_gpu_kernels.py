@@ -232,6 +232,55 @@ def test_flash_attention_f32_mx(lib, case, mode):
         assert err >= 5 * err_exact          # the documented weakness of mode 2 (if this ever fails the default can change)
 
 
+@pytest.mark.parametrize("mx", [0, 2])
+@pytest.mark.parametrize("case", [(1, 2, 257, 1.0), (2, 3, 1370, 1.0), (1, 1, 64, 1.0), (1, 2, 700, 1.0), (1, 2, 362, 0.02), (1, 2, 500, 30.0)])
+def test_flash_attention_f32_pv_hi(lib, case, mx):
+    """Option attn_f32_pv = 1 ("f32_precision fast", round 5): P V as the single product v_hi . p_hi on the f16 pipe, row sums of the SAME
+    rounded P on the matrix pipe; scores on f16 lo planes (mx 0) or e4m3 pairs (mx 2).  P and V carry 11 bits, so the bar is f16 rounding
+    of the largest value (2^-11 max|v|; measured about half of that on random data), not the 2e-5 of the full form.  Because numerator and denominator see the same rounded weights, a V that is constant over the keys comes back EXACTLY as
+    f16(V) for every query, whatever the scores are — the property that keeps a large common offset of V out of the error."""
+    B, H, n, scale = case
+    npad = (n + 127) // 128 * 128
+    g = torch.Generator(device="cpu").manual_seed(n + H)
+    q = torch.zeros(B, H, npad, 64); k = torch.zeros(B, H, npad, 64); v = torch.zeros(B, H, npad, 64)
+    q[:, :, :n] = torch.randn(B, H, n, 64, generator=g) * 0.65 * (scale if scale < 1 else 1.0)
+    k[:, :, :n] = torch.randn(B, H, n, 64, generator=g) * (scale if scale > 1 else 1.0)
+    v[:, :, :n] = torch.randn(B, H, n, 64, generator=g) * scale
+    k[:, :, n:] = 37.0
+    v[:, :, n:] = -91.0
+    qd, kd = q.cuda(), k.cuda()
+    vtd = v.transpose(2, 3).contiguous().cuda()
+    ctx = torch.empty(B * npad, H * 64, device="cuda")
+    ws = torch.empty(lib.rz_flash_attention_split_workspace(B, H, npad), dtype=torch.uint8, device="cuda")
+    vc = torch.zeros(B, H, npad, 64)
+    vc[:, :, :n] = (torch.randn(B, H, 1, 64, generator=g) * 300.0 * scale).expand(B, H, n, 64)       # constant over the keys, per (head, channel)
+    vc[:, :, n:] = -91.0
+    vctd = vc.transpose(2, 3).contiguous().cuda()
+    ctx_c = torch.empty_like(ctx)
+    check(lib, lib.rz_set_option(b"attn_f32_pv", 1))
+    check(lib, lib.rz_set_option(b"attn_f32_mx", mx))
+    try:
+        fn = lib.rz_flash_attention_f32_mx if mx else lib.rz_flash_attention_f32_split
+        check(lib, fn(P(qd), P(kd), P(vtd), P(ctx), P(ws), B, H, n, npad, stream()))
+        check(lib, fn(P(qd), P(kd), P(vctd), P(ctx_c), P(ws), B, H, n, npad, stream()))
+    finally:
+        lib.rz_set_option(b"attn_f32_pv", 0)
+        lib.rz_set_option(b"attn_f32_mx", 1)
+    torch.cuda.synchronize()
+    ref = _attn_ref(q[:, :, :n].double(), k[:, :, :n].double(), v[:, :, :n].double())
+    got = ctx.double().cpu().view(B, npad, H, 64).permute(0, 2, 1, 3)[:, :, :n]
+    err = (got - ref).abs().max().item()
+    print("f32 attention, P V on hi planes, scores mx", mx, case, "err", err)
+    assert torch.isfinite(got).all()
+    if not (mx == 2 and scale > 1):               # mode 2's exponentiated score error on +-150 scores: test_flash_attention_f32_mx documents it
+        # worst case (one key takes all the weight): half an f16 ulp of p plus half an ulp of v, relative to the LARGEST |v| = 2^-11 max|v|
+        assert err <= 2.0 ** -11 * float(v[:, :, :n].abs().max()) * 1.05, (case, mx, err)
+    got_c = ctx_c.cpu().view(B, npad, H, 64).permute(0, 2, 1, 3)[:, :, :n]
+    want_c = vc[:, :, :n].half().float()
+    # sum_j p_j c / sum_j p_j with the same fp32-accumulated p_j: equal up to fp32 rounding of the two sums
+    assert (got_c - want_c).abs().max().item() <= 2e-6 * 300.0 * scale * 4, (case, mx, (got_c - want_c).abs().max().item())
+
+
 @pytest.mark.parametrize("g,size", [(16, (224, 224)), (37, (512, 640)), (73, (1024, 1024)), (19, (300, 200))])
 def test_upsample(lib, g, size):
     gen = torch.Generator(device="cpu").manual_seed(g)
