@@ -8,7 +8,8 @@ Differences from the reference, all deliberate:
   * under torch.distributed the SOURCE is sharded — batches are dealt round-robin to the ranks by a strided batch
     sampler, a rank never reads an image it does not compute — and logits are gathered to rank 0 in the original order;
   * raw detector images are preprocessed on the device (the raw bytes cross PCIe, not fp32 pixels), overlapped with the
-    previous batch's forward.
+    previous batch's forward; a map-style dataset is read by a background thread two batches ahead (the reference's
+    4-worker DataLoader, inference/utils.py:81-90, does the same job with processes).
 """
 from __future__ import annotations
 
@@ -26,6 +27,48 @@ def process_class_prompts(text_prompt: Dict[str, List[str]], tokenizer, model):
     enc = tokenizer(prompts, padding=True, truncation=True, return_tensors="pt").to(model.device)
     neg = tokenizer(negatives, padding=True, truncation=True, return_tensors="pt").to(model.device)
     return {"encoded_key_phrases": enc, "encoded_negative_phrases": neg}
+
+
+def _prefetch(gen, depth: int = 2):
+    """Run the generator `gen` in a background thread, `depth` results ahead (bounded queue): host-side dataset reads / decodes of batch
+    k + 1, k + 2 overlap the compute of batch k.  Exceptions of the producer are re-raised at the consumer; if the consumer stops
+    early the producer is told to stop and unblocked."""
+    import queue
+    import threading
+    q: "queue.Queue" = queue.Queue(maxsize=max(1, depth))
+    stop = threading.Event()
+    END = object()
+
+    def put(item) -> bool:
+        while not stop.is_set():
+            try:
+                q.put(item, timeout=0.1)
+                return True
+            except queue.Full:
+                pass
+        return False
+
+    def run():
+        try:
+            for item in gen:
+                if not put((item, None)):
+                    return
+            put((END, None))
+        except BaseException as e:          # noqa: BLE001 — handed to the consumer
+            put((END, e))
+
+    t = threading.Thread(target=run, name="radzero-prefetch", daemon=True)
+    t.start()
+    try:
+        while True:
+            item, err = q.get()
+            if item is END:
+                if err is not None:
+                    raise err
+                return
+            yield item
+    finally:
+        stop.set()
 
 
 def _is_dataset(source) -> bool:
@@ -50,9 +93,28 @@ def _collate_default(items, model, preprocessor):
     return preprocessor(raws)
 
 
+_guard_warned = False
+
+
+def _warn_guard_reruns(model, n_batches: int) -> None:
+    """fp32 mode: a checkpoint whose activations leave the f16 planes' range makes every forward run twice, the second time on the
+    exact-fp32 kernels at about a quarter of the speed — results are right, throughput is not.  Said once per process."""
+    global _guard_warned
+    reruns = getattr(model, "guard_reruns", None)
+    if _guard_warned or reruns is None or getattr(model, "dtype", None) is not torch.float32:
+        return
+    n = int(reruns())
+    if n > 0:
+        import warnings
+        _guard_warned = True
+        warnings.warn(f"radzero_amd fp32 mode: {n} forward(s) so far (this call: {n_batches} batch(es)) left the range of the f16 operand planes and were "
+                      "repeated on the exact-fp32 kernels (option f32_split_guard; correct results at ~1/4 of the speed). "
+                      "model.set_model_option('gemm_f32_split', 0) + ('attn_f32_split', 0) runs the exact kernels directly.", RuntimeWarning, stacklevel=3)
+
+
 @torch.no_grad()
 def calculate_similarities(source, text_batch, model, distributed: bool = False, *, batch_size: Optional[int] = None,
-                           collate_fn: Optional[Callable] = None, preprocessor=None, overlap: bool = True):
+                           collate_fn: Optional[Callable] = None, preprocessor=None, overlap: bool = True, presharded: bool = False):
     """Class logits (n_images, T) as float32 numpy (exp/cxr_pt/inference/utils.py:70-106, :103-104), in the order of the source.
 
     `source` is either
@@ -62,10 +124,14 @@ def calculate_similarities(source, text_batch, model, distributed: bool = False,
         an image it will not compute (the host-side share of an 8-GPU run is 1/8 per rank, not 8/8).  A batch of items becomes
         pixel_values through `collate_fn(items)` if given, else: (3, S, S) float tensors are stacked; raw images (2-D / HWC uint8 /
         uint16 / float arrays, sizes may differ) run the device preprocessing `preprocessor` (DevicePreprocessor) — the raw bytes
-        cross PCIe, not fp32 pixels.  With a CUDA model and `overlap`, batch k + 1 is fetched, copied and preprocessed on a side
-        stream while batch k computes;
-      * or an iterable of pixel_values tensors (B, 3, S, S) — under torch.distributed THIS RANK'S batches only (global batch i = the
-        (i // world)-th batch of rank i % world: shard the source with StridedBatchSampler, not the results).
+        cross PCIe, not fp32 pixels.  With `overlap`, a background thread reads the items two batches ahead (a slow `__getitem__` —
+        file decode — runs beside the forward, not between launches) and, with a CUDA model, batch k + 1 is copied and preprocessed
+        on a side stream while batch k computes;
+      * or an iterable of pixel_values tensors (B, 3, S, S).  Under torch.distributed every rank passes the SAME full sequence of
+        batches and computes batch i where i % world == rank (the others are skipped: the contract of rounds 1-3).  `presharded=True`
+        says the iterable holds THIS RANK'S batches only (global batch i = the (i // world)-th batch of rank i % world — e.g. a
+        DataLoader built on StridedBatchSampler): nothing is skipped, a rank never produces a batch it does not compute.  Passing a
+        full sequence with presharded=True would compute everything on every rank and return world x duplicated rows — hence opt-in.
 
     distributed=True (one process per GPU, torch.distributed initialised): the prompt set is encoded once, sharded over ranks + one
     all_gather (parallel.sharded_text_features); per-rank logits — unequal row counts are fine, a rank may get nothing — are gathered to
@@ -74,7 +140,9 @@ def calculate_similarities(source, text_batch, model, distributed: bool = False,
     dist_on = distributed and dist.is_available() and dist.is_initialized()
     world, rank = (dist.get_world_size(), dist.get_rank()) if dist_on else (1, 0)
     encode = lambda e: model.forward_text_model(e)["text_features_wo_l2_norm"]
-    feats = sharded_text_features(encode, enc, feature_dim=model.config.hidden_size) if dist_on else model.encode_prompts(enc)
+    # with a text projector (cls_alignment / global_alignment heads, modeling.py:70-73) the text features are 2 x hidden wide
+    feat_dim = model.config.hidden_size * (2 if getattr(model.config, "use_text_projection", False) else 1)
+    feats = sharded_text_features(encode, enc, feature_dim=feat_dim) if dist_on else model.encode_prompts(enc)
     n_prompts = int(feats.shape[0])
     cuda = model.device.type == "cuda"
 
@@ -82,9 +150,14 @@ def calculate_similarities(source, text_batch, model, distributed: bool = False,
         if not batch_size or batch_size <= 0:
             raise ValueError("calculate_similarities: a dataset source needs batch_size")
         make = collate_fn if collate_fn is not None else (lambda items: _collate_default(items, model, preprocessor))
-        batches = (make([source[j] for j in idxs]) for idxs in StridedBatchSampler(len(source), batch_size, rank, world))
-    else:
+        fetched = ([source[j] for j in idxs] for idxs in StridedBatchSampler(len(source), batch_size, rank, world))
+        if overlap:
+            fetched = _prefetch(fetched, depth=2)           # host reads / decodes beside the compute
+        batches = (make(items) for items in fetched)        # device work (H2D, preprocessing) stays on the calling thread's side stream
+    elif presharded or world == 1:
         batches = iter(source)
+    else:
+        batches = (px for i, px in enumerate(source) if i % world == rank)
 
     out, rows = [], []
     if cuda and overlap:
@@ -118,6 +191,7 @@ def calculate_similarities(source, text_batch, model, distributed: bool = False,
             out.append(logits.reshape(px.shape[0], -1))
             rows.append(int(px.shape[0]))
     logits = torch.cat(out, dim=0) if out else torch.zeros((0, n_prompts), dtype=torch.float32, device=feats.device)
+    _warn_guard_reruns(model, len(rows))
     if dist_on:
         all_rows = [None] * world
         dist.all_gather_object(all_rows, rows)

@@ -418,8 +418,9 @@ class RadZeroModel:
         feat = self._text_cache.get(key)
         if feat is None:
             self._check_ids(int(hi_.min()), int(hi_.max()))
-            feat = self._text_forward_raw(ids.to(device=self._device, dtype=torch.int64).contiguous(),
-                                          mask.to(device=self._device, dtype=torch.int64).contiguous())
+            # projected like forward_text_model's output (text_projector, modeling.py:199-200): cached and uncached paths hand out the same features
+            feat = self._project_text(self._text_forward_raw(ids.to(device=self._device, dtype=torch.int64).contiguous(),
+                                                             mask.to(device=self._device, dtype=torch.int64).contiguous()))
             self._cache_put(key, feat)
         return feat
 
@@ -438,8 +439,13 @@ class RadZeroModel:
         with torch.cuda.stream(side):
             side.wait_event(ids_ready)
             if capturing or not self.text_cache_enabled:
-                feat = self._text_forward_raw(ids.to(device=self._device, dtype=torch.int64).contiguous(),
-                                              mask.to(device=self._device, dtype=torch.int64).contiguous())
+                if ids.dim() != 2 or ids.shape != mask.shape:
+                    raise ValueError("input_ids / attention_mask must be (n_prompts, len) and agree")
+                dev_ids = ids.to(device=self._device, dtype=torch.int64).contiguous()
+                if not capturing:           # the reference's IndexError for ids outside the vocabulary (one host read of both bounds, as forward_text_model)
+                    lo, hi = torch.stack([dev_ids.min(), dev_ids.max()]).tolist()
+                    self._check_ids(int(lo), int(hi))
+                feat = self._project_text(self._text_forward_raw(dev_ids, mask.to(device=self._device, dtype=torch.int64).contiguous()))
             else:
                 ident = self._ident(ids, mask)
                 feat = self._encode_by_content(ids, mask)
@@ -456,7 +462,7 @@ class RadZeroModel:
         """kwargs (encoded_negative_phrases, use_negative_logits, ...) are accepted and ignored, as in the
         reference (modeling.py:282).  `text_features` lets a data-parallel driver pass all-gathered embeddings."""
         if self.config.compute_logits_type != "radzero":
-            return self._compute_alignment_logits(pixel_values, encoded_key_phrases)
+            return self._compute_alignment_logits(pixel_values, encoded_key_phrases, text_features)
         pending = None
         if text_features is None:
             enc = encoded_key_phrases[0]
@@ -492,9 +498,13 @@ class RadZeroModel:
         return outputs
 
     # ---- compute_logits_type "cls_alignment" / "global_alignment" (modeling.py:330-353) --------
-    def _compute_alignment_logits(self, pixel_values, encoded_key_phrases):
+    def _compute_alignment_logits(self, pixel_values, encoded_key_phrases, text_features: Optional[torch.Tensor] = None):
+        """`text_features`: the prompt groups' un-normalised features (encode_prompts / a data-parallel driver's all-gathered table), concatenated
+        in group order; otherwise every group is encoded through the text cache (the reference re-encodes them for every image batch)."""
         tokens, (b, n) = self._vision(pixel_values, want_tokens=True)
-        key_features = torch.cat([self.forward_text_model(kp)["text_features"] for kp in encoded_key_phrases], dim=0).contiguous()     # (N_total, D')
+        if text_features is None:
+            text_features = torch.cat([self.encode_prompts(kp) for kp in encoded_key_phrases], dim=0)
+        key_features = F.normalize(text_features.to(device=self._device, dtype=torch.float32), p=2, dim=1).contiguous()     # (N_total, D') "text_features"
         t, d = key_features.shape[0], self.config.hidden_size
         outputs = {}
         if self.config.compute_logits_type == "cls_alignment":
