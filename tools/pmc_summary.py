@@ -90,15 +90,26 @@ ALGO = {   # (read bytes, written bytes) per launch, formulas in DESIGN.md §4
 }
 
 
+EPI_NAMES.update({12: "EPI_HEADS_LN", 13: "EPI_VT_LN", 14: "EPI_PATCH_LN"})
+ALGO[("EPI_PATCH_LN", None)] = (M * KP * 2 + NP * D * 4 + D * KP * 2, M * D * 4 + M * D * 2 + M * 96)
+
+
 def epi_of(name):
-    m = re.search(r"gemm_kernel_v(?:8|10)<[^,>]+,\s*(?:\(rz::Epilogue\))?(\d+)", name) or re.search(r"gemm_kernel_v(?:8|10)I[^L]*Li(\d+)E", name)
+    """EPI template argument of a gemm_kernel_v8 / v10 instantiation: from the MANGLED name (tools/profile_round.sh runs the FETCH / WRITE passes with
+    --mangled-kernels: _ZN2rz14gemm_kernel_v8IDF16bLi9ELb0ELb0ELin1EEEvNS_8GemmArgsE), else from a well-formed demangled one."""
+    m = re.search(r"gemm_kernel_v(?:8|10)I(?:DF16b|DF16_|u6__bf16|Dh|f|[^L]*?)Li(\d+)E", name) or \
+        re.search(r"gemm_kernel_v(?:8|10)<[^,>]+,\s*(?:\(rz::Epilogue\))?(\d+)", name)
     return EPI_NAMES.get(int(m.group(1))) if m else None
+
+
+def is_bf16(name):
+    return "bf16" in name or "DF16b" in name or "u6__bf16" in name
 
 
 per = {}
 for k in set(fetch) | set(write):
     e = epi_of(k)
-    if not e or ("bf16" not in k and "DF16b" not in k):
+    if not e or not is_bf16(k):
         continue
     f, w = fetch.get(k, {}).get("FETCH_SIZE", []), write.get(k, {}).get("WRITE_SIZE", [])
     n = min(len(f), len(w))                     # same command, same dispatch order in both passes

@@ -4,7 +4,9 @@
 # 1. rocprofv3 --kernel-trace --stats of the default bench command           -> kernel_stats.csv (+ the bench line it printed)
 # 2. two --pmc passes (FETCH_SIZE, WRITE_SIZE: they do not fit one pass)      -> HBM bytes per launch (tools/pmc_summary.py)
 # 3. one --pmc pass of SQ / GRBM counters                                     -> MFMA busy, VALU active, wait fractions, clock
-# Counter passes carry --kernel-trace only (no other trace domain), and python3 is the program after `--`.
+# Counter passes carry --kernel-trace only (no other trace domain), and python3 is the program after `--`.  The FETCH / WRITE passes keep the MANGLED kernel
+# names (-M): rocprofv3 7.x garbles the demangled template arguments of gemm_kernel_v8 (r04: "<bool _Accum, int, ELb0ELb0E, -1>"), and the per-epilogue
+# traffic table of tools/pmc_summary.py is keyed on the EPI template argument.
 set -e -o pipefail
 R=${1:-r02}
 OUT=gpurun_out/prof_$R
@@ -14,9 +16,9 @@ BENCH="python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-other-config
 PMCB="python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-other-configs --no-kernel-events"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- $BENCH > $OUT/bench_under_rocprof.json 2> $OUT/trace.err
 echo "[profile] kernel trace done"
-rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- $PMCB > $OUT/pmc_fetch.json 2> $OUT/pmc_fetch.err
+rocprofv3 --kernel-trace --mangled-kernels --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- $PMCB > $OUT/pmc_fetch.json 2> $OUT/pmc_fetch.err
 echo "[profile] FETCH_SIZE pass done"
-rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- $PMCB > $OUT/pmc_write.json 2> $OUT/pmc_write.err
+rocprofv3 --kernel-trace --mangled-kernels --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- $PMCB > $OUT/pmc_write.json 2> $OUT/pmc_write.err
 echo "[profile] WRITE_SIZE pass done"
 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU --output-format csv -d $OUT/pmc_sq -- $PMCB > $OUT/pmc_sq.json 2> $OUT/pmc_sq.err
 echo "[profile] SQ pass done"
@@ -28,7 +30,7 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_cfg4 -- pytho
 echo "[profile] cfg4 trace done"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_cfg5 -- python3 bench.py --dtype f16 --batch 1 --side 1536 --prompts 193 --min-len 6 --max-len 16 --steps 10 --warmup 3 --no-cpu-baseline --no-other-configs > $OUT/bench_cfg5_under_rocprof.json 2> $OUT/trace_cfg5.err
 echo "[profile] cfg5 trace done"
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_f32 -- python3 bench.py --dtype f32 --steps 2 --warmup 1 --no-cpu-baseline --no-other-configs > $OUT/bench_f32_under_rocprof.json 2> $OUT/trace_f32.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_f32 -- python3 bench.py --dtype f32 --steps 3 --warmup 1 --no-cpu-baseline --no-other-configs > $OUT/bench_f32_under_rocprof.json 2> $OUT/trace_f32.err
 echo "[profile] fp32-mode trace done"
 for c in cfg4 cfg5 f32; do f=$(find $OUT/trace_$c -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $OUT/summary/kernel_stats_$c.csv; cp $OUT/bench_${c}_under_rocprof.json $OUT/summary/ || true; done
 # drop the bulky per-dispatch traces, keep the summaries (gpurun merges <= 64 MiB back)
