@@ -792,10 +792,11 @@ def main():
                                "peak": round(pk["attn"], 1), "unit": "TFLOP/s",
                                "frac": round(achieved / pk["attn"], 4),
                                "traffic": traffic,
-                               "traffic_unit": "HBM bytes per launch; RECORDED by separate rocprofv3 --pmc passes of this command "
-                                               f"(2*FETCH_SIZE + WRITE_SIZE, KiB -> B; profiles/{traffic_rnd}/hbm_traffic_pmc.json), not measured in this run",
+                               "traffic_unit": ("HBM bytes per launch; RECORDED by separate rocprofv3 --pmc passes of this command "
+                                                f"(2*FETCH_SIZE + WRITE_SIZE, KiB -> B; profiles/{traffic_rnd}/hbm_traffic_pmc.json), not measured in this run") if traffic is not None
+                                               else "no PMC passes are committed for this exact workload (profiles/*/hbm_traffic_pmc.json cover B = 32, 1024^2, bf16)",
                                "algorithmic_bytes": int(B * cfg.tokens(S) * 768 * 2 * 4),
-                               "avg_launch_ms": round(avg_ms, 4), "launches": launches}
+                               "avg_launch_ms": round(avg_ms, 4), "launches": launches, **({"peak_note": pk["note"]} if "note" in pk else {})}
             res["kernel_family_ms_per_step"] = {k: round(v["ms"] / (args.steps if k == "attn" else fam_steps), 3) for k, v in prof.items()}
             gemm_ms = res["kernel_family_ms_per_step"].get("gemm", 0.0)
             if gemm_ms > 0:
