@@ -83,7 +83,8 @@ def test_set_option_known_and_unknown_names():
     No compute call: runs without a GPU."""
     from radzero_amd.modeling import RadZeroModel
     defaults = {"gemm_variant": 0, "attn_variant": 0, "ln_fused": 1, "attn_f32_split": 1, "gemm_f32_split": 1,
-                "pad_rows": 0, "f32_split_guard": 1, "gemm_v1_only": 0, "sim_op": 0, "gemm_f32_mx": 1, "attn_f32_mx": 1}
+                "pad_rows": 0, "f32_split_guard": 1, "gemm_v1_only": 0, "sim_op": 0, "gemm_f32_mx": 1, "attn_f32_mx": 1,
+                "attn_f32_pv": 0, "f32_drop": 0}
     for name, value in defaults.items():
         RadZeroModel.set_option(name, value)
     with pytest.raises(ValueError):
@@ -135,6 +136,7 @@ def test_encode_prompts_cache_under_inference_mode():
     m.config = RadZeroConfig()            # token ids are range-checked before the content key is built
     m.text_cache_enabled = True
     m._text_cache, m._text_ident_cache = {}, {}
+    m._text_proj = None                   # no text projector (the released configuration)
     calls = []
 
     def fake_text(ids, mask):            # stands in for rz_text_forward (the content-keyed level calls the raw encoder)
