@@ -20,7 +20,40 @@ namespace rz {
 
 constexpr int VC_CHUNK = 128;   // token rows per workgroup = per softmax chunk
 constexpr int VC_TG = 16;       // prompts per workgroup
+#ifndef RZ_VLCABS_WAVES
+#define RZ_VLCABS_WAVES 4        // waves per workgroup of vlcabs_kernel (4 | 8): A/B with RZ_CXXFLAGS=-DRZ_VLCABS_WAVES=8
+#endif
 constexpr int VC_LDS_STRIDE = 772;      // floats; 772 mod 64 = 4 spreads the 16 rows of an A-fragment read over the banks
+
+// Cross-lane reductions on the vector ALU's data-parallel primitives (DPP) instead of ds_bpermute: the kernel is a chain of dependent latencies, and
+// the 104 LDS-crossbar shuffles per 16-token tile (3 wave sums per LayerNorm row, a 16-lane max and sum per softmax row) were ~100 cycles each.
+// quad_perm [1,0,3,2], [2,3,0,1], row_half_mirror, row_mirror: after the four steps every lane of a 16-lane row holds the row's total, bit-identical
+// in all 16 lanes (each step adds two values that both partners hold).
+template <int CTRL> __device__ __forceinline__ float vc_dpp(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float vc_row16_sum(float v) {
+    v += vc_dpp<0xB1>(v);
+    v += vc_dpp<0x4E>(v);
+    v += vc_dpp<0x141>(v);
+    v += vc_dpp<0x140>(v);
+    return v;
+}
+__device__ __forceinline__ float vc_row16_max(float v) {
+    v = fmaxf(v, vc_dpp<0xB1>(v));
+    v = fmaxf(v, vc_dpp<0x4E>(v));
+    v = fmaxf(v, vc_dpp<0x141>(v));
+    v = fmaxf(v, vc_dpp<0x140>(v));
+    return v;
+}
+// all 64 lanes: the four row totals through scalar registers, summed in a fixed order
+__device__ __forceinline__ float vc_wave_sum(float v) {
+    v = vc_row16_sum(v);
+    const int vi = __builtin_bit_cast(int, v);          // v_readlane moves 32 bits: the builtin is typed int, a float argument would be CONVERTED
+    const float s0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(vi, 0)), s1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(vi, 16)),
+                s2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(vi, 32)), s3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(vi, 48));
+    return (s0 + s1) + (s2 + s3);
+}
 
 // ---- fused scores + per-chunk online-softmax partials: ws[b][chunk][t] = {m, l, agg[768]} ----
 // One workgroup = (128-token chunk, image, group of 16 prompts), walked as eight 16-token tiles.  Per tile:
@@ -33,14 +66,20 @@ constexpr int VC_LDS_STRIDE = 772;      // floats; 772 mod 64 = 4 spreads the 16
 //   4. agg[16 prompts][768] += P V on the matrix pipe, each wave owning 192 channels (12 accumulator tiles).
 // Token traffic: each token row is read once per prompt group — from HBM by the first group's workgroup, from L2 / the
 // Infinity Cache by the others (a 128-token chunk is 393 KB; cfg 5 reads its 36 MB of tokens 13 times, on chip).
-__global__ __launch_bounds__(256) void vlcabs_kernel(const float* __restrict__ tokens, const float* __restrict__ gamma,
+template <int NW>
+__global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 2) void vlcabs_kernel(const float* __restrict__ tokens, const float* __restrict__ gamma,
                                                      const float* __restrict__ beta, float eps, const float* __restrict__ qhat,
                                                      float inv_tau, float* __restrict__ ws, float* __restrict__ scores, int T,
                                                      int n_valid, int n_pad, int l2_tokens) {
     constexpr int D = 768, REC = D + 2;
     __shared__ __attribute__((aligned(16))) float vs[16 * VC_LDS_STRIDE];
-    __shared__ float sred[4][16][17];        // [wave][prompt][token]: K-quarter partial scores
-    __shared__ float pT[4][16][17];          // [wave][prompt][token]: wave-private P for the aggregation MFMAs
+    static_assert(NW == 4 || NW == 8, "waves per workgroup");
+    constexpr int RPW = 16 / NW;             // token rows a wave normalises per tile
+    constexpr int KBW = 48 / NW;             // 16-wide K blocks of the score contraction per wave (K = 768 split over the waves)
+    constexpr int CPW = D / NW;              // output channels of the aggregation per wave
+    constexpr int NACC = CPW / 16;           // 16 x 16 accumulator tiles per wave
+    constexpr int KUNR = NW == 4 ? 4 : 3;    // score K blocks in flight (registers)
+    __shared__ float sred[NW][16][17];       // [wave][token][prompt]: partial scores of the wave's K slice
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l15 = lane & 15, lg = lane >> 4;
     // prompt group fastest: the workgroups that share a token chunk are dispatched together and read it once from HBM
@@ -49,114 +88,134 @@ __global__ __launch_bounds__(256) void vlcabs_kernel(const float* __restrict__ t
     // B operand of the score MFMAs: qhat row of prompt t0 + l15 (clamped: rows >= T are computed and dropped)
     const int tq = t0 + l15;
     const float* qrow = qhat + (int64_t)(tq < T ? tq : T - 1) * D + 4 * lg;
-    f32x4 acc[12];
+    f32x4 acc[NACC];
 #pragma unroll
-    for (int i = 0; i < 12; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    f32x4 m_run = (f32x4){-INFINITY, -INFINITY, -INFINITY, -INFINITY}, l_run = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int i = 0; i < NACC; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    float m_run = -INFINITY, l_run = 0.f;    // running maximum / sum of prompt l15
 
     for (int tile = 0; tile < VC_CHUNK / 16; ++tile) {
         const int tok0 = c * VC_CHUNK + tile * 16;
-        // ---- 1. shared LayerNorm (eps 1e-5, two-pass) + L2 normalisation of 16 token rows -> LDS (rows one after the other:
-        // four rows side by side, or the next tile's rows prefetched under the matrix phases, cost registers = occupancy and
-        // measured slower: 0.39 against 0.33 ms at cfg 2)
-#pragma unroll 1
-        for (int rr = 0; rr < 4; ++rr) {
-            const int rl = wave * 4 + rr;
-            const int64_t row = (int64_t)b * n_pad + tok0 + rl;
-            f32x4 v[3];
+        // ---- 1. shared LayerNorm (eps 1e-5, two-pass) + L2 normalisation of 16 token rows -> LDS.  Round 5: the wave's four rows are requested
+        // from HBM TOGETHER (12 x 16 B per lane in flight: one memory latency per tile instead of four back to back — the kernel is a chain of
+        // latencies, MFMA busy 0.19) and their four reduction chains are independent, so they interleave; per row the arithmetic and its order are
+        // unchanged (same bits).  [Round 2 measured "four rows side by side" slower at 153 VGPRs: that version also held gamma / beta per row.]
+        {
+            f32x4 v[RPW][3];
 #pragma unroll
-            for (int i = 0; i < 3; ++i) v[i] = *reinterpret_cast<const f32x4*>(tokens + row * D + (lane + 64 * i) * 4);
-            float sm = 0.f;
+            for (int rr = 0; rr < RPW; ++rr) {
+                const int64_t row = (int64_t)b * n_pad + tok0 + wave * RPW + rr;
 #pragma unroll
-            for (int i = 0; i < 3; ++i) sm += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
-            const float mu = wave_sum(sm) * (1.0f / D);
-            float q = 0.f;
+                for (int i = 0; i < 3; ++i) v[rr][i] = *reinterpret_cast<const f32x4*>(tokens + row * D + (lane + 64 * i) * 4);
+            }
+            f32x4 gm[3], be[3];
 #pragma unroll
             for (int i = 0; i < 3; ++i) {
-                v[i] -= mu;
-                q += (v[i][0] * v[i][0] + v[i][1] * v[i][1]) + (v[i][2] * v[i][2] + v[i][3] * v[i][3]);
+                gm[i] = *reinterpret_cast<const f32x4*>(gamma + (lane + 64 * i) * 4);
+                be[i] = *reinterpret_cast<const f32x4*>(beta + (lane + 64 * i) * 4);
             }
-            const float rstd = rsqrtf(wave_sum(q) * (1.0f / D) + eps);
-            float n2 = 0.f;
 #pragma unroll
-            for (int i = 0; i < 3; ++i) {
-                const f32x4 gm = *reinterpret_cast<const f32x4*>(gamma + (lane + 64 * i) * 4);
-                const f32x4 be = *reinterpret_cast<const f32x4*>(beta + (lane + 64 * i) * 4);
-                v[i] = v[i] * rstd * gm + be;
-                n2 += (v[i][0] * v[i][0] + v[i][1] * v[i][1]) + (v[i][2] * v[i][2] + v[i][3] * v[i][3]);
+            for (int rr = 0; rr < RPW; ++rr) {
+                const int rl = wave * RPW + rr;
+                float sm = 0.f;
+#pragma unroll
+                for (int i = 0; i < 3; ++i) sm += (v[rr][i][0] + v[rr][i][1]) + (v[rr][i][2] + v[rr][i][3]);
+                const float mu = vc_wave_sum(sm) * (1.0f / D);
+                float q = 0.f;
+#pragma unroll
+                for (int i = 0; i < 3; ++i) {
+                    v[rr][i] -= mu;
+                    q += (v[rr][i][0] * v[rr][i][0] + v[rr][i][1] * v[rr][i][1]) + (v[rr][i][2] * v[rr][i][2] + v[rr][i][3] * v[rr][i][3]);
+                }
+                const float rstd = rsqrtf(vc_wave_sum(q) * (1.0f / D) + eps);
+                float n2 = 0.f;
+#pragma unroll
+                for (int i = 0; i < 3; ++i) {
+                    v[rr][i] = v[rr][i] * rstd * gm[i] + be[i];
+                    n2 += (v[rr][i][0] * v[rr][i][0] + v[rr][i][1] * v[rr][i][1]) + (v[rr][i][2] * v[rr][i][2] + v[rr][i][3] * v[rr][i][3]);
+                }
+                const float inv = l2_tokens ? 1.0f / fmaxf(sqrtf(vc_wave_sum(n2)), 1e-12f) : 1.0f;
+#pragma unroll
+                for (int i = 0; i < 3; ++i) *reinterpret_cast<f32x4*>(vs + rl * VC_LDS_STRIDE + (lane + 64 * i) * 4) = v[rr][i] * inv;
             }
-            const float inv = l2_tokens ? 1.0f / fmaxf(sqrtf(wave_sum(n2)), 1e-12f) : 1.0f;
-#pragma unroll
-            for (int i = 0; i < 3; ++i) *reinterpret_cast<f32x4*>(vs + rl * VC_LDS_STRIDE + (lane + 64 * i) * 4) = v[i] * inv;
         }
         __syncthreads();
-        // ---- 2. S^T tile: D[prompt 4*lg + r][token l15], this wave's quarter of K (walked in blocks of 16: lane (., lg)
-        // supplies k = 16*kb + 4*lg + u for the u-th of four MFMAs — a permuted but consistent K order for both operands)
+        // ---- 2. score tile D[token 4*lg + r][prompt l15] (tokens are the MFMA rows, prompts its columns), this wave's slice of K, walked in
+        // blocks of 16: lane (., lg) supplies k = 16*kb + 4*lg + u for the u-th of four MFMAs — a permuted but consistent K order for both operands.
+        // Round 5: transposed against rounds 1-4 (which had prompts as rows), so that a lane owns ONE prompt and four consecutive tokens: the
+        // probabilities it computes are exactly the B operand of the aggregation MFMAs (no LDS round trip of P), the softmax statistics are per-lane
+        // scalars reduced over 4 registers + 2 cross-row steps (instead of a 16-lane max and sum per accumulator register), scores and partial
+        // records leave as runs of four consecutive floats.
         {
             const float* arow = vs + l15 * VC_LDS_STRIDE + 4 * lg;
             f32x4 sp = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll 4
-            for (int kb = wave * 12; kb < wave * 12 + 12; ++kb) {
+#pragma unroll KUNR
+            for (int kb = wave * KBW; kb < wave * KBW + KBW; ++kb) {
                 const f32x4 tv = *reinterpret_cast<const f32x4*>(arow + kb * 16);     // token row l15
                 const f32x4 qv = *reinterpret_cast<const f32x4*>(qrow + kb * 16);     // prompt row l15
 #pragma unroll
-                for (int u = 0; u < 4; ++u) sp = __builtin_amdgcn_mfma_f32_16x16x4f32(qv[u], tv[u], sp, 0, 0, 0);
+                for (int u = 0; u < 4; ++u) sp = __builtin_amdgcn_mfma_f32_16x16x4f32(tv[u], qv[u], sp, 0, 0, 0);
             }
 #pragma unroll
-            for (int r = 0; r < 4; ++r) sred[wave][4 * lg + r][l15] = sp[r];
+            for (int r = 0; r < 4; ++r) sred[wave][4 * lg + r][l15] = sp[r];                // [token][prompt]
         }
         __syncthreads();
         f32x4 sv;
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
-            sv[r] = ((sred[0][4 * lg + r][l15] + sred[1][4 * lg + r][l15]) + (sred[2][4 * lg + r][l15] + sred[3][4 * lg + r][l15])) * inv_tau;
-        const bool live_tok = tok0 + l15 < n_valid;
-        if (wave == 0 && live_tok) {
+        for (int r = 0; r < 4; ++r) {
+            float t4 = (sred[0][4 * lg + r][l15] + sred[1][4 * lg + r][l15]) + (sred[2][4 * lg + r][l15] + sred[3][4 * lg + r][l15]);
+            if constexpr (NW == 8)
+                t4 += (sred[4][4 * lg + r][l15] + sred[5][4 * lg + r][l15]) + (sred[6][4 * lg + r][l15] + sred[7][4 * lg + r][l15]);
+            sv[r] = t4 * inv_tau;
+        }
+        const int tokb = tok0 + 4 * lg;                  // this lane's four tokens: tokb .. tokb + 3
+        if (wave == 0 && tq < T) {
+            float* srow = scores + ((int64_t)b * T + tq) * n_valid + tokb;
 #pragma unroll
             for (int r = 0; r < 4; ++r)
-                if (t0 + 4 * lg + r < T) scores[((int64_t)b * T + t0 + 4 * lg + r) * n_valid + tok0 + l15] = sv[r];
+                if (tokb + r < n_valid) srow[r] = sv[r];
         }
-        // ---- 3. online softmax over the token tiles (every wave keeps the same running statistics)
-        f32x4 p;
+        // ---- 3. online softmax over the token tiles: per lane the statistics of prompt l15 (every wave keeps the same ones)
+        f32x4 e;
+        {
+            f32x4 sm;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const float s = live_tok ? sv[r] : -INFINITY;
-            float tm = s;
+            for (int r = 0; r < 4; ++r) sm[r] = (tokb + r < n_valid) ? sv[r] : -INFINITY;
+            float tm = fmaxf(fmaxf(sm[0], sm[1]), fmaxf(sm[2], sm[3]));
+            tm = fmaxf(tm, __shfl_xor(tm, 16, 64));
+            tm = fmaxf(tm, __shfl_xor(tm, 32, 64));                                        // max over the tile's 16 tokens
+            const float mn = fmaxf(m_run, tm);
+            // e^x as 2^(x log2 e) on the transcendental pipe (v_exp_f32, ~1 ulp): libm's expf was ~20 instructions on this latency chain
+            const float alpha = (m_run == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f((m_run - mn) * 1.4426950408889634f);
 #pragma unroll
-            for (int o = 8; o > 0; o >>= 1) tm = fmaxf(tm, __shfl_xor(tm, o, 64));          // max over the tile's 16 tokens
-            const float mn = fmaxf(m_run[r], tm);
-            const float alpha = (m_run[r] == -INFINITY) ? 0.f : expf(m_run[r] - mn);
-            const float e = (s == -INFINITY) ? 0.f : expf(s - mn);
-            float es = e;
+            for (int r = 0; r < 4; ++r) e[r] = (sm[r] == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f((sm[r] - mn) * 1.4426950408889634f);
+            float es = (e[0] + e[1]) + (e[2] + e[3]);
+            es += __shfl_xor(es, 16, 64);
+            es += __shfl_xor(es, 32, 64);
+            l_run = l_run * alpha + es;
+            m_run = mn;
 #pragma unroll
-            for (int o = 8; o > 0; o >>= 1) es += __shfl_xor(es, o, 64);
-            l_run[r] = l_run[r] * alpha + es;
-            m_run[r] = mn;
-            p[r] = e;
-#pragma unroll
-            for (int i = 0; i < 12; ++i) acc[i][r] *= alpha;
+            for (int i = 0; i < NACC; ++i) acc[i] *= alpha;
         }
-#pragma unroll
-        for (int r = 0; r < 4; ++r) pT[wave][4 * lg + r][l15] = p[r];
-        // same wave, in-order LDS queue: the reads below see the writes above
-        // ---- 4. agg[prompt 4*lg + r][channel wave*192 + 16*i + l15] += sum_token P[prompt][token] vhat[token][channel]
+        // ---- 4. agg^T[channel wave*CPW + 16*i + 4*lg + r][prompt l15] += sum_token vhat[token][channel] P[prompt][token]: A = vhat^T from LDS
+        // (row = channel 16*i + l15, k = lg <-> token 4*lg + ks), B = this lane's own e[ks] (k = lg, column = prompt l15)
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
-            const float a = pT[wave][l15][4 * ks + lg];
-            const float* brow = vs + (4 * ks + lg) * VC_LDS_STRIDE + wave * 192 + l15;
+            const float* arow = vs + (4 * lg + ks) * VC_LDS_STRIDE + wave * CPW + l15;
 #pragma unroll
-            for (int i = 0; i < 12; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, brow[i * 16], acc[i], 0, 0, 0);
+            for (int i = 0; i < NACC; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(arow[i * 16], e[ks], acc[i], 0, 0, 0);
         }
         __syncthreads();          // vs and sred are rewritten by the next tile
     }
+    if (tq < T) {
+        float* rec = ws + (((int64_t)b * nchunks + c) * T + tq) * REC;
+        if (wave == 0 && lg == 0) { rec[0] = m_run; rec[1] = l_run; }
+        // channels wave*CPW + 16*i + 4*lg .. + 3: rec + 2 is 8-byte aligned (REC is even), not 16
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int t = t0 + 4 * lg + r;
-        if (t >= T) continue;
-        float* rec = ws + (((int64_t)b * nchunks + c) * T + t) * REC;
-        if (wave == 0 && l15 == 0) { rec[0] = m_run[r]; rec[1] = l_run[r]; }
-#pragma unroll
-        for (int i = 0; i < 12; ++i) rec[2 + wave * 192 + i * 16 + l15] = acc[i][r];
+        for (int i = 0; i < NACC; ++i) {
+            float* o = rec + 2 + wave * CPW + i * 16 + 4 * lg;
+            *reinterpret_cast<f32x2*>(o) = (f32x2){acc[i][0], acc[i][1]};
+            *reinterpret_cast<f32x2*>(o + 2) = (f32x2){acc[i][2], acc[i][3]};
+        }
     }
 }
 
@@ -209,8 +268,13 @@ hipError_t launch_vlcabs(const float* tokens, const float* ln_gamma, const float
                          float* logits, int B, int T, int n_valid, int n_pad, int D, hipStream_t s) {
     if (D != 768 || B <= 0 || T <= 0 || n_pad % VC_CHUNK || n_valid > n_pad) return hipErrorInvalidValue;
     const int nchunks = n_pad / VC_CHUNK;
-    hipLaunchKernelGGL(vlcabs_kernel, dim3((T + VC_TG - 1) / VC_TG, nchunks, B), dim3(256), 0, s, tokens, ln_gamma, ln_beta, ln_eps,
+#if RZ_VLCABS_WAVES == 8
+    hipLaunchKernelGGL(vlcabs_kernel<8>, dim3((T + VC_TG - 1) / VC_TG, nchunks, B), dim3(512), 0, s, tokens, ln_gamma, ln_beta, ln_eps,
                        qhat, 1.0f / score_denominator, ws, scores, T, n_valid, n_pad, sim_dot ? 0 : 1);
+#else
+    hipLaunchKernelGGL(vlcabs_kernel<4>, dim3((T + VC_TG - 1) / VC_TG, nchunks, B), dim3(256), 0, s, tokens, ln_gamma, ln_beta, ln_eps,
+                       qhat, 1.0f / score_denominator, ws, scores, T, n_valid, n_pad, sim_dot ? 0 : 1);
+#endif
     hipLaunchKernelGGL(vlcabs_finalize_kernel, dim3(T, B), dim3(256), 0, s, ws, qhat, logit_tau, t2i_logits, logits, T, B, nchunks, sim_dot ? 1 : 0);
     return hipGetLastError();
 }
