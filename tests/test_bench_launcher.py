@@ -61,3 +61,54 @@ def test_gpus_flag_must_match_world_size():
     env = dict(os.environ, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4"], capture_output=True, text=True, timeout=120, env=env)
     assert r.returncode != 0 and "WORLD_SIZE=2" in r.stderr
+
+
+def _clog_worker(rank, world, port, q):
+    import torch
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    sys.path.insert(0, ROOT)
+    import bench
+    from radzero_amd.parallel import sharded_text_features
+    clog = bench.CollectiveLog()                      # before init_process_group, as bench.main() does
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        ids = torch.arange(14 * 6).reshape(14, 6)
+        enc = {"input_ids": ids, "attention_mask": torch.ones_like(ids)}
+        clog.phase = "prompt_exchange"
+        table = sharded_text_features(lambda e: e["input_ids"].float().repeat(1, 128), enc, feature_dim=768)      # (14, 768) fp32
+        clog.phase = "setup"
+        dist.barrier()
+        clog.phase = "timed_steps"
+        for _ in range(3):
+            (table * 2).sum()                          # a "step": no collective
+        clog.phase = "closing_barrier"
+        dist.barrier()
+        clog.phase = "after"
+        t = torch.tensor([1.0])
+        dist.all_reduce(t)
+        q.put((rank, clog.count("prompt_exchange"), clog.bytes("prompt_exchange", "all_gather"), clog.count("timed_steps"),
+               sum(1 for ph, n, _ in clog.calls if ph == "closing_barrier" and n == "barrier"), tuple(table.shape), clog.count("after")))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_collective_log_counts_what_the_process_group_carried():
+    """The `rccl` block of the bench line is READ from the live process group: the collective log around
+    torch.distributed sees ONE gather for the prompt exchange — world x ceil(T / world) x 768 fp32 — nothing inside the timed steps, and the
+    contract's closing barrier.  gloo, world size 2, CPU."""
+    import torch.multiprocessing as mp
+    import socket
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_clog_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=180) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, n_exchange, gather_bytes, n_steps, n_barriers, shape, n_after in res:
+        assert n_exchange == 1 and n_steps == 0 and n_barriers == 1 and n_after == 1 and shape == (14, 768)
+        assert gather_bytes == 7 * 768 * 4                  # gloo path: a list all_gather of (7, 768) fp32 shards (the NCCL path gathers into one tensor)
