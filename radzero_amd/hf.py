@@ -91,6 +91,49 @@ class RadZeroHFModel(RadZeroModel):
         return cls.from_state_dict(sd, rz_cfg, torch_dtype=dtype, device=dev).eval()
 
 
+def config_dict(cfg, dtype=None) -> dict:
+    """A RadZeroConfig in the LAYOUT of the reference's config.json (CxrAlignConfig, exp/cxr_pt/model/configuration.py:107-129: three nested
+    configurations + the loss / head keys at the top level), with the auto_map that makes it loadable through AutoModel.  Inverse of
+    checkpoint.config_from_hf for the fields the kernels read."""
+    return {
+        "architectures": ["RadZeroHFModel"], "model_type": MODEL_TYPE, "auto_map": dict(AUTO_MAP),
+        "vision_config": {"model_type": "dinov2", "hidden_size": cfg.hidden_size, "num_attention_heads": cfg.num_attention_heads, "mlp_ratio": cfg.mlp_ratio,
+                          "patch_size": cfg.patch_size, "num_channels": cfg.num_channels, "image_size": cfg.pretrain_image_size,
+                          "num_hidden_layers": cfg.vit_layers, "layer_norm_eps": cfg.vit_layer_norm_eps},
+        "text_config": {"model_type": "mpnet", "vocab_size": cfg.vocab_size, "max_position_embeddings": cfg.max_position_embeddings,
+                        "num_hidden_layers": cfg.text_layers, "intermediate_size": cfg.text_intermediate_size, "layer_norm_eps": cfg.text_layer_norm_eps,
+                        "relative_attention_num_buckets": cfg.relative_attention_num_buckets, "use_text_projection": bool(cfg.use_text_projection)},
+        "align_transformer_config": {"model_type": "align_transformer", "num_hidden_layers": cfg.align_layers, "use_layer_norm": False},
+        "loss": {"RadZeroLoss": {"loss_temperature": cfg.loss_temperature, "sim_op": cfg.sim_op, "attn_temperature": cfg.attn_temperature,
+                                 "hidden_dim": cfg.hidden_size}, "apply": ["RadZeroLoss"], "ratio": [1.0]},
+        "compute_logits_type": cfg.compute_logits_type,
+        **({"dtype": str(dtype).replace("torch.", "")} if dtype is not None else {}),
+    }
+
+
+def save_pretrained(model, save_directory: str) -> str:
+    """`model.save_pretrained(dir)` for the HIP model: model.safetensors with the reference's tensor names (the state dict the model was
+    loaded from), config.json in the reference's layout + auto_map, and the two module files — a directory that both
+    `RadZeroModel.from_pretrained` and the README's `AutoModel.from_pretrained(dir, trust_remote_code=True, ...)` read back."""
+    from .checkpoint import save_checkpoint
+    sd = getattr(model, "_state_dict", None)
+    if sd is None:
+        raise RuntimeError("save_pretrained: the model holds no state dict (load weights first)")
+    os.makedirs(save_directory, exist_ok=True)
+    import torch
+    save_checkpoint({k: (v.detach().float().cpu().numpy() if isinstance(v, torch.Tensor) else v) for k, v in sd.items()}, save_directory)
+    with open(os.path.join(save_directory, "config.json"), "w") as f:
+        json.dump(config_dict(model.config, getattr(model, "dtype", None)), f, indent=2, sort_keys=True)
+    with open(os.path.join(save_directory, CONFIG_MODULE + ".py"), "w") as f:
+        f.write(_SHIM.format(what="Configuration class", name="RadZeroHFConfig"))
+    with open(os.path.join(save_directory, MODEL_MODULE + ".py"), "w") as f:
+        f.write(_SHIM.format(what="Model class", name="RadZeroHFModel"))
+    return save_directory
+
+
+RadZeroModel.save_pretrained = lambda self, save_directory, **_ignored: save_pretrained(self, save_directory)
+
+
 def register() -> None:
     """model_type "radzero_hip" -> (RadZeroHFConfig, RadZeroHFModel) in transformers' auto classes (idempotent)."""
     AutoConfig.register(MODEL_TYPE, RadZeroHFConfig, exist_ok=True)

@@ -189,6 +189,15 @@ def test_readme_automodel_call_returns_the_hip_model(tmp_path, monkeypatch):
         Image.fromarray((np.random.default_rng(4).random((260, 340)) * 255).astype(np.uint8)).save(path)
         prob, sim_map = model_inference(path, "There is fibrosis", tokenizer=_Tokenizer(), image_processor=BlipImageProcessor(224), model=model)
         assert tuple(sim_map.shape) == (260, 340) and 0.0 < float(prob) < 1.0 and torch.isfinite(sim_map).all()
+        # and back out: model.save_pretrained writes a directory the same AutoModel call reads (bf16 this time, device_map as a string)
+        saved = model.save_pretrained(str(tmp_path / "resaved"))
+        again = AutoModel.from_pretrained(saved, trust_remote_code=True, torch_dtype=torch.bfloat16, device_map="cuda")
+        try:
+            assert again.config == cfg and again.dtype == torch.bfloat16
+            oc = again.compute_logits(px, [enc])
+            assert float((oc["logits"] - oa["logits"]).abs().max()) <= 0.05
+        finally:
+            again.close()
     finally:
         model.close()
         b.close()

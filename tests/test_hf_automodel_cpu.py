@@ -67,3 +67,29 @@ def test_hf_config_gives_the_kernels_config(tmp_path):
     c = AutoConfig.from_pretrained(str(src))                   # model_type is registered by importing radzero_amd.hf: no remote code needed
     assert isinstance(c, RadZeroHFConfig)
     assert c.to_radzero(load_checkpoint(str(src))) == cfg
+
+
+def test_save_pretrained_round_trip(tmp_path):
+    """`model.save_pretrained(dir)` (radzero_amd.hf): weights under the reference's names + config.json in the reference's layout + auto_map;
+    the directory reads back to the same RadZeroConfig and tensors, for the released head and for a projected global_alignment one.  Host
+    logic only: the model object is a stand-in carrying what save_pretrained reads."""
+    import numpy as np
+    import torch
+    from transformers import AutoConfig
+    from radzero_amd.checkpoint import config_from_hf, load_checkpoint
+    from radzero_amd.config import RadZeroConfig
+    from radzero_amd.hf import RadZeroHFConfig, save_pretrained
+    from radzero_amd.weights import make_state_dict
+    for i, over in enumerate(({}, {"compute_logits_type": "global_alignment", "use_text_projection": True, "sim_op": "dot"})):
+        cfg = RadZeroConfig(vit_layers=1, align_layers=1, text_layers=1, vocab_size=1000, loss_temperature=0.05, **over)
+        sd = make_state_dict(cfg, 5)
+
+        class _M:
+            config, _state_dict, dtype = cfg, sd, torch.float32
+        d = save_pretrained(_M(), str(tmp_path / f"saved{i}"))
+        assert sorted(os.listdir(d)) == ["config.json", "configuration_radzero_hip.py", "model.safetensors", "modeling_radzero_hip.py"]
+        back = load_checkpoint(d)
+        assert set(back) == set(sd) and all(np.array_equal(back[k], np.asarray(sd[k], np.float32)) for k in sd)
+        assert config_from_hf(d, state_dict=back) == cfg
+        c = AutoConfig.from_pretrained(d)
+        assert isinstance(c, RadZeroHFConfig) and c.to_radzero(back) == cfg and c.dtype in ("float32", torch.float32)
