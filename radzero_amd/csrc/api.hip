@@ -207,7 +207,7 @@ struct rz_model {
     DevBuf ovf;                          // fp32 mode: one word the hi/lo-split producers OR into when a value leaves the f16 range
     unsigned* ovf_host = nullptr;        // pinned mirror of it
     int64_t guard_reruns = 0;            // forwards repeated on the exact-fp32 kernels since rz_create
-    struct SplitW { const char* p; size_t bytes; const char* p3; const char* p4; };
+    struct SplitW { const char* p; size_t bytes; const char* p3; const char* p4; int e8_hi; };      // e8_hi: E8M0 scale byte of the MX copy's hi8 plane (lo8: 11 below)
     std::vector<SplitW> split_w;         // fp32 weight matrix -> its split copy
     bool split_dirty = true;             // a weight was (re)loaded since the split copies were built
     bool mx_weights_ok = false;          // every split weight fits the MX form's hi8 plane
@@ -431,6 +431,7 @@ int gemm_f32_split(rz_model* m, int epi, GemmArgs g, int a_mode, bool out_split,
             const size_t row = (size_t)(w - e.p) / ((size_t)g.K * 4);
             if (e.p + row * g.K * 4 != w) return 0;
             w3 = mx ? e.p4 + row * 4 * g.K : e.p3 + row * 3 * g.K * 2;
+            g.mx_w_e8_hi = e.e8_hi; g.mx_w_e8_lo = e.e8_hi - 11;
             break;
         }
     }
@@ -741,7 +742,8 @@ int rz_weights_ready(rz_handle_t m) {
     if (m->dt == RZ_F32 && m->split_dirty) {     // f16 [hi | hi | lo] copies of the vision encoder's matrices for the hi/lo-split GEMMs
         m->split_w.clear();
         // overflow guard words: [0] activations (cleared by every forward), [1] weights (checked here, once)
-        // overflow guard words: [0] activations, [1] weights beyond the f16 range, [2] weights beyond the MX hi8 range (|w| > 28)
+        // overflow guard words: [0] activations, [1] weights beyond the f16 range, [2] weights beyond their MX hi8 plane (cannot happen with per-matrix
+        // scales unless a weight is not finite), [3] scratch of the per-matrix |w| maximum
         RZ_HIP(m->ovf.ensure(16, true));
         if (!m->ovf_host) RZ_HIP(hipHostMalloc((void**)&m->ovf_host, 16, hipHostMallocDefault));
         RZ_HIP(hipMemset(m->ovf.p, 0, 16));
@@ -755,8 +757,25 @@ int rz_weights_ready(rz_handle_t m) {
                 RZ_HIP(hipMalloc(&t.p4, N * 4 * K));
                 m->allocs.push_back(t.p4);
             }
-            RZ_HIP(launch_split3((const float*)t.p, (int64_t)K, t.p4, (int64_t)N, (int)K, 3, (unsigned*)m->ovf.p + 2, nullptr));
-            m->split_w.push_back({(const char*)t.p, N * K * 4, (const char*)t.p3, (const char*)t.p4});
+            // the MX copy's plane scales follow THIS matrix (round 5; rounds 1-4 fixed them at 2^-4 / 2^-15, and one matrix with |w| > 28 — the outlier
+            // checkpoint's fc2 rows, 400 x the rest — sent the whole model back to the three-plane form): hi8 = e4m3(w / 2^e) with 2^e the smallest
+            // power of two that brings the matrix's largest |w| inside e4m3's 448, lo8 = e4m3((w - f16(w)) / 2^(e - 11)).  Smaller weights keep
+            // e4m3's relative precision down to 2^-6 of the scale (15 binades below the largest), and below that their correction terms are negligible.
+            RZ_HIP(hipMemset((unsigned*)m->ovf.p + 3, 0, 4));
+            RZ_HIP(launch_absmax_bits((const float*)t.p, (int64_t)(N * K), (unsigned*)m->ovf.p + 3, nullptr));
+            unsigned bits = 0;
+            RZ_HIP(hipMemcpy(&bits, (unsigned*)m->ovf.p + 3, 4, hipMemcpyDeviceToHost));
+            float wmax;
+            memcpy(&wmax, &bits, 4);
+            int e8 = 123;                                       // 2^-4: the fixed scale of rounds 1-4 (an all-zero matrix)
+            if (std::isfinite(wmax) && wmax > 0.f) {
+                int ex = 0;
+                const float fr = frexpf(wmax / 448.0f, &ex);           // wmax / 448 = fr 2^ex, fr in [0.5, 1)
+                e8 = 127 + (fr == 0.5f ? ex - 1 : ex);                  // smallest 2^e >= wmax / 448
+                e8 = std::min(std::max(e8, 127 - 40), 127 + 8);
+            }
+            RZ_HIP(launch_split3((const float*)t.p, (int64_t)K, t.p4, (int64_t)N, (int)K, 3, (unsigned*)m->ovf.p + 2, nullptr, e8));
+            m->split_w.push_back({(const char*)t.p, N * K * 4, (const char*)t.p3, (const char*)t.p4, e8});
             return 0;
         };
         const size_t D = m->D, F = m->F;

@@ -366,7 +366,7 @@ __global__ __launch_bounds__(256) void split3_rows_kernel(const float* __restric
 
 // src fp32 [rows][K] -> MX form (rz_common.h): row = [hi f16 x K | per 64 columns: activations lo8 x 64, hi8 x 64 | weights hi8 x 64, lo8 x 64]
 __global__ __launch_bounds__(256) void split_mx_rows_kernel(const float* __restrict__ src, int64_t ld, char* __restrict__ dst, int64_t rows,
-                                                            int K, int weights, unsigned* ovf_flag) {
+                                                            int K, int weights, unsigned* ovf_flag, float w_hi_scale, float w_lo_scale) {
     const int k4 = K / 4;
     const int64_t total = rows * k4;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
@@ -375,7 +375,7 @@ __global__ __launch_bounds__(256) void split_mx_rows_kernel(const float* __restr
         const f32x4 v = *reinterpret_cast<const f32x4*>(src + r * ld + c);
         f16x4 h;
         uint32_t lo8, hi8;
-        split4_mx(v, h, lo8, hi8, weights ? MX_W_HI_SCALE : MX_A_HI_SCALE, weights ? MX_W_LO_SCALE : MX_A_LO_SCALE, ovf_flag);
+        split4_mx(v, h, lo8, hi8, weights ? w_hi_scale : MX_A_HI_SCALE, weights ? w_lo_scale : MX_A_LO_SCALE, ovf_flag);
         char* o = dst + r * 4 * K;
         *reinterpret_cast<f16x4*>(o + 2 * c) = h;
         char* pr = o + mx_pair_off(K, c);
@@ -384,13 +384,29 @@ __global__ __launch_bounds__(256) void split_mx_rows_kernel(const float* __restr
     }
 }
 
-hipError_t launch_split3(const float* src, int64_t ld, void* dst, int64_t rows, int K, int w_layout, unsigned* ovf_flag, hipStream_t s) {
+__global__ __launch_bounds__(256) void absmax_bits_kernel(const float* __restrict__ src, int64_t n, unsigned* __restrict__ out_bits) {
+    unsigned best = 0;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) best = max(best, __float_as_uint(src[i]) & 0x7fffffffu);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) best = max(best, (unsigned)__shfl_xor((int)best, o, 64));
+    if ((threadIdx.x & 63) == 0) atomicMax(out_bits, best);
+}
+
+hipError_t launch_absmax_bits(const float* src, int64_t n, unsigned* out_bits, hipStream_t s) {
+    if (!src || !out_bits || n <= 0) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(absmax_bits_kernel, dim3((unsigned)std::min<int64_t>((n + 255) / 256, 2048)), dim3(256), 0, s, src, n, out_bits);
+    return hipGetLastError();
+}
+
+hipError_t launch_split3(const float* src, int64_t ld, void* dst, int64_t rows, int K, int w_layout, unsigned* ovf_flag, hipStream_t s, int w_e8_hi) {
     if (rows <= 0 || K <= 0 || K % 4 || ld % 4) return hipErrorInvalidValue;
     const int64_t total = rows * (K / 4);
     const int blocks = (int)std::min<int64_t>((total + 255) / 256, 8192);
     if (w_layout >= 2) {
         if (K % 64) return hipErrorInvalidValue;
-        hipLaunchKernelGGL(split_mx_rows_kernel, dim3(blocks), dim3(256), 0, s, src, ld, (char*)dst, rows, K, w_layout == 3 ? 1 : 0, ovf_flag);
+        if (w_e8_hi < 12 || w_e8_hi > 254) return hipErrorInvalidValue;
+        const float w_hi = ldexpf(1.0f, w_e8_hi - 127);
+        hipLaunchKernelGGL(split_mx_rows_kernel, dim3(blocks), dim3(256), 0, s, src, ld, (char*)dst, rows, K, w_layout == 3 ? 1 : 0, ovf_flag, w_hi, w_hi * (1.0f / 2048.0f));
     } else {
         hipLaunchKernelGGL(split3_rows_kernel, dim3(blocks), dim3(256), 0, s, src, ld, (f16_t*)dst, rows, K, w_layout, ovf_flag);
     }

@@ -228,7 +228,7 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel_v7(GemmArgs g) {
         clk0 = __builtin_amdgcn_s_memtime(); rt0 = __builtin_amdgcn_s_memrealtime();
     }
     // E8M0 scale byte of this lane's 32-element block (block index = lane >> 4): A rows = [lo8 | hi8], W rows = [hi8 | lo8]
-    const int sa = lg < 2 ? MX_E8_A_LO : MX_E8_A_HI, sw = lg < 2 ? MX_E8_W_HI : MX_E8_W_LO;
+    const int sa = lg < 2 ? MX_E8_A_LO : MX_E8_A_HI, sw = lg < 2 ? g.mx_w_e8_hi : g.mx_w_e8_lo;      // per weight matrix (api.hip: chosen from its largest |w| when the planes are built)
     const int nkh = MXK ? nk / 2 : nk;          // MXK: nk >= 4 and even
     int kt = 0;
     for (; kt + 2 < nk && kt < nkh; ++kt) {

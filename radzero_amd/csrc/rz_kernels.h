@@ -44,6 +44,7 @@ struct GemmArgs {
     const float* ln_mu = nullptr;    // EPI_RESID_SCALE_LN: [M] centring constant of each row (its mean before this update): ln_hb = T((x - ln_mu[m]) * ln_gamma[n])
     int64_t plane_off = 0;        // hi/lo-split outputs (fp32 mode, EPI_HEADS / EPI_VT): elements from the hi plane to the lo plane
     unsigned* ovf_flag = nullptr; // hi/lo-split outputs: word that receives 1 when a value leaves the f16 range (rz_common.h flag_f16_range)
+    int mx_w_e8_hi = 123, mx_w_e8_lo = 112;   // fp32 mode, MX form: E8M0 scale bytes (127 + log2 scale) of THIS weight matrix's hi8 / lo8 planes; defaults = 2^-4 / 2^-15 (rz_common.h)
     int raster = 0;               // gemm12.hip tile order inside an XCD: 0 = gemm8's (4 x tiles_n groups) | S > 0 = slab walk, slabs of <= S n tiles
     int variant = 0;              // kernel choice: 0 auto | 1 128x128 two-stage | 3 256x256 two-stage | 7 staggered 8-phase (gemm7.hip) | 8 persistent (gemm8.hip) | 10 persistent, 4 waves x 128x128, asm K loop (gemm10.hip) | 11 persistent, 8 waves, one phase per K tile (gemm11.hip)
 };
@@ -61,7 +62,8 @@ bool gemm_patch_ln_ok(int dtype, const GemmArgs& g);                  // may the
 bool gemm_ln_fused_ok(int dtype, int M, int D, int F, int variant);   // may a Dinov2 block of M token rows use the fused-LayerNorm epilogues
 // fp32 mode on the f16 matrix pipe: operands split into f16 planes along K (gemm.hip)
 hipError_t launch_gemm_split_f32out(int epi, const GemmArgs& g, hipStream_t s, bool split_out = false);
-hipError_t launch_split3(const float* src, int64_t ld, void* dst, int64_t rows, int K, int w_layout, unsigned* ovf_flag, hipStream_t s);   // w_layout 0 / 1: f16 planes [hi|lo|hi] / [hi|hi|lo]; 2 / 3: MX form of an activation / weight matrix (K % 64 == 0)
+hipError_t launch_split3(const float* src, int64_t ld, void* dst, int64_t rows, int K, int w_layout, unsigned* ovf_flag, hipStream_t s, int w_e8_hi = 123);   // w_layout 0 / 1: f16 planes [hi|lo|hi] / [hi|hi|lo]; 2 / 3: MX form of an activation / weight matrix (K % 64 == 0); w_e8_hi: layout 3's hi8 plane scale as an E8M0 byte (lo8: 2^-11 of it)
+hipError_t launch_absmax_bits(const float* src, int64_t n, unsigned* out_bits, hipStream_t s);   // *out_bits = max over src of the bit pattern of |x| (NaN / inf included: the largest patterns); out_bits zeroed by the caller
 hipError_t launch_gemm_v8(int dtype, int epi, const GemmArgs& g, hipStream_t s);   // persistent 256x256 kernel (gemm8.hip)
 bool gemm_v10_ok(int dtype, int epi, const GemmArgs& g);
 bool gemm_v11_ok(int dtype, int epi, const GemmArgs& g);

@@ -91,3 +91,16 @@ for mxa in (1, 2):
         print(f"attn_f32_mx={mxa} attn_f32_pv={pv}: worst scores {max(x[1] for x in r):.2e}  logits {max(x[2] for x in r):.2e}  class argmax kept {all(x[3] for x in r)} | "
               + " ".join(f"{n}:{es:.1e}/{el:.1e}" for n, es, el, _ in r), flush=True)
 m.close()
+del m
+torch.cuda.empty_cache()
+m = RadZeroModel.from_state_dict(add_outlier_channels(sd, cfg), cfg, torch_dtype=torch.float32, device="cuda:0").eval()
+m.set_model_option("pad_rows", 256)
+m.set_model_option("gemm_f32_mx", 2)
+print("== MX form forced, outlier-channel checkpoint (G8)")
+for mxa in (1, 2):
+    for pv in (0, 1):
+        m.set_model_option("attn_f32_mx", mxa)
+        m.set_model_option("attn_f32_pv", pv)
+        r = run_cases(m, ["g8_outlier_s224_b2_t3"])
+        print(f"attn_f32_mx={mxa} attn_f32_pv={pv}: scores {r[0][1]:.2e}  logits {r[0][2]:.2e}  class argmax kept {r[0][3]}  guard reruns {m.get_model_option('f32_split_guard_reruns')}", flush=True)
+m.close()

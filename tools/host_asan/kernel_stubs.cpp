@@ -110,7 +110,13 @@ hipError_t launch_gemm_split_f32out(int epi, const GemmArgs& g, hipStream_t s, b
     if (g.ovf_flag) wr(g.ovf_flag, 0, "ovf");
     return hipSuccess;
 }
-hipError_t launch_split3(const float* src, int64_t ld, void* dst, int64_t rows, int K, int layout, unsigned* ovf, hipStream_t) {
+hipError_t launch_absmax_bits(const float* src, int64_t n, unsigned* out_bits, hipStream_t) {
+    unsigned best = 0;
+    for (int64_t i = 0; i < n; ++i) { unsigned u; memcpy(&u, src + i, 4); u &= 0x7fffffffu; best = u > best ? u : best; }
+    *out_bits = best > *out_bits ? best : *out_bits;
+    return hipSuccess;
+}
+hipError_t launch_split3(const float* src, int64_t ld, void* dst, int64_t rows, int K, int layout, unsigned* ovf, hipStream_t, int) {
     rd(src, ((size_t)(rows - 1) * ld + K) * 4, "split3 src");
     wr(dst, layout >= 2 ? (size_t)rows * 4 * K : (size_t)rows * 3 * K * 2, "split3 dst");          // 2 / 3: the MX form, 4 K bytes per row
     if (ovf) rd(ovf, 4, "split3 overflow word");
