@@ -838,7 +838,7 @@ def main():
                                      "f32_split_guard_reruns": f32_leg.get("f32_split_guard_reruns"),
                                      "error_vs_reference": "not measured by this run: tests/test_gpu_fullsize.py::test_cfg2_full_batch_fp32_default_options gates THIS configuration "
                                                            "(B = 32, default options, the reference's 1024^2 golden inside the batch) and tests/test_gpu_model.py every golden at <= 1e-3 "
-                                                           "(FP32_TOL); last recorded maxima 6.5e-5 scores / 2.8e-5 logits, 3.3e-5 on the outlier-channel checkpoint: "
+                                                           "(FP32_TOL); last recorded maxima 7.5e-5 scores / 2.7e-5 logits on the goldens, 4.7e-4 on the outlier-channel checkpoint in the MX form (3.3e-5 in the three-plane form): "
                                                            "profiles/r05/fp32_term_ablation.log (MX form rows), profiles/r04/fp32_mx_accuracy.log",
                                      "opt_in_fast": {"images_per_s": fast_leg["images_per_s"], "how": "model.set_f32_precision('fast') / option attn_f32_pv = 1",
                                                      "error_vs_reference": "3.1e-4 scores / 8.9e-5 logits worst over the goldens but 1.2e-3 on the outlier-channel checkpoint G8 — "

@@ -254,7 +254,7 @@ int rz_gemm_f32_split(int form, const float* a_dev, const float* w_dev, const fl
  *                      0 = three f16 planes throughout the attention
  *   "attn_f32_pv"      fp32 mode: 0 (default, "f32_precision high") = P V with its correction terms; 1 ("f32_precision fast") = P V as the single
  *                      product v_hi . p_hi (P and V at f16's 11 bits, row sums of the rounded P on the matrix pipe so that the weights still sum to
- *                      one): attention 89 -> 63 ms per B = 32 step at 1024^2 (198 -> 235 images/s), 3.1e-4 instead of 6.5e-5 from the reference
+ *                      one): attention 89 -> 63 ms per B = 32 step at 1024^2 (198 -> 235 images/s), 3.1e-4 instead of 7e-5 from the reference
  *                      on the goldens but 1.2e-3 on the outlier-channel checkpoint G8 — outside the 1e-3 contract there, hence not the default
  *                      (profiles/r05/fp32_term_ablation.log).  With 1, "attn_f32_mx" only chooses the scores' form (0 / 1: f16 planes, 2: e4m3 pairs)
  *   "f32_drop"         fp32 mode, ACCURACY ABLATION only (tools/fp32_term_ablation.py; needs gemm_f32_mx = 0): bit mask of GEMM classes computed on

@@ -674,7 +674,7 @@ class RadZeroModel:
 
     def set_f32_precision(self, level: str) -> None:
         """fp32 (1e-3) mode only: which correction terms the split products keep (include/radzero_hip.h "attn_f32_pv";
-        profiles/r05/fp32_term_ablation.log).  "high" (default): every product at 22 bits — 6.5e-5 from the reference on the goldens,
+        profiles/r05/fp32_term_ablation.log).  "high" (default): every product at 22 bits — 7e-5 from the reference on the goldens,
         3e-5 on the outlier-channel checkpoint.  "fast": the attention's P V product on the f16 hi planes alone — 3.1e-4 on the goldens,
         but 1.2e-3 on the outlier-channel checkpoint (outside the 1e-3 contract there), 19 % more images per second."""
         if level not in self.F32_PRECISIONS:
