@@ -205,12 +205,28 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel_v3(GemmArgs g) {
 // Kernel choice: GemmArgs::variant (0 = auto; a forced kernel is used where its shape constraints hold).  No process-wide state
 // lives here: the caller (api.hip) resolves the handle's / the process-wide option into every launch.
 
-// big tiles pay off once their rounds over the 256 CUs are >= 55 % full (measured, bench.py --batch 1..7:
-// 126 tiles -> 128x128 kernel 6 % faster; 189 tiles -> 256x256 kernel 7 % faster; 315 tiles -> 1 % faster)
-static bool big_tiles_pay(const GemmArgs& g) {
+// 256 x 256 tiles (one persistent workgroup per CU: rounds of 256 tiles) or 128 x 128 ones (two workgroups per CU: rounds of 512 tiles, four times as many
+// tiles)?  Round 5: a cost model fitted to an isolated sweep of both kernels over 11 .. 176 row tiles of 256 (tools/ktiles.py,
+// profiles/r05/gemm_tile_choice_sweep.txt): time = rounds x (a + b K / 64) us per round with
+//   256 x 256: b = 1.21, a = 20 (fp32 residual read-modify-write epilogues: out-proj, fc2, patch), 13 (GELU: fc1), 8 (the others)
+//   128 x 128: b = 0.83, a = 8.5 (residual epilogues), 7.5 (the others)
+// which reproduces the winner at every measured point (e.g. out-proj: 128 x 128 up to 126 big tiles and again at 264 - 330 and 528, 256 x 256 at 132 - 252 and 396;
+// fc2: 256 x 256 from 132 big tiles except 264 - 330).  Rounds 1-4 used "at least 128 big tiles and rounds >= 55 % full", which sent fc2 of 132 - 141 tiles (eight 518^2
+// images, one 1536^2 image) to the small kernel (88 against 77 us) and out-proj / fc2 of 315 - 330 tiles to the big one (69 against 56 - 62 us).  From 1024 big tiles on
+// (four rounds) the big kernel is taken as before: the model was not fitted there and the fused-LayerNorm epilogues of the large shapes are tuned on it.
+static bool big_tiles_pay(const GemmArgs& g, int epi) {
     if (g.M % BM2 || g.M < 4 * BM2 || g.N % BN3) return false;
     const int64_t t256 = (int64_t)(g.M / BM2) * (g.N / BN3);
-    return t256 >= 128 && (double)t256 / (double)(((t256 + 255) / 256) * 256) >= 0.55;
+    if (t256 >= 1024) return true;
+    // rounds 1-4's criterion stays a sufficient one: inside the step (tools/step_ab.py, profiles/r05/gemm_tile_choice_in_step.txt) the small kernel's fused-LayerNorm
+    // epilogues lose where the isolated sweep's plain ones win (six 1024^2 images, 378 big tiles: 409 against 391 images/s); the model decides the rest
+    if (t256 >= 128 && (double)t256 / (double)(((t256 + 255) / 256) * 256) >= 0.55) return true;
+    const bool resid = epi == EPI_RESID_SCALE || epi == EPI_RESID_SCALE_LN || epi == EPI_RESID_ADD || epi == EPI_PATCH || epi == EPI_PATCH_LN;
+    const bool gelu = epi == EPI_GELU || epi == EPI_GELU_LN;
+    const double nk = (double)g.K / 64.0;
+    const double t_big = (resid ? 20.0 : gelu ? 13.0 : 8.0) + 1.21 * nk, t_small = (resid ? 8.5 : 7.5) + 0.83 * nk;
+    const double c_big = (double)((t256 + 255) / 256) * t_big, c_small = (double)((4 * t256 + 511) / 512) * t_small;
+    return c_big <= c_small;
 }
 
 // the persistent kernels (the only ones with the merged q|k|v projection and the whole-batch fused-LayerNorm epilogues); 10, 11 and 12
@@ -223,7 +239,18 @@ bool gemm_qkv_fused_ok(int dtype, const GemmArgs& g) {
 #ifdef RZ_EXPERIMENTS
     if (g.variant == 12) return gemm_v12_ok(dtype, EPI_QKV, g);
 #endif
-    return (g.variant == 0 || persistent_variant(g.variant)) && gemm_v8_ok(dtype, EPI_QKV, g) && (g.variant != 0 || big_tiles_pay(g));
+    // auto: the merged launch (N = 3 D) against ITS alternative, the q|k (N = 2 D) and v (N = D) launches of the small kernel (same cost model)
+    auto merged_pays = [&]() {
+        if (g.M % BM2 || g.M < 4 * BM2 || g.N % BN3) return false;
+        const int64_t rt = g.M / BM2, t256 = rt * (g.N / BN3);
+        if (t256 >= 1024 || (t256 >= 128 && (double)t256 / (double)(((t256 + 255) / 256) * 256) >= 0.55)) return true;
+        const double nk = (double)g.K / 64.0, t_big = 8.0 + 1.21 * nk, t_small = 7.5 + 0.83 * nk;
+        const int64_t t_qk = rt * (g.split_n / BN3), t_v = t256 - t_qk;
+        const double c_big = (double)((t256 + 255) / 256) * t_big;
+        const double c_small = (double)((4 * t_qk + 511) / 512 + (4 * t_v + 511) / 512) * t_small;
+        return c_big <= c_small;
+    };
+    return (g.variant == 0 || persistent_variant(g.variant)) && gemm_v8_ok(dtype, EPI_QKV, g) && (g.variant != 0 || merged_pays());
 }
 
 // EPI_PATCH_LN: the persistent kernel or the 128x128 kernel (bit-identical arithmetic, as for the other fused-LayerNorm epilogues)
@@ -247,7 +274,8 @@ static hipError_t launch_gemm_t(int epi, const GemmArgs& g, hipStream_t s) {
     // v7 (gemm7.hip, 16-bit only): K loop 1.40 us per 256x256x64 step against 1.68 for v3 (tools/kslope.py);
     // v8 (gemm8.hip): the same loop, persistent, operand stream continuous across output tiles.
     if (variant == 0) {
-        const bool big = big_tiles_pay(g);
+        // the merged q|k|v projection exists in the persistent kernel only: its caller has already weighed it against the two small launches (gemm_qkv_fused_ok)
+        const bool big = (epi == EPI_QKV || epi == EPI_QKV_LN) ? true : big_tiles_pay(g, epi);
         variant = !big ? 1 : gemm_v8_ok(Traits<T>::kDType, epi, g) ? 8 : gemm_v7_ok(Traits<T>::kDType, g) ? 7 : 3;
     }
     if ((epi == EPI_QKV || epi == EPI_QKV_LN) && !persistent_variant(variant)) return hipErrorInvalidValue;     // merged projection: persistent kernels only
@@ -319,7 +347,7 @@ static hipError_t launch_gemm_t(int epi, const GemmArgs& g, hipStream_t s) {
 hipError_t launch_gemm_split_f32out(int epi, const GemmArgs& g, hipStream_t s, bool split_out) {
     if (epi == EPI_RESID_SCALE || epi == EPI_RESID_ADD || epi == EPI_PATCH || epi == EPI_STORE_F32) return launch_gemm(DT_F16, epi, g, s);
     if (g.M <= 0 || g.N <= 0 || g.K <= 0 || g.M % BM || g.N % BN || (g.K * 2) % 128 || (g.lda * 2) % 16 || (g.ldw * 2) % 16) return hipErrorInvalidValue;
-    const bool v3 = big_tiles_pay(g);
+    const bool v3 = big_tiles_pay(g, epi);
     if (v3 && (g.variant == 0 || g.variant == 7) && gemm_v7_ok(DT_F16, g)) return launch_gemm_v7_f16_out(epi, g, split_out, s);   // the deeper-pipelined K loop
     const int ntiles = v3 ? (g.M / BM2) * (g.N / BN3) : (g.M / BM) * (g.N / BN);
     dim3 grid(ntiles), block(v3 ? 512 : 256);
