@@ -180,12 +180,19 @@ struct rz_model {
     bool o_guard() const { return pick(opt.f32_split_guard, g_opt.f32_split_guard) != 0; }
     bool force_exact = false;            // set while a forward is repeated on the exact-fp32 kernels (overflow guard)
     // padded token rows per image: a multiple of 128 (every GEMM M-tile and attention query block is full); of 256 when that costs less
-    // than 2 % more rows, so that the 256x256 GEMM kernels apply at any batch size (one 1536^2 image: 11882 -> 12032 instead of 11904)
-    int pad_tokens(int nv) const {
+    // than 2 % more rows, so that the 256x256 GEMM kernels apply at any batch size (one 1536^2 image: 11882 -> 12032 instead of 11904).
+    // Round 5: also of 256 for an ODD batch whose 128-multiple is an odd one (B x rows would not be a multiple of 256: every GEMM on the 128 x 128
+    // kernels) when that costs <= 10 % more rows — 518^2: 1408 -> 1536 for 1, 3, 5, ... images (+6 % / +13 % / +9 % / +12 % images per second at
+    // 1 / 3 / 5 / 7 images, profiles/NOTEBOOK.md r5).  Pad rows are masked keys and unused query rows: the results' bits do not depend on the choice
+    // (tests: forced 256-row padding, batches 1..10).  batch = 0: the batch-independent upper bound (table and workspace sizes).
+    int pad_tokens(int nv, int batch = 0) const {
         const int p128 = (nv + 127) / 128 * 128, p256 = (nv + 255) / 256 * 256, rule = o_pad_rows();
         if (rule == 128) return p128;
         if (rule == 256) return p256;
-        return (p256 - nv) * 50 <= nv ? p256 : p128;
+        if ((p256 - nv) * 50 <= nv) return p256;
+        const bool odd_case = p128 != p256 && (p256 - p128) * 10 <= p128;
+        if (odd_case && (batch == 0 || ((batch & 1) && (int64_t)batch * p256 >= 4 * 256))) return p256;
+        return p128;
     }
     int dt;               // compute dtype
     int D, H, F, KP, KPAD;
@@ -795,7 +802,7 @@ int rz_weights_ready(rz_handle_t m) {
 int rz_set_position_table(rz_handle_t m, int gh, int gw, const float* pos_host) {
     if (!m || !pos_host || gh <= 0 || gw <= 0) return fail(RZ_ERR_INVALID, "rz_set_position_table: bad argument");
     if (!m->cls_loaded || !m->patch_bias_loaded) return fail(RZ_ERR_STATE, "rz_set_position_table: load cls_token and patch bias first");
-    const int D = m->D, nv = 1 + gh * gw, np = m->pad_tokens(nv);
+    const int D = m->D, nv = 1 + gh * gw, np = m->pad_tokens(nv);          // the largest padding any batch takes: rows beyond nv are zero
     std::vector<float> tbl((size_t)np * D, 0.f);
     for (int d = 0; d < D; ++d) tbl[d] = pos_host[d] + m->cls_host[d];
     for (int t = 1; t < nv; ++t)
@@ -898,7 +905,8 @@ static int vision_forward_once(rz_handle_t m, const float* px, int B, int C, int
     if (rc) return rc;
     auto it = m->pos_tables.find({gh, gw});
     if (it == m->pos_tables.end()) return fail(RZ_ERR_STATE, "rz_vision_forward: no position table for this patch grid (rz_set_position_table)");
-    const int nv = it->second.n_valid, np = it->second.n_pad;
+    const int nv = it->second.n_valid, np = m->pad_tokens(nv, B);           // <= the table's rows (its padding is the batch-independent upper bound)
+    if (np > it->second.n_pad) return fail(RZ_ERR_STATE, "rz_vision_forward: position table smaller than this batch's row padding (rz_set_position_table again after changing pad_rows)");
     if (B > m->cap_batch || np > m->cap_npad || (size_t)B * np > (size_t)m->cap_batch * m->cap_npad)
         return fail(RZ_ERR_STATE, "rz_vision_forward: workspace too small (rz_reserve)");
     const int D = m->D, H = m->H, F = m->F;
