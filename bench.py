@@ -829,6 +829,7 @@ def main():
                 short_run(sd, cfg, device, "f32", 32, 1024, 14, "none", 6, 10, f32_precision="fast"),      # the 1e-3 mode's opt-in level: P V on the f16 hi planes alone
             ]
             res["per_request"] = request_leg(sd, cfg, device)
+            res["per_request_518"] = request_leg(sd, cfg, device, S=518)      # the released model's own resolution (radzero.yaml:19): the README's single-image call
             # north_star's tolerance (1e-3 on logits and maps) is met by the fp32 mode only: its throughput on the SAME shape,
             # stated next to `value` (which is BASELINE configs[1]'s own dtype, bf16)
             f32_leg, fast_leg = res["other_configs"][3], res["other_configs"][8]
