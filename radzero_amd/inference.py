@@ -126,7 +126,8 @@ def calculate_similarities(source, text_batch, model, distributed: bool = False,
         uint16 / float arrays, sizes may differ) run the device preprocessing `preprocessor` (DevicePreprocessor) — the raw bytes
         cross PCIe, not fp32 pixels.  With `overlap`, a background thread reads the items two batches ahead (a slow `__getitem__` —
         file decode — runs beside the forward, not between launches) and, with a CUDA model, batch k + 1 is copied and preprocessed
-        on a side stream while batch k computes;
+        on a side stream while batch k computes (`overlap=False`: everything on the calling thread and stream — for a dataset whose
+        `__getitem__` must not run on another thread);
       * or an iterable of pixel_values tensors (B, 3, S, S).  Under torch.distributed every rank passes the SAME full sequence of
         batches and computes batch i where i % world == rank (the others are skipped: the contract of rounds 1-3).  `presharded=True`
         says the iterable holds THIS RANK'S batches only (global batch i = the (i // world)-th batch of rank i % world — e.g. a
