@@ -139,6 +139,27 @@ def test_oracle_matches_reference_on_outlier_checkpoint(cfg, state_dict):
     assert float(g["residual_absmax_per_layer"].max()) > 400.0
 
 
+@pytest.mark.parametrize("name", ["g15_outlier_s518_b2_t14", "g14_outlier_s1024_b1_t14"])
+def test_oracle_matches_reference_on_outlier_checkpoint_at_timed_shapes(name, cfg, state_dict):
+    """G14 / G15 (round 6): the outlier-channel checkpoint at the shapes the bench times — N = 5330 (1024^2, the headline) and
+    N = 1370 (518^2, the released resolution), 14 prompts; reference run by tools/make_goldens_post.py --outlier-timed-shapes
+    (SDPA in the ViT blocks as G9).  ~30 s of CPU for the 1024^2 case."""
+    from oracle.radzero_oracle import OracleModel
+    from radzero_amd.weights import add_outlier_channels
+    g = load_golden(name)
+    sd = add_outlier_channels(state_dict, cfg)
+    assert state_dict_digest(sd) == str(g["weights_digest"])
+    px, enc = _inputs(g)
+    with torch.no_grad():
+        out = OracleModel(sd, cfg, attn_impl="sdpa").compute_logits(px, [enc])
+    e_l = np.abs(out["logits"].numpy() - g["logits"]).max()
+    e_s = np.abs(out["similarity_scores"].numpy() - g["similarity_scores"]).max()
+    print(f"\n[{name}] oracle vs reference: max|dlogits| {e_l:.2e} max|dscores| {e_s:.2e}")
+    assert e_l <= TOL and e_s <= 5 * TOL
+    assert np.array_equal(np.argmax(np.atleast_2d(out["logits"].numpy()), 1), np.argmax(np.atleast_2d(g["logits"]), 1))
+    assert float(g["residual_absmax_per_layer"].max()) > 400.0
+
+
 @pytest.mark.parametrize("name,over", [("g10_dot_s224_b2_t3", dict(sim_op="dot")), ("g11_attntemp_s224_b2_t3", dict(attn_temperature=0.2))])
 def test_oracle_head_variants_match_reference(name, over, cfg):
     """G10 / G11: the reference run with sim_op 'dot' (losses.py:214-215) and with a separate attn_temperature (losses.py:57-63,
