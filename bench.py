@@ -26,39 +26,59 @@ from radzero_amd.config import RadZeroConfig, attention_flops_per_image_layer, f
 from radzero_amd.synthetic import synthetic_prompts  # noqa: E402
 from radzero_amd.weights import make_state_dict  # noqa: E402
 
-# dense MFMA peaks, MI355X_MICROARCH.md: 2.5 PFLOP/s for bf16 / f16 operands.  The fp32 mode computes every product on the 16-bit / fp8 matrix pipes over
-# split operands, so an algorithmic FLOP is priced by the MFMA units it actually issues (one unit = one v_mfma_f32_16x16x32_f16, 16 cycles):
-#   three-plane form   a_hi b_hi + a_lo b_hi + a_hi b_lo as three f16 MFMAs                                              -> 3 units, peak 2500 / 3
-#   MX form            a_hi b_hi on the f16 pipe + both correction terms as ONE block-scaled e4m3 MFMA over K' = 128 (32 cycles) -> 2 units, peak 2500 / 2
-#   hi planes alone    (the attention's P V product with f32_precision "fast")                                               -> 1 unit
-# attention = (scores' units + P V's units) / 2; see f32_units() below.  (The exact-fp32 MFMA peak, 157.3 TFLOP/s, applies with both split switches off.)
-PEAK_TFLOPS = {"bf16": 2500.0, "f16": 2500.0}
+# Hardware peaks (MI355X_MICROARCH.md): 2.5 PFLOP/s dense MFMA for bf16 / f16 operands — EVERY roofline block below prints `peak` = 2500 and `frac` against it,
+# the fp32 mode's too.  The fp32 mode computes every product on the 16-bit / fp8 matrix pipes over split operands, so one
+# algorithmic product issues more than one MFMA unit (one unit = one v_mfma_f32_16x16x32_f16, 16 cycles):
+#   three-plane form   a_hi b_hi + a_lo b_hi + a_hi b_lo as three f16 MFMAs                                                   -> 3 units
+#   MX form            a_hi b_hi on the f16 pipe + both correction terms as ONE block-scaled e4m3 MFMA over K' = 128 (32 cycles) -> 2 units
+#   hi planes alone    (the attention's P V product with f32_precision "fast")                                                 -> 1 unit
+# That derating explains the gap; it is not a peak: it goes into `issued_units_per_product` / `frac_of_issue_bound` (= frac x units) beside `frac`.
+# For context the exact-fp32 matrix peak (v_mfma_f32_*_f32 / xf32-less gfx950: 157.3 TFLOP/s) is printed as `exact_fp32_matrix_peak`.
+HW_MFMA_PEAK_TFLOPS = 2500.0
+EXACT_FP32_MATRIX_PEAK_TFLOPS = 157.3
 
 
-def f32_units(model, rows):
-    """(attention units, GEMM units) per algorithmic product of the fp32 mode, from the options in force for `model` and the token rows of the launch."""
-    mxo, mxa, pv = model.get_model_option("gemm_f32_mx"), model.get_model_option("attn_f32_mx"), model.get_model_option("attn_f32_pv")
-    mx_form = mxo != 0 and rows % 256 == 0 and (mxo == 2 or rows >= 256 * 64)          # csrc/api.hip run_chunk
+def f32_units(model):
+    """(attention units, GEMM units) per algorithmic product of the fp32 mode for the LAST forward of `model`: the operand form it actually took
+    (option "last_f32_form", set by rz_vision_forward — bench.py no longer re-derives the padding / form rules) and the options in force."""
+    form, mxa, pv = model.get_model_option("last_f32_form"), model.get_model_option("attn_f32_mx"), model.get_model_option("attn_f32_pv")
+    if form == 0:
+        return None                     # exact-fp32 MFMA kernels (both split switches off, or a weight beyond the f16 range)
+    mx_form = form == 2
     gemm = 2.0 if mx_form else 3.0
     scores = 2.0 if (mx_form and mxa >= 2) else 3.0
     pv_units = 1.0 if pv else (2.0 if (mx_form and mxa >= 1) else 3.0)
     return (scores + pv_units) / 2.0, gemm
 
 
-def peaks(dtype, model, cfg, batch, side, prompts):
-    """{"attn", "gemm", "whole"}: the dense MFMA peak an algorithmic TFLOP of that part of the step is priced against."""
+def issue_units(dtype, model, cfg, side, prompts):
+    """None for the 16-bit modes; for the fp32 mode {"attn", "gemm", "whole", "form"}: MFMA units issued per algorithmic product (call AFTER a forward)."""
     if dtype != "f32":
-        return {k: PEAK_TFLOPS[dtype] for k in ("attn", "gemm", "whole")}
-    n = cfg.tokens(side)
-    p128, p256 = (n + 127) // 128 * 128, (n + 255) // 256 * 256
-    rule = model.get_model_option("pad_rows")
-    npad = p128 if rule == 128 else p256 if rule == 256 else (p256 if (p256 - n) * 50 <= n else p128)          # rz_model::pad_tokens
-    ua, ug = f32_units(model, batch * npad)
+        return None
+    u = f32_units(model)
+    if u is None:
+        return {"attn": None, "gemm": None, "whole": None, "form": "exact-fp32 MFMA kernels"}
+    ua, ug = u
     f_img = flops_per_image(cfg, side, prompts)
     f_attn = cfg.num_blocks * attention_flops_per_image_layer(cfg, side)
-    pa, pg = 2500.0 / ua, 2500.0 / ug
-    return {"attn": pa, "gemm": pg, "whole": f_img / (f_attn / pa + (f_img - f_attn) / pg),
-            "note": f"fp32 mode priced by issued MFMA units: attention {ua:g}, GEMMs {ug:g} f16-MFMA units per algorithmic product (bench.py f32_units)"}
+    return {"attn": ua, "gemm": ug, "whole": round((f_attn * ua + (f_img - f_attn) * ug) / f_img, 4),
+            "form": {1: "three f16 planes", 2: "MX form (f16 hi plane + block-scaled e4m3 correction planes)"}[model.get_model_option("last_f32_form")],
+            "npad": model.get_model_option("last_npad")}
+
+
+def roofline_mfma(kernel, achieved_tflops, units, extra):
+    """One MFMA-bound roofline block: `frac` against the hardware peak; the fp32 mode adds the issue-bound view."""
+    r = {"kernel": kernel, "bound": "mfma", "achieved": round(achieved_tflops, 2), "peak": HW_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+         "frac": round(achieved_tflops / HW_MFMA_PEAK_TFLOPS, 4)}
+    r.update(extra)
+    if units is not None:
+        r["issued_units_per_product"] = units
+        r["frac_of_issue_bound"] = round(achieved_tflops * units / HW_MFMA_PEAK_TFLOPS, 4)
+        r["issue_bound_note"] = ("fp32 mode: each algorithmic product issues `issued_units_per_product` f16-MFMA units (split operands, DESIGN.md §4.4); "
+                                 "frac_of_issue_bound = frac x units is the share of the matrix pipe's issue slots in use — an explanation of the gap, not a peak")
+        r["exact_fp32_matrix_peak"] = EXACT_FP32_MATRIX_PEAK_TFLOPS
+        r["vs_exact_fp32_matrix_peak"] = round(achieved_tflops / EXACT_FP32_MATRIX_PEAK_TFLOPS, 3)
+    return r
 
 
 DTYPES = {"bf16": torch.bfloat16, "f16": torch.float16, "f32": torch.float32}
@@ -66,13 +86,14 @@ DTYPES = {"bf16": torch.bfloat16, "f16": torch.float16, "f32": torch.float32}
 
 def pmc_traffic(kernel, batch, side, dtype):
     """HBM bytes per launch of `kernel` from the committed PMC passes (a separate rocprofv3 --pmc run cannot happen inside
-    this process); null unless the passes were taken on exactly this workload."""
-    for rnd in ("r05", "r04", "r03", "r02", "r01"):
+    this process); null unless the passes were taken on exactly this workload.  -> (bytes, "profiles/<round>/<file>")"""
+    fname = "hbm_traffic_pmc_f32.json" if dtype == "f32" else "hbm_traffic_pmc.json"
+    for rnd in ("r06", "r05", "r04", "r03", "r02", "r01"):
         try:
-            rec = json.load(open(os.path.join(ROOT, "profiles", rnd, "hbm_traffic_pmc.json")))
+            rec = json.load(open(os.path.join(ROOT, "profiles", rnd, fname)))
             c = rec["config"]
             if (c["batch"], c["image_side"], c["dtype"]) == (batch, side, dtype):
-                return rec["kernels"][kernel]["hbm_bytes_per_launch"], rnd
+                return rec["kernels"][kernel]["hbm_bytes_per_launch"], f"profiles/{rnd}/{fname}"
         except (OSError, KeyError, ValueError):
             pass
     return None, None
@@ -342,15 +363,17 @@ def short_run(sd, cfg, device, dtype, B, S, T, maps, min_len, max_len, steps=5, 
             graph_ips = B * steps / (time.perf_counter() - t0)
             assert bool(torch.isfinite(gout["logits"]).all())
         f_img = flops_per_image(cfg, S, T)
-        pk = peaks(dtype, model, cfg, B, S, T)
+        iu = issue_units(dtype, model, cfg, S, T)
         guard_reruns = model.guard_reruns() if dtype == "f32" else None
         attn_ms = prof["attn"]["ms"] / max(1, prof["attn"]["launches"])
         attn_tf = B * attention_flops_per_image_layer(cfg, S) / (attn_ms * 1e-3) / 1e12 if attn_ms > 0 else None
         roof = None
         if attn_tf is not None:
-            roof = {"kernel": "flash_attn_split_kernel" if dtype == "f32" else "flash_attn_kernel", "bound": "mfma", "achieved": round(attn_tf, 1),
-                    "peak": round(pk["attn"], 1), "unit": "TFLOP/s", "frac": round(attn_tf / pk["attn"], 4), "traffic": None,
-                    "avg_launch_ms": round(attn_ms, 4), "launches": prof["attn"]["launches"], **({"peak_note": pk["note"]} if "note" in pk else {})}
+            kname = "flash_attn_split_kernel" if dtype == "f32" else "flash_attn_kernel"
+            traffic, traffic_src = pmc_traffic(kname, B, S, dtype)
+            roof = roofline_mfma(kname, attn_tf, iu["attn"] if iu else None,
+                                 {"traffic": traffic, **({"traffic_unit": f"HBM bytes per launch, recorded by separate rocprofv3 --pmc passes ({traffic_src}), not measured in this run"} if traffic is not None else {}),
+                                  "avg_launch_ms": round(attn_ms, 4), "launches": prof["attn"]["launches"]})
         roof_post = None
         if maps == "upsample" and prof["post"]["launches"] > 0:
             # upsample_bilinear_kernel: algorithmic bytes = the fp32 maps it writes, B*T*S*S*4 (the patch-grid input is 0.5 % of that)
@@ -370,7 +393,9 @@ def short_run(sd, cfg, device, dtype, B, S, T, maps, min_len, max_len, steps=5, 
                 **({"roofline": roof} if roof else {}), **({"roofline_upsample": roof_post} if roof_post else {}),
                 "images_per_s": round(ips, 3), "similarity_maps_per_s": round(ips * T, 2), "ms_per_step": round(dt / steps * 1e3, 3),
                 "model_tflops_per_s": round(ips * f_img / 1e12, 2),
-                "frac_of_mfma_peak_whole_path": round(ips * f_img / 1e12 / pk["whole"], 4),
+                "frac_of_mfma_peak_whole_path": round(ips * f_img / 1e12 / HW_MFMA_PEAK_TFLOPS, 4),
+                **({"issued_units_per_product_whole_path": iu["whole"], "f32_operand_form": iu["form"],
+                    "frac_of_issue_bound_whole_path": round(ips * f_img / 1e12 * iu["whole"] / HW_MFMA_PEAK_TFLOPS, 4)} if iu and iu["whole"] else {}),
                 "attention_tflops_per_s": None if attn_tf is None else round(attn_tf, 1),
                 **({} if guard_reruns is None else {"f32_split_guard_reruns": guard_reruns}),
                 **({} if graph_ips is None else {"images_per_s_hipgraph_replay": round(graph_ips, 3)}),
@@ -499,13 +524,38 @@ def free_port():
         return sk.getsockname()[1]
 
 
-def launch_ranks(n, argv, child_cmd=None, grace_s=30.0):
+def visible_gpu_count():
+    """GPUs this node exposes to this process, WITHOUT loading any GPU library (torch.cuda.device_count() falls back to hipGetDeviceCount — which
+    initialises HIP / HSA in the parent — when the amdsmi module is missing): KFD topology nodes with simd_count > 0, narrowed by
+    HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES / CUDA_VISIBLE_DEVICES.  None when the topology is not readable (then the children decide)."""
+    import glob
+    n = 0
+    try:
+        nodes = glob.glob("/sys/class/kfd/kfd/topology/nodes/*/properties")
+        if not nodes:
+            return None
+        for path in nodes:
+            for line in open(path):
+                k, _, v = line.partition(" ")
+                if k == "simd_count" and int(v) > 0:
+                    n += 1
+    except (OSError, ValueError):
+        return None
+    for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None:
+            n = min(n, len([x for x in v.split(",") if x.strip() != ""]))
+    return n
+
+
+def launch_ranks(n, argv, child_cmd=None, grace_s=30.0, overall_timeout_s=None):
     """`python bench.py --gpus N` without a launcher around it: start N FRESH child processes, one rank per GPU (RANK / LOCAL_RANK /
     WORLD_SIZE / MASTER_* in their environment — what torch.distributed.run would set), relay rank 0's JSON line, return the children's
     worst exit code.  This parent never touches the GPU (no torch.cuda call, no HIP library load): a process that has initialised the GPU
     must not fork / exec workers on this pool.  A failed rank is reported, never retried; once one rank has died the others get `grace_s`
     to exit by themselves (their barrier will never complete) and are then terminated by PID.
-    `child_cmd` (tests: RZ_BENCH_CHILD_CMD, a JSON list) replaces `[sys.executable, bench.py]`."""
+    `child_cmd` (tests: RZ_BENCH_CHILD_CMD, a JSON list) replaces `[sys.executable, bench.py]`.  `overall_timeout_s` (default
+    RZ_BENCH_LAUNCH_TIMEOUT_S or 3600): ranks that all hang without any of them exiting are terminated by PID instead of waited for forever."""
     import subprocess
     import threading
     cmd = list(child_cmd) if child_cmd else [sys.executable, os.path.abspath(__file__)]
@@ -532,7 +582,13 @@ def launch_ranks(n, argv, child_cmd=None, grace_s=30.0):
         threads.append(t)
     codes = [None] * n
     failed_at = None
+    if overall_timeout_s is None:
+        overall_timeout_s = float(os.environ.get("RZ_BENCH_LAUNCH_TIMEOUT_S", "3600"))
+    started = time.time()
     while any(c is None for c in codes):
+        if failed_at is None and time.time() - started > overall_timeout_s:
+            print(f"[bench launcher] no rank has finished after {overall_timeout_s:.0f} s: terminating all ranks", file=sys.stderr, flush=True)
+            failed_at = time.time() - grace_s - 1.0
         for r, p in enumerate(procs):
             if codes[r] is None:
                 codes[r] = p.poll()
@@ -591,19 +647,15 @@ def main():
     ap.add_argument("--no-other-configs", action="store_true", help="skip the short runs of BASELINE configs[3], configs[4] per-GPU shape and the fp32 mode")
     ap.add_argument("--attn-variant", type=int, default=None, help="A/B switch (rz_set_option): 0 = default (4 waves x 32 query rows; bf16 without the running maximum), 417 = running maximum tracked; RZ_EXPERIMENTS=1 library: 64 / 128 / ...")
     ap.add_argument("--ln-fused", type=int, default=None, help="A/B switch: 1 fused LayerNorm (default, 16-bit modes), 0 stand-alone LayerNorm kernels")
-    ap.add_argument("--vision-chunk", type=int, default=None, help="RZ_EXPERIMENTS=1 library only: images per internal pass of the vision encoder (0 = whole batch)")
-    ap.add_argument("--mlp-chunk", type=int, default=None, help="RZ_EXPERIMENTS=1 library only: images per fc1->fc2 pass (-1 = auto, 0 = whole batch)")
-    ap.add_argument("--vision-streams", type=int, default=None, help="RZ_EXPERIMENTS=1 library only: 2 = split the batch over two internal HIP streams")
     ap.add_argument("--gemm-variant", type=int, default=None, help="A/B switch: 0 auto, 1 / 3 / 7 / 8 force that GEMM kernel (include/radzero_hip.h); RZ_EXPERIMENTS=1 library: 10 / 11 / 12")
-    ap.add_argument("--gemm-raster", type=int, default=None, help="RZ_EXPERIMENTS=1 library only (gemm12.hip): tile order inside an XCD, 0 = 4 x tiles_n groups, S > 0 = slab walk with <= S n tiles per slab")
     args = ap.parse_args()
 
     if (args.gpus > 1 or args.launch) and "WORLD_SIZE" not in os.environ:
         # not under torch.distributed.run: launch the ranks ourselves, before anything in this process touches the GPU
         child = os.environ.get("RZ_BENCH_CHILD_CMD")
         if not child:
-            have = torch.cuda.device_count()          # counts devices without initialising the runtime
-            if have < args.gpus:
+            have = visible_gpu_count()                # KFD topology: no GPU library is loaded in this parent
+            if have is not None and have < args.gpus:
                 raise SystemExit(f"bench.py --gpus {args.gpus}: this node exposes {have} GPU(s)")
         raise SystemExit(launch_ranks(args.gpus, sys.argv[1:], json.loads(child) if child else None))
 
@@ -616,13 +668,21 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"bench.py --gpus {args.gpus} under WORLD_SIZE={world}: launch one rank per GPU (or run `python bench.py --gpus N`, which starts them)")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    # RZ_BENCH_DEVICE / RZ_BENCH_BACKEND: test hooks only (tests/test_bench_main_world8_cpu.py rehearses every world > 1 branch of this function on
+    # CPU over gloo with a stub model).  The product model has no CPU path: with the real RadZeroModel "cpu" fails at construction.
+    dev_kind, backend = os.environ.get("RZ_BENCH_DEVICE", "cuda"), os.environ.get("RZ_BENCH_BACKEND", "nccl")
+    if dev_kind == "cuda":
+        torch.cuda.set_device(local_rank)
+        device = torch.device("cuda", local_rank)
+        sync = torch.cuda.synchronize
+    else:
+        device = torch.device(dev_kind)
+        sync = lambda: None      # noqa: E731
     use_dist = world > 1 or args.force_dist
     clog = None
     if use_dist:
         clog = CollectiveLog()
-        dist.init_process_group(backend="nccl", device_id=device, rank=rank, world_size=world)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world, **({"device_id": device} if device.type == "cuda" else {}))
 
     from radzero_amd.modeling import RadZeroModel
     from radzero_amd.parallel import sharded_text_features
@@ -632,16 +692,8 @@ def main():
         _lib.check(_lib.load().rz_set_option(b"attn_variant", args.attn_variant), "rz_set_option")
     if args.ln_fused is not None:
         _lib.check(_lib.load().rz_set_option(b"ln_fused", args.ln_fused), "rz_set_option")
-    if args.vision_chunk is not None:
-        _lib.check(_lib.load().rz_set_option(b"vision_chunk", args.vision_chunk), "rz_set_option")
-    if args.mlp_chunk is not None:
-        _lib.check(_lib.load().rz_set_option(b"mlp_chunk", args.mlp_chunk), "rz_set_option")
-    if args.vision_streams is not None:
-        _lib.check(_lib.load().rz_set_option(b"vision_streams", args.vision_streams), "rz_set_option")
     if args.gemm_variant is not None:
         _lib.check(_lib.load().rz_set_option(b"gemm_variant", args.gemm_variant), "rz_set_option")
-    if args.gemm_raster is not None:
-        _lib.check(_lib.load().rz_set_option(b"gemm_raster", args.gemm_raster), "rz_set_option")
 
     cfg = RadZeroConfig()
     sd = node_shared_state_dict(cfg, 20260103, local_rank, use_dist and world > 1)
@@ -650,20 +702,19 @@ def main():
         model.set_f32_precision(args.f32_precision)
 
     B, S, T = args.batch, args.side, args.prompts
-    pk = peaks(args.dtype, model, cfg, B, S, T)
     g = torch.Generator(device=device).manual_seed(1234 + rank)
     pixels = torch.randn((B, 3, S, S), generator=g, device=device, dtype=torch.float32)   # resident in HBM
     ids, mask = synthetic_prompts(T, args.min_len, args.max_len, 4321)
     enc = {"input_ids": torch.from_numpy(ids).to(device), "attention_mask": torch.from_numpy(mask).to(device)}
 
     # one-time prompt encoding: sharded over ranks + ONE all_gather (RCCL over xGMI), then cached
-    torch.cuda.synchronize()
+    sync()
     if clog:
         clog.phase = "prompt_exchange"
     t0 = time.time()
     text_features = sharded_text_features(lambda e: model.forward_text_model(e)["text_features_wo_l2_norm"], enc,
                                           feature_dim=cfg.hidden_size)
-    torch.cuda.synchronize()
+    sync()
     text_ms = (time.time() - t0) * 1e3
     if clog:
         clog.phase = "setup"
@@ -690,7 +741,7 @@ def main():
         step()
     if use_dist:
         dist.barrier()
-    torch.cuda.synchronize()
+    sync()
     if not args.no_kernel_events:
         # HIP events (rz_profile_*) on the launch stream around the dominant kernel's launches only: ~110 event pairs per step for every
         # kernel would cost the timed region ~1 %
@@ -700,13 +751,13 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         out = step()
-    torch.cuda.synchronize()
+    sync()
     own_elapsed = time.perf_counter() - t0          # this rank's K steps, before waiting for the slowest rank
     if clog:
         clog.phase = "closing_barrier"
     if use_dist:
         dist.barrier()
-    torch.cuda.synchronize()
+    sync()
     elapsed = time.perf_counter() - t0
     if clog:
         clog.phase = "after"
@@ -719,7 +770,7 @@ def main():
             model.profile(True)
             for _ in range(2):
                 step()
-            torch.cuda.synchronize()
+            sync()
             extra = model.profile_read()
             model.profile(False)
             fam_steps = 2
@@ -738,6 +789,7 @@ def main():
 
     if rank == 0:
         n_tok = cfg.tokens(S)
+        iu = issue_units(args.dtype, model, cfg, S, T)
         total_images = world * B * args.steps
         ips = total_images / elapsed
         f_img = flops_per_image(cfg, S, T)
@@ -751,7 +803,9 @@ def main():
                        "map_postprocessing": args.maps},
             "similarity_maps_per_s": round(ips * T, 2),
             "model_tflops_per_s": round(ips * f_img / 1e12, 2),
-            "frac_of_mfma_peak_whole_path": round(ips * f_img / 1e12 / (pk["whole"] * world), 4),
+            "frac_of_mfma_peak_whole_path": round(ips * f_img / 1e12 / (HW_MFMA_PEAK_TFLOPS * world), 4),
+            **({"issued_units_per_product_whole_path": iu["whole"], "f32_operand_form": iu["form"],
+                "frac_of_issue_bound_whole_path": round(ips * f_img / 1e12 * iu["whole"] / (HW_MFMA_PEAK_TFLOPS * world), 4)} if iu and iu["whole"] else {}),
             "text_encode_once_ms": round(text_ms, 2),
         }
         if use_dist:
@@ -764,7 +818,8 @@ def main():
             res["rccl"] = {"backend": dist.get_backend(), "world_size": pg_world, "rccl_version": rccl_version,
                            "launched_by": os.environ.get("RZ_BENCH_LAUNCHED_BY") or ("torch.distributed.run" if "TORCHELASTIC_RUN_ID" in os.environ else "environment"),
                            "prompt_exchange_collectives": clog.count("prompt_exchange"),
-                           "all_gather_bytes": clog.bytes("prompt_exchange", "all_gather_into_tensor"),
+                           # bytes of the gathered table; the list form (CPU / gloo rehearsal, parallel._all_gather_cpu) logs one rank's buffer
+                           "all_gather_bytes": clog.bytes("prompt_exchange", "all_gather_into_tensor") + pg_world * clog.bytes("prompt_exchange", "all_gather"),
                            "all_gather_note": f"ONE all_gather_into_tensor of ({-(-T // pg_world)} x {pg_world} ranks, {cfg.hidden_size}) fp32 prompt embeddings, before the timed region (bytes of the gathered table)",
                            "data_path_collectives": clog.count("timed_steps"),
                            "timed_region_barriers": sum(1 for ph, n, _ in clog.calls if ph == "closing_barrier" and n == "barrier"),
@@ -784,19 +839,17 @@ def main():
             # algorithmic FLOPs per launch = B images x 4*N^2*D (QK^T + PV over all 12 heads), SURVEY.md §8(d)
             launches = prof["attn"]["launches"]
             avg_ms = prof["attn"]["ms"] / launches
-            # (robust to --vision-chunk: total attention FLOPs of the timed region / number of launches)
             flops_launch = args.steps * cfg.num_blocks * B * attention_flops_per_image_layer(cfg, S) / launches
             achieved = flops_launch / (avg_ms * 1e-3) / 1e12
-            traffic, traffic_rnd = pmc_traffic("flash_attn_kernel", B, S, args.dtype)
-            res["roofline"] = {"kernel": "flash_attn_split_kernel" if args.dtype == "f32" else "flash_attn_kernel", "bound": "mfma", "achieved": round(achieved, 2),
-                               "peak": round(pk["attn"], 1), "unit": "TFLOP/s",
-                               "frac": round(achieved / pk["attn"], 4),
-                               "traffic": traffic,
-                               "traffic_unit": ("HBM bytes per launch; RECORDED by separate rocprofv3 --pmc passes of this command "
-                                                f"(2*FETCH_SIZE + WRITE_SIZE, KiB -> B; profiles/{traffic_rnd}/hbm_traffic_pmc.json), not measured in this run") if traffic is not None
-                                               else "no PMC passes are committed for this exact workload (profiles/*/hbm_traffic_pmc.json cover B = 32, 1024^2, bf16)",
-                               "algorithmic_bytes": int(B * cfg.tokens(S) * 768 * 2 * 4),
-                               "avg_launch_ms": round(avg_ms, 4), "launches": launches, **({"peak_note": pk["note"]} if "note" in pk else {})}
+            kname = "flash_attn_split_kernel" if args.dtype == "f32" else "flash_attn_kernel"
+            traffic, traffic_src = pmc_traffic(kname, B, S, args.dtype)
+            res["roofline"] = roofline_mfma(kname, achieved, iu["attn"] if iu else None, {
+                "traffic": traffic,
+                "traffic_unit": ("HBM bytes per launch; RECORDED by separate rocprofv3 --pmc passes of this command "
+                                 f"(2*FETCH_SIZE + WRITE_SIZE, KiB -> B; {traffic_src}), not measured in this run") if traffic is not None
+                                else "no PMC passes are committed for this exact workload (profiles/*/hbm_traffic_pmc*.json cover B = 32, 1024^2, bf16 and f32)",
+                "algorithmic_bytes": int(B * cfg.tokens(S) * 768 * (2 if args.dtype != "f32" else 4) * 4),
+                "avg_launch_ms": round(avg_ms, 4), "launches": launches})
             res["kernel_family_ms_per_step"] = {k: round(v["ms"] / (args.steps if k == "attn" else fam_steps), 3) for k, v in prof.items()}
             gemm_ms = res["kernel_family_ms_per_step"].get("gemm", 0.0)
             if gemm_ms > 0:
@@ -805,9 +858,8 @@ def main():
                 npatch = n_tok - 1
                 gemm_flops = B * (cfg.num_blocks * 24.0 * n_tok * cfg.hidden_size ** 2 + 2.0 * npatch * 588 * cfg.hidden_size)
                 gtf = gemm_flops / (gemm_ms * 1e-3) / 1e12
-                res["roofline_gemm"] = {"kernel": "gemm_kernel_v8 (all instantiations: q|k|v, out-proj, fc1, fc2, patch embedding)", "bound": "mfma",
-                                        "achieved": round(gtf, 2), "peak": round(pk["gemm"], 1), "unit": "TFLOP/s",
-                                        "frac": round(gtf / pk["gemm"], 4), "traffic": None, "ms_per_step": gemm_ms}
+                res["roofline_gemm"] = roofline_mfma("gemm_kernel_v8 (all instantiations: q|k|v, out-proj, fc1, fc2, patch embedding)", gtf, iu["gemm"] if iu else None,
+                                                     {"traffic": None, "ms_per_step": gemm_ms})
             if fam_steps != args.steps:
                 res["kernel_family_note"] = "attn: HIP events inside the timed region; gemm / rowops / vlcabs: two extra un-timed steps"
         if world == 1 and not args.no_other_configs:
@@ -827,9 +879,14 @@ def main():
                 short_run(sd, cfg, device, "bf16", 32, 1024, 14, "none", 6, 10, pipeline="rawhost"),
                 short_run(sd, cfg, device, "bf16", 64, 518, 14, "none", 6, 10),      # the released model's own resolution and eval batch
                 short_run(sd, cfg, device, "f32", 32, 1024, 14, "none", 6, 10, f32_precision="fast"),      # the 1e-3 mode's opt-in level: P V on the f16 hi planes alone
+                # round 6: the 1e-3 mode with its input pipeline inside the step — possible since the fp32 forward no longer synchronises the stream (predicated guard)
+                short_run(sd, cfg, device, "f32", 32, 1024, 14, "none", 6, 10, pipeline="rawhost"),
             ]
             res["per_request"] = request_leg(sd, cfg, device)
             res["per_request_518"] = request_leg(sd, cfg, device, S=518)      # the released model's own resolution (radzero.yaml:19): the README's single-image call
+            # the same two requests in the mode that meets north_star's 1e-3 (the reference's own inference precision: run.py:135-137, inference/utils.py:37)
+            res["per_request_f32"] = request_leg(sd, cfg, device, dtype="f32", steps=12, warmup=4)
+            res["per_request_518_f32"] = request_leg(sd, cfg, device, dtype="f32", S=518, steps=12, warmup=4)
             # north_star's tolerance (1e-3 on logits and maps) is met by the fp32 mode only: its throughput on the SAME shape,
             # stated next to `value` (which is BASELINE configs[1]'s own dtype, bf16)
             f32_leg, fast_leg = res["other_configs"][3], res["other_configs"][8]
@@ -837,10 +894,15 @@ def main():
                                      "dtype": "f32, default options (f32_precision high): operands as f16 hi planes + correction planes — block-scaled e4m3 MFMAs for the GEMMs' and "
                                               "the attention's P V correction terms, f16 lo planes for the scores; fp32 accumulate",
                                      "f32_split_guard_reruns": f32_leg.get("f32_split_guard_reruns"),
+                                     "ms_per_step": f32_leg["ms_per_step"], "roofline": f32_leg.get("roofline"),
+                                     "frac_of_mfma_peak_whole_path": f32_leg.get("frac_of_mfma_peak_whole_path"),
+                                     "frac_of_issue_bound_whole_path": f32_leg.get("frac_of_issue_bound_whole_path"),
+                                     "with_input_pipeline_rawhost_images_per_s": res["other_configs"][9]["images_per_s"],
                                      "error_vs_reference": "not measured by this run: tests/test_gpu_fullsize.py::test_cfg2_full_batch_fp32_default_options gates THIS configuration "
                                                            "(B = 32, default options, the reference's 1024^2 golden inside the batch) and tests/test_gpu_model.py every golden at <= 1e-3 "
-                                                           "(FP32_TOL); last recorded maxima 7.5e-5 scores / 2.7e-5 logits on the goldens, 4.7e-4 on the outlier-channel checkpoint in the MX form (3.3e-5 in the three-plane form): "
-                                                           "profiles/r05/fp32_term_ablation.log (MX form rows), profiles/r04/fp32_mx_accuracy.log",
+                                                           "(FP32_TOL); last recorded maxima 7.5e-5 scores / 2.7e-5 logits on the goldens; on the outlier-channel checkpoint 4.7e-4 at N = 257 (G8) and, round 6, at the timed shapes themselves "
+                                                           "2.3e-4 (G14: 1024^2 inside B = 32) / 3.2e-4 (G15: 518^2 inside B = 64) in the MX form, 1.5e-5 / 2.2e-5 alone in the three-plane form "
+                                                           "(tests/test_gpu_outlier_timed_shapes.py; profiles/r06/outlier_timed_shapes.log)",
                                      "opt_in_fast": {"images_per_s": fast_leg["images_per_s"], "how": "model.set_f32_precision('fast') / option attn_f32_pv = 1",
                                                      "error_vs_reference": "3.1e-4 scores / 8.9e-5 logits worst over the goldens but 1.2e-3 on the outlier-channel checkpoint G8 — "
                                                                            "outside the 1e-3 contract there, hence opt-in (profiles/r05/fp32_term_ablation.log)"}}

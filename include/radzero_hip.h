@@ -259,9 +259,12 @@ int rz_gemm_f32_split(int form, const float* a_dev, const float* w_dev, const fl
  *                      (profiles/r05/fp32_term_ablation.log).  With 1, "attn_f32_mx" only chooses the scores' form (0 / 1: f16 planes, 2: e4m3 pairs)
  *   "f32_drop"         fp32 mode, ACCURACY ABLATION only (tools/fp32_term_ablation.py; needs gemm_f32_mx = 0): bit mask of GEMM classes computed on
  *                      their hi planes alone — 1 q|k projection, 2 V projection, 4 out-projection, 8 fc1, 16 fc2, 32 patch embedding
- *   "f32_split_guard"  1 (default) = fp32 mode: a forward in which a value left the f16 range of the hi/lo planes (|x| > 65504) is
- *                      repeated on the exact-fp32 kernels before rz_vision_forward returns (one stream synchronisation per forward;
- *                      not under stream capture); rz_get_model_option(h, "f32_split_guard_reruns") counts the repeats
+ *   "f32_split_guard"  1 (default) = fp32 mode: a forward in which a value left the range of the hi/lo planes (|x| > 65504) is
+ *                      repeated on the exact-fp32 kernels: rz_vision_forward enqueues that second pass behind the first with the
+ *                      device guard word as every launch's predicate (its waves leave at once when the word is 0: ~75 empty
+ *                      launches) — no host read, so the call stays asynchronous and a captured forward carries the guard into
+ *                      every replay; rz_get_model_option(h, "f32_split_guard_reruns") reads the device-side count of repeats
+ *                      (it waits for the device first: not while a stream is capturing)
  *   "ln_fused"         1 (default) = the blocks' LayerNorms are fused into the GEMMs either side of them (16-bit modes);
  *                      0 = stand-alone LayerNorm kernels everywhere
  *   "sim_op"           VL-CABS similarity (losses.py:207-217): 0 (default) "cos" — the released config; 1 "dot" — RadZeroLoss's constructor
@@ -274,7 +277,8 @@ int rz_gemm_f32_split(int form, const float* a_dev, const float* w_dev, const fl
  * no gain and are known to the RZ_EXPERIMENTS tools library only.) */
 int rz_set_option(const char* name, int value);
 int rz_set_model_option(rz_handle_t h, const char* name, int value);
-/* the value in force for this handle (its own, else the process-wide one); also "f32_split_guard_reruns" */
+/* the value in force for this handle (its own, else the process-wide one); also "f32_split_guard_reruns" and the read-only facts of the last
+ * rz_vision_forward: "last_batch", "last_npad" (token rows per image after padding), "last_f32_form" (0 the dtype's own kernels | 1 three f16 planes | 2 MX form) */
 int rz_get_model_option(rz_handle_t h, const char* name, int* value_out);
 /* diagnostic library builds only (-DRZ_EXPERIMENTS, tools/kstamp8.py): "gemm_v8_stamps" = device buffer of 256 x 8 x 32 uint64 that the
  * stamped build of the persistent GEMM fills with per-wave K-loop / epilogue times; the production library knows no buffer */

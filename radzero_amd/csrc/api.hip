@@ -71,10 +71,18 @@ int* option_field(Options& o, const char* name) {
     return nullptr;
 }
 inline int pick(int own, int process_wide) { return own == RZ_OPT_INHERIT ? process_wide : own; }
+inline bool f32_drop_ok(int value) {
+#ifdef RZ_EXPERIMENTS
+    (void)value;
+    return true;
+#else
+    return value == RZ_OPT_INHERIT || (value & (64 | 128)) == 0;
+#endif
+}
 
 hipError_t flash_attn(int variant, int dt, const void* q, const void* k, const void* vt, void* ctx, int64_t bs, int B, int H, int nv, int np,
-                      hipStream_t s) {
-    return launch_flash_attn(dt, q, k, vt, ctx, bs, B, H, nv, np, variant, s);       // unknown values run the default shapes
+                      hipStream_t s, const unsigned* run_if = nullptr) {
+    return launch_flash_attn(dt, q, k, vt, ctx, bs, B, H, nv, np, variant, s, run_if);       // unknown values run the default shapes
 }
 
 int hip_fail(hipError_t e, const char* what) {
@@ -178,7 +186,8 @@ struct rz_model {
     int o_pad_rows() const { return pick(opt.pad_rows, g_opt.pad_rows); }
     bool o_sim_dot() const { return pick(opt.sim_op, g_opt.sim_op) == 1; }
     bool o_guard() const { return pick(opt.f32_split_guard, g_opt.f32_split_guard) != 0; }
-    bool force_exact = false;            // set while a forward is repeated on the exact-fp32 kernels (overflow guard)
+    bool force_exact = false;            // set while the exact-fp32 pass of a guarded forward is enqueued (overflow guard)
+    const unsigned* run_if = nullptr;    // that pass's predicate (the guard word): its kernels do nothing unless the word is set
     // padded token rows per image: a multiple of 128 (every GEMM M-tile and attention query block is full); of 256 when that costs less
     // than 2 % more rows, so that the 256x256 GEMM kernels apply at any batch size (one 1536^2 image: 11882 -> 12032 instead of 11904).
     // Round 5: also of 256 for an ODD batch whose 128-multiple is an odd one (B x rows would not be a multiple of 256: every GEMM on the 128 x 128
@@ -211,15 +220,16 @@ struct rz_model {
     DevBuf h, xn, qk, vt, ctx, mid, vws, qhat, lnpart, lnstat, lnmu;      // xn doubles as the residual's T copy on the fused-LayerNorm path
     DevBuf th, txn, tqkv, tctx, tmid, tsum;
     DevBuf asplit;                       // fp32 mode: [hi | lo | hi] f16 planes of the A operand of the GEMM in flight (3 x max K per token row)
-    DevBuf ovf;                          // fp32 mode: one word the hi/lo-split producers OR into when a value leaves the f16 range
-    unsigned* ovf_host = nullptr;        // pinned mirror of it
-    int64_t guard_reruns = 0;            // forwards repeated on the exact-fp32 kernels since rz_create
+    DevBuf ovf;                          // fp32 mode, 8 words: [0] the hi/lo-split producers OR into it when a value leaves a plane's range, [1..3] weight checks
+                                         // (rz_weights_ready), [4] forwards repeated on the exact-fp32 kernels since rz_create (counted on the device)
+    unsigned* ovf_host = nullptr;        // pinned mirror of words [0..3] (weight checks only: no forward reads it)
     struct SplitW { const char* p; size_t bytes; const char* p3; const char* p4; int e8_hi; };      // e8_hi: E8M0 scale byte of the MX copy's hi8 plane (lo8: 11 below)
     std::vector<SplitW> split_w;         // fp32 weight matrix -> its split copy
     bool split_dirty = true;             // a weight was (re)loaded since the split copies were built
     bool mx_weights_ok = false;          // every split weight fits the MX form's hi8 plane
     // state of the last vision forward
     int last_batch = 0, last_nvalid = 0, last_npad = 0;
+    int last_f32_form = 0;               // operand form of the last forward's GEMMs: 0 the dtype's own kernels (16-bit modes, exact fp32), 1 three f16 planes, 2 MX form
     // profiling
     bool prof = false;
     unsigned prof_mask = 0x1F;   // kernel families that record events (bit = rz_prof_family)
@@ -496,7 +506,7 @@ int gemm(rz_model* m, int epi, const void* A, int64_t lda, const void* W, int64_
     GemmArgs g;
     g.A = A; g.lda = lda; g.W = W; g.ldw = ldw; g.M = M; g.N = N; g.K = K; g.bias = bias; g.out = out; g.ldo = ldo;
     g.scale = scale; g.resid = resid; g.ldr = ldr; g.rows_per_image = rpi; g.heads_total = heads; g.plane_off = plane_off;
-    g.variant = m->o_gemm_variant(); g.raster = m->o_gemm_raster(); g.ovf_flag = (unsigned*)m->ovf.p;
+    g.variant = m->o_gemm_variant(); g.raster = m->o_gemm_raster(); g.ovf_flag = (unsigned*)m->ovf.p; g.run_if = m->run_if;
     ProfScope ps(m, RZ_PROF_GEMM, s);
     if (m->dt == RZ_F32 && m->o_gemm_f32_split()) {
         bool done = false;
@@ -751,7 +761,7 @@ int rz_weights_ready(rz_handle_t m) {
         // overflow guard words: [0] activations (cleared by every forward), [1] weights (checked here, once)
         // overflow guard words: [0] activations, [1] weights beyond the f16 range, [2] weights beyond their MX hi8 plane (cannot happen with per-matrix
         // scales unless a weight is not finite), [3] scratch of the per-matrix |w| maximum
-        RZ_HIP(m->ovf.ensure(16, true));
+        RZ_HIP(m->ovf.ensure(32, true));      // zeroed when allocated; a re-split (weights reloaded) clears the flags, not the re-run counter
         if (!m->ovf_host) RZ_HIP(hipHostMalloc((void**)&m->ovf_host, 16, hipHostMallocDefault));
         RZ_HIP(hipMemset(m->ovf.p, 0, 16));
         auto split = [&](Tensor& t, size_t N, size_t K) -> int {
@@ -866,33 +876,30 @@ static int vision_forward_once(rz_handle_t m, const float* px, int B, int C, int
 int rz_vision_forward(rz_handle_t m, const float* px, int B, int C, int Himg, int Wimg, float* tokens_out, void* stream) {
     if (!m || !px) return fail(RZ_ERR_INVALID, "rz_vision_forward: null argument");
     hipStream_t s = (hipStream_t)stream;
-    // fp32 mode on the f16 matrix pipe: the planes are f16, so an activation beyond +-65504 would turn into inf where fp32 stays finite.
-    // Every producer of planes raises a device word (rz_common.h flag_f16_range); it is read here once per forward — one stream
-    // synchronisation, in the mode whose step takes 200 ms — and a forward that raised it is repeated on the exact-fp32 MFMA kernels:
-    // fresh launches on the same stream, same buffers, nothing of the first pass survives.  Under stream capture no synchronisation is
-    // possible: a captured fp32 forward is not guarded (option "f32_split_guard" = 0 gives the same behaviour outside a capture).
+    // fp32 mode on the f16 matrix pipe: the planes are f16 / e4m3, so an activation beyond a plane's range would turn into inf where fp32 stays
+    // finite.  Every producer of planes raises a device word (rz_common.h flag_f16_range).  The guard never reads it on the host: behind the
+    // first pass the SAME forward is enqueued once more on the exact-fp32 MFMA kernels with that word as every launch's predicate
+    // (GemmArgs::run_if & co.: a wave reads the word and leaves at once when it is 0) — same stream, same buffers, nothing of the first pass
+    // survives when it runs, ~75 empty launches when it does not.  So the call stays asynchronous, it can be captured (hipGraph replays carry the
+    // guard), and the repeats are counted on the device (word [4], read lazily by rz_get_model_option "f32_split_guard_reruns").
     if (m->dt == RZ_F32) {       // builds the split weight copies and the guard words on first use
         const int rc0 = rz_weights_ready(m);
         if (rc0) return rc0;
     }
-    const bool split = m->dt == RZ_F32 && (m->o_gemm_f32_split() || m->o_attn_f32_split()) && m->ovf.p && m->ovf_host;
-    bool guard = split && m->o_guard();
-    if (guard) {
-        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-        if (hipStreamIsCapturing(s, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) guard = false;
-    }
-    if (split) RZ_HIP(hipMemsetAsync(m->ovf.p, 0, 4, s));
+    const bool split = m->dt == RZ_F32 && (m->o_gemm_f32_split() || m->o_attn_f32_split()) && m->ovf.p;
+    const bool guard = split && m->o_guard();
+    // the word is cleared by a kernel, not a hipMemsetAsync: a memset node between kernels was not ordered with them on graph replay (see EPI_PATCH_LN below)
+    if (split) RZ_HIP(launch_guard_word((unsigned*)m->ovf.p, 0, s));
     int rc = vision_forward_once(m, px, B, C, Himg, Wimg, tokens_out, stream);
     if (rc || !guard) return rc;
-    RZ_HIP(hipMemcpyAsync(m->ovf_host, m->ovf.p, 4, hipMemcpyDeviceToHost, s));
-    RZ_HIP(hipStreamSynchronize(s));
-    if (m->ovf_host[0]) {
-        m->force_exact = true;
-        rc = vision_forward_once(m, px, B, C, Himg, Wimg, tokens_out, stream);
-        m->force_exact = false;
-        m->guard_reruns += 1;
-    }
-    return rc;
+    m->force_exact = true;
+    m->run_if = (const unsigned*)m->ovf.p;
+    rc = vision_forward_once(m, px, B, C, Himg, Wimg, tokens_out, stream);
+    m->force_exact = false;
+    m->run_if = nullptr;
+    if (rc) return rc;
+    RZ_HIP(launch_guard_word((unsigned*)m->ovf.p, 1, s));
+    return 0;
 }
 
 static int vision_forward_once(rz_handle_t m, const float* px, int B, int C, int Himg, int Wimg, float* tokens_out, void* stream) {
@@ -928,8 +935,10 @@ static int vision_forward_once(rz_handle_t m, const float* px, int B, int C, int
         // kernel that runs it needs M % 256 == 0; option 1 (default) takes it where that kernel's grid fills the chip, 2 wherever it applies
         const int mxo = m->o_gemm_f32_mx();
         const bool mxg = sp && mxo != 0 && m->mx_weights_ok && M % 256 == 0 && (mxo == 2 || M >= 256 * 64);
+        if (!m->force_exact) m->last_f32_form = mxg ? 2 : sp ? 1 : 0;
         const int mxa = mxg ? m->o_attn_f32_mx() : 0;                         // the attention's MX form rides on the GEMMs' (its ctx leaves in the MX form)
-        // which of the attention's correction terms are dropped (flash_attn_split_kernel ABL): P V on the hi planes alone by default
+        // which of the attention's correction terms are dropped (flash_attn_split_kernel ABL): none by default; P V on the hi planes alone only with
+        // attn_f32_pv = 1 ('f32_precision fast': 1.2e-3 on the outlier checkpoint G8, outside the 1e-3 contract)
         const int drop = m->o_f32_drop();
         const int attn_abl = (m->o_attn_f32_pv() != 0 && !(drop & 128) ? 1 : 0) | ((drop & 128) ? 2 : 0) | ((drop & 64) ? 4 : 0);
         const int mx = mxg ? (1 | (mxa >= 1 && !(attn_abl & 1) ? 2 : 0) | (mxa >= 2 ? 4 : 0)) : 0;       // V^T needs no pair plane when P V runs on the hi planes alone
@@ -947,7 +956,7 @@ static int vision_forward_once(rz_handle_t m, const float* px, int B, int C, int
 
         {   // patch embedding: im2col + GEMM with (pos | cls | bias) table epilogue
             ProfScope ps(m, RZ_PROF_ROWOPS, s);
-            RZ_HIP(launch_im2col(m->dt, pxc, mid, Bc, C, Himg, Wimg, P, gh, gw, np, m->KPAD, s));
+            RZ_HIP(launch_im2col(m->dt, pxc, mid, Bc, C, Himg, Wimg, P, gh, gw, np, m->KPAD, s, m->run_if));
         }
         const int nblocks = (int)m->blocks.size();
         // LayerNorm fused into the GEMMs either side of it (gemm8.hip): every block of this chunk or none
@@ -987,7 +996,7 @@ static int vision_forward_once(rz_handle_t m, const float* px, int B, int C, int
             // no ViT blocks: Dinov2Model.layernorm (TF:dinov2/modeling_dinov2.py:469) acts on the embeddings, align blocks follow
             ProfScope ps(m, RZ_PROF_ROWOPS, s);
             if (fused) RZ_HIP(launch_ln_prepare(m->dt, h, (const float*)m->vit_ln_g.p, (const float*)m->vit_ln_b.p, eps, h, (const float*)m->blocks[0].ln1_g.p, xn, lnmu, stat, eps, M, D, s));
-            else RZ_HIP(launch_layernorm(m->dt, h, (const float*)m->vit_ln_g.p, (const float*)m->vit_ln_b.p, eps, nullptr, h, M, D, s));
+            else RZ_HIP(launch_layernorm(m->dt, h, (const float*)m->vit_ln_g.p, (const float*)m->vit_ln_b.p, eps, nullptr, h, M, D, s, m->run_if));
         } else if (fused && !patch_ln) {      // block 0 reads the patch-embedding output: copy + statistics by the row kernel
             ProfScope ps(m, RZ_PROF_ROWOPS, s);
             RZ_HIP(launch_ln_prepare(m->dt, h, nullptr, nullptr, 0.f, nullptr, (const float*)m->blocks[0].ln1_g.p, xn, lnmu, stat, eps, M, D, s));
@@ -1008,7 +1017,7 @@ static int vision_forward_once(rz_handle_t m, const float* px, int B, int C, int
             } else if (!fused) {
                 {
                     ProfScope ps(m, RZ_PROF_ROWOPS, s);
-                    RZ_HIP(launch_layernorm(m->dt, h, (const float*)b.ln1_g.p, (const float*)b.ln1_b.p, eps, xn, nullptr, M, D, s));
+                    RZ_HIP(launch_layernorm(m->dt, h, (const float*)b.ln1_g.p, (const float*)b.ln1_b.p, eps, xn, nullptr, M, D, s, m->run_if));
                 }
                 // q | k | v projection (TF:dinov2/modeling_dinov2.py:199-213): ONE launch over N = 3D where the persistent kernel
                 // applies (q, k -> per-head rows, v -> transposed, chosen per 256-column tile), else q|k and v separately
@@ -1039,7 +1048,7 @@ static int vision_forward_once(rz_handle_t m, const float* px, int B, int C, int
                     RZ_HIP(launch_flash_attn_f32_split((const float*)qb, (const float*)kb, (const float*)vtb, (float*)ctxb, mid, (int64_t)2 * H * np * 64,
                                                        Bc, H, nv, np, (unsigned*)m->ovf.p, s, 0, (attn_abl & 1) != 0));
                 else
-                    RZ_HIP(flash_attn(m->o_attn_variant(), m->dt, qb, kb, vtb, ctxb, (int64_t)2 * H * np * 64, Bc, H, nv, np, s));
+                    RZ_HIP(flash_attn(m->o_attn_variant(), m->dt, qb, kb, vtb, ctxb, (int64_t)2 * H * np * 64, Bc, H, nv, np, s, m->run_if));
             }
             if (sp) {
                 if ((rc = gemm(m, EPI_RESID_SCALE, ctxb, D, b.wo.p, D, M, D, D, (const float*)b.bo.p, nullptr, 0, (const float*)b.ls1.p, h, D, np, 0, s, A_SPLIT, false, 0, mx))) return rc;
@@ -1051,7 +1060,7 @@ static int vision_forward_once(rz_handle_t m, const float* px, int B, int C, int
                 if ((rc = gemm(m, EPI_RESID_SCALE, ctxb, D, b.wo.p, D, M, D, D, (const float*)b.bo.p, nullptr, 0, (const float*)b.ls1.p, h, D, np, 0, s))) return rc;
                 {
                     ProfScope ps(m, RZ_PROF_ROWOPS, s);
-                    RZ_HIP(launch_layernorm(m->dt, h, (const float*)b.ln2_g.p, (const float*)b.ln2_b.p, eps, xn, nullptr, M, D, s));
+                    RZ_HIP(launch_layernorm(m->dt, h, (const float*)b.ln2_g.p, (const float*)b.ln2_b.p, eps, xn, nullptr, M, D, s, m->run_if));
                 }
             } else {
                 if ((rc = gemm_resid_ln(m, ctxb, D, b.wo, b.bo, b.ls1, M, D, h, np, b.ln2_g, xn, part, lnmu, stat, eps, s))) return rc;
@@ -1084,7 +1093,7 @@ static int vision_forward_once(rz_handle_t m, const float* px, int B, int C, int
                 if (fused && !last)
                     RZ_HIP(launch_ln_prepare(m->dt, h, (const float*)m->vit_ln_g.p, (const float*)m->vit_ln_b.p, eps, h, (const float*)m->blocks[li + 1].ln1_g.p, xn, lnmu, stat, eps, M, D, s));
                 else
-                    RZ_HIP(launch_layernorm(m->dt, h, (const float*)m->vit_ln_g.p, (const float*)m->vit_ln_b.p, eps, nullptr, h, M, D, s));
+                    RZ_HIP(launch_layernorm(m->dt, h, (const float*)m->vit_ln_g.p, (const float*)m->vit_ln_b.p, eps, nullptr, h, M, D, s, m->run_if));
             }
         }
         return 0;
@@ -1119,7 +1128,7 @@ static int vision_forward_once(rz_handle_t m, const float* px, int B, int C, int
     m->last_npad = np;
     if (tokens_out) {
         ProfScope ps(m, RZ_PROF_ROWOPS, s);
-        RZ_HIP(launch_copy_tokens((const float*)m->h.p, tokens_out, B, nv, np, D, s));
+        RZ_HIP(launch_copy_tokens((const float*)m->h.p, tokens_out, B, nv, np, D, s, m->run_if));
     }
     return 0;
 }
@@ -1477,6 +1486,7 @@ int rz_set_option(const char* name, int value) {
     if (!strcmp(name, "gemm_v1_only")) { g_opt.gemm_variant = value ? 1 : 0; return 0; }
     int* f = option_field(g_opt, name);
     if (!f) return fail(RZ_ERR_INVALID, std::string("rz_set_option: unknown option ") + name);
+    if (f == &g_opt.f32_drop && !f32_drop_ok(value)) return fail(RZ_ERR_INVALID, "rz_set_option: f32_drop bits 64 / 128 (scores / P on the hi planes alone) exist only in the -DRZ_EXPERIMENTS tools build");
     *f = value;
     return 0;
 }
@@ -1485,6 +1495,7 @@ int rz_set_model_option(rz_handle_t m, const char* name, int value) {
     if (!m || !name) return fail(RZ_ERR_INVALID, "rz_set_model_option: null argument");
     int* f = option_field(m->opt, name);
     if (!f) return fail(RZ_ERR_INVALID, std::string("rz_set_model_option: unknown option ") + name);
+    if (f == &m->opt.f32_drop && !f32_drop_ok(value)) return fail(RZ_ERR_INVALID, "rz_set_model_option: f32_drop bits 64 / 128 (scores / P on the hi planes alone) exist only in the -DRZ_EXPERIMENTS tools build");
     if (f == &m->opt.pad_rows) {
         if (value != RZ_OPT_INHERIT && value != 0 && value != 128 && value != 256) return fail(RZ_ERR_INVALID, "rz_set_model_option: pad_rows is 0, 128 or 256");
         RZ_HIP(hipDeviceSynchronize());
@@ -1498,7 +1509,20 @@ int rz_set_model_option(rz_handle_t m, const char* name, int value) {
 
 int rz_get_model_option(rz_handle_t m, const char* name, int* value_out) {
     if (!m || !name || !value_out) return fail(RZ_ERR_INVALID, "rz_get_model_option: null argument");
-    if (!strcmp(name, "f32_split_guard_reruns")) { *value_out = (int)std::min<int64_t>(m->guard_reruns, INT32_MAX); return 0; }
+    if (!strcmp(name, "f32_split_guard_reruns")) {
+        // counted on the device behind each guarded forward: wait for the device's queued work, then read the word (not callable while a stream is capturing)
+        unsigned n = 0;
+        if (m->ovf.p && m->ovf.bytes >= 32) {
+            RZ_HIP(hipDeviceSynchronize());
+            RZ_HIP(hipMemcpy(&n, (const unsigned*)m->ovf.p + 4, 4, hipMemcpyDeviceToHost));
+        }
+        *value_out = (int)std::min<unsigned>(n, (unsigned)INT32_MAX);
+        return 0;
+    }
+    // read-only facts of the last rz_vision_forward (bench.py prices its roofline from these instead of re-deriving the padding rule)
+    if (!strcmp(name, "last_npad")) { *value_out = m->last_npad; return 0; }
+    if (!strcmp(name, "last_batch")) { *value_out = m->last_batch; return 0; }
+    if (!strcmp(name, "last_f32_form")) { *value_out = m->last_f32_form; return 0; }
     Options own = m->opt, proc = g_opt;
     int* fo = option_field(own, name);
     int* fp = option_field(proc, name);

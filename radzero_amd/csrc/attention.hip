@@ -94,8 +94,11 @@ __device__ __forceinline__ typename Traits<T>::frag lds_frag_row(const char* til
 template <typename T, int NW, int QT, bool LS = false, bool NOMAX = false, int ABL = 0, int NBUF = 2>
 __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : ((QT == 4 || sizeof(T) == 4) ? 2 : RZ_FA_WAVES)) void flash_attn_kernel(const T* __restrict__ q, const T* __restrict__ k,
                                                             const T* __restrict__ vT, T* __restrict__ ctx,
-                                                            int64_t qk_batch_stride, int B, int H, int n_valid, int n_pad) {
+                                                            int64_t qk_batch_stride, int B, int H, int n_valid, int n_pad, const unsigned* __restrict__ run_if) {
     typedef typename Traits<T>::frag frag_t;
+    if constexpr (sizeof(T) == 4) {      // exact-fp32 operands: predicated launch (fp32 mode's overflow guard, rz_kernels.h GemmArgs::run_if)
+        if (run_if && *run_if == 0) return;
+    }
     constexpr int NPAN = FaCfg<T>::NPAN;
     constexpr int TILE = FaCfg<T>::TILE_BYTES;
     constexpr int ES = (int)sizeof(T);
@@ -1345,7 +1348,7 @@ hipError_t launch_flash_attn_split_planes(const void* q_hi, const void* k_hi, co
 }
 
 hipError_t launch_flash_attn(int dtype, const void* q, const void* k, const void* vT, void* ctx,
-                             int64_t qk_batch_stride, int B, int H, int n_valid, int n_pad, int variant, hipStream_t s) {
+                             int64_t qk_batch_stride, int B, int H, int n_valid, int n_pad, int variant, hipStream_t s, const unsigned* run_if) {
     if (n_pad % FA_QROWS || n_valid <= 0 || n_valid > n_pad || B <= 0 || H <= 0) return hipErrorInvalidValue;
     // `variant` = option attn_variant.  Every 16-bit kernel: 4 waves per workgroup, row sums on the matrix pipe (LS); bf16 without the
     // running maximum in the hot loop (NOMAX), f16 with it.
@@ -1364,7 +1367,7 @@ hipError_t launch_flash_attn(int dtype, const void* q, const void* k, const void
     [[maybe_unused]] bool deep = false;
 #define RZ_FA(TT, NWV, QTV, LSV, NOMAXV, ABLV, NBUFV)                                                                                      \
     hipLaunchKernelGGL((flash_attn_kernel<TT, NWV, QTV, LSV, NOMAXV, ABLV, NBUFV>), dim3(((B * H * (n_pad / (16 * QTV * NWV)) + 7) / 8) * 8), \
-                       dim3(64 * NWV), 0, s, (const TT*)q, (const TT*)k, (const TT*)vT, (TT*)ctx, qk_batch_stride, B, H, n_valid, n_pad)
+                       dim3(64 * NWV), 0, s, (const TT*)q, (const TT*)k, (const TT*)vT, (TT*)ctx, qk_batch_stride, B, H, n_valid, n_pad, run_if)
 #ifdef RZ_EXPERIMENTS
     if (variant >= 1000 && variant < 3000) {                 // timing ablations: results wrong by construction (tools/attn_ablate.py)
         if (dtype != DT_BF16 || (variant >= 2000 && n_pad % 256)) return hipErrorInvalidValue;

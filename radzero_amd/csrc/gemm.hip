@@ -26,6 +26,9 @@ namespace rz {
 template <typename T, int EPI, typename OT = T>
 __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs g) {
     __shared__ __attribute__((aligned(1024))) char lds[4 * PANEL_BYTES];  // A0 A1 B0 B1
+    if constexpr (sizeof(T) == 4) {      // exact-fp32 instantiations: predicated launch (fp32 mode's overflow guard, rz_kernels.h GemmArgs::run_if)
+        if (g.run_if && *g.run_if == 0) return;
+    }
     constexpr bool SWAP = (EPI != EPI_VT && EPI != EPI_VT_LN);
     constexpr int KS = 128 / (32 * (int)sizeof(T));  // MFMA k-steps (of 32 elements) per panel
     typedef typename Traits<T>::frag frag_t;
@@ -120,6 +123,9 @@ constexpr int STAGE3_BYTES = (BM2 + BN3) * 128;   // 64 KB
 template <typename T, int EPI, typename OT = T>
 __global__ __launch_bounds__(512, 2) void gemm_kernel_v3(GemmArgs g) {
     __shared__ __attribute__((aligned(1024))) char lds[2 * STAGE3_BYTES];
+    if constexpr (sizeof(T) == 4) {      // exact-fp32 instantiations: predicated launch (GemmArgs::run_if)
+        if (g.run_if && *g.run_if == 0) return;
+    }
     constexpr bool SWAP = (EPI != EPI_VT);
     constexpr int KS = 128 / (32 * (int)sizeof(T));
     typedef typename Traits<T>::frag frag_t;

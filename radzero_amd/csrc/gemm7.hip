@@ -221,11 +221,9 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel_v7(GemmArgs g) {
     if (wr == 1) __builtin_amdgcn_s_barrier();          // group 1 runs one barrier behind group 0
 
     unsigned long long st[24];
-    unsigned long long clk0 = 0, rt0 = 0;
     if constexpr (MODE == 2) {
 #pragma unroll
         for (int i = 0; i < 24; ++i) st[i] = 0;
-        clk0 = __builtin_amdgcn_s_memtime(); rt0 = __builtin_amdgcn_s_memrealtime();
     }
     // E8M0 scale byte of this lane's 32-element block (block index = lane >> 4): A rows = [lo8 | hi8], W rows = [hi8 | lo8]
     const int sa = lg < 2 ? MX_E8_A_LO : MX_E8_A_HI, sw = lg < 2 ? g.mx_w_e8_hi : g.mx_w_e8_lo;      // per weight matrix (api.hip: chosen from its largest |w| when the planes are built)

@@ -43,8 +43,9 @@ __device__ __forceinline__ void row_layernorm(RowRegs<NV>& r, const float* gamma
 template <typename T, int NV>
 __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ in, const float* __restrict__ gamma,
                                                         const float* __restrict__ beta, float eps, T* out_t,
-                                                        float* out_f32, int64_t rows) {
+                                                        float* out_f32, int64_t rows, const unsigned* __restrict__ run_if) {
     constexpr int D = 256 * NV;
+    if (run_if && *run_if == 0) return;      // predicated launch (fp32 mode's overflow guard): wave-uniform
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
@@ -113,13 +114,13 @@ hipError_t launch_layernorm_split3(const float* in, const float* gamma, const fl
 }
 
 hipError_t launch_layernorm(int dtype, const float* in, const float* gamma, const float* beta, float eps,
-                            void* out_t, float* out_f32, int64_t rows, int D, hipStream_t s) {
+                            void* out_t, float* out_f32, int64_t rows, int D, hipStream_t s, const unsigned* run_if) {
     if (D != 768 || rows <= 0) return hipErrorInvalidValue;
     dim3 grid((unsigned)((rows + 3) / 4)), block(256);
     switch (dtype) {
-        case DT_F32: hipLaunchKernelGGL((layernorm_kernel<float, 3>), grid, block, 0, s, in, gamma, beta, eps, (float*)out_t, out_f32, rows); break;
-        case DT_BF16: hipLaunchKernelGGL((layernorm_kernel<bf16_t, 3>), grid, block, 0, s, in, gamma, beta, eps, (bf16_t*)out_t, out_f32, rows); break;
-        case DT_F16: hipLaunchKernelGGL((layernorm_kernel<f16_t, 3>), grid, block, 0, s, in, gamma, beta, eps, (f16_t*)out_t, out_f32, rows); break;
+        case DT_F32: hipLaunchKernelGGL((layernorm_kernel<float, 3>), grid, block, 0, s, in, gamma, beta, eps, (float*)out_t, out_f32, rows, run_if); break;
+        case DT_BF16: hipLaunchKernelGGL((layernorm_kernel<bf16_t, 3>), grid, block, 0, s, in, gamma, beta, eps, (bf16_t*)out_t, out_f32, rows, run_if); break;
+        case DT_F16: hipLaunchKernelGGL((layernorm_kernel<f16_t, 3>), grid, block, 0, s, in, gamma, beta, eps, (f16_t*)out_t, out_f32, rows, run_if); break;
         default: return hipErrorInvalidValue;
     }
     return hipGetLastError();
@@ -245,8 +246,9 @@ hipError_t launch_ln_l2norm(const float* in, int64_t ld_in, const float* gamma, 
 // read 42 runs of 56 bytes: 0.28 ms per 32 images against 0.13 for the bytes).  blockIdx.x == gh zero-fills the CLS row and the padding rows.
 template <typename T>
 __global__ __launch_bounds__(256) void im2col_kernel(const float* __restrict__ px, T* __restrict__ out, int B, int C,
-                                                     int Himg, int Wimg, int P, int gh, int gw, int n_pad, int k_pad) {
+                                                     int Himg, int Wimg, int P, int gh, int gw, int n_pad, int k_pad, const unsigned* __restrict__ run_if) {
     typedef typename Traits<T>::vec4 v4;
+    if (run_if && *run_if == 0) return;      // predicated launch (fp32 mode's overflow guard)
     extern __shared__ __attribute__((aligned(16))) char im2col_lds[];
     T* tile = reinterpret_cast<T*>(im2col_lds);          // [gw][pp4]: one channel of one patch row, P*P elements per patch (+ pad to 4)
     const int b = blockIdx.y, tid = threadIdx.x;
@@ -310,7 +312,7 @@ __global__ __launch_bounds__(256) void im2col_kernel(const float* __restrict__ p
 }
 
 hipError_t launch_im2col(int dtype, const float* px, void* out, int B, int C, int Himg, int Wimg, int patch, int gh,
-                         int gw, int n_pad, int k_pad, hipStream_t s) {
+                         int gw, int n_pad, int k_pad, hipStream_t s, const unsigned* run_if) {
     if (B <= 0 || gh * patch > Himg || gw * patch > Wimg || 1 + gh * gw > n_pad || C * patch * patch > k_pad || k_pad % 4) return hipErrorInvalidValue;
     const int pp4 = (patch * patch + 3) & ~3;
     const size_t es = dtype == DT_F32 ? 4 : 2;
@@ -322,9 +324,9 @@ hipError_t launch_im2col(int dtype, const float* px, void* out, int B, int C, in
         if (e != hipSuccess) return e;
     }
     switch (dtype) {
-        case DT_F32: hipLaunchKernelGGL(im2col_kernel<float>, grid, block, lds, s, px, (float*)out, B, C, Himg, Wimg, patch, gh, gw, n_pad, k_pad); break;
-        case DT_BF16: hipLaunchKernelGGL(im2col_kernel<bf16_t>, grid, block, lds, s, px, (bf16_t*)out, B, C, Himg, Wimg, patch, gh, gw, n_pad, k_pad); break;
-        case DT_F16: hipLaunchKernelGGL(im2col_kernel<f16_t>, grid, block, lds, s, px, (f16_t*)out, B, C, Himg, Wimg, patch, gh, gw, n_pad, k_pad); break;
+        case DT_F32: hipLaunchKernelGGL(im2col_kernel<float>, grid, block, lds, s, px, (float*)out, B, C, Himg, Wimg, patch, gh, gw, n_pad, k_pad, run_if); break;
+        case DT_BF16: hipLaunchKernelGGL(im2col_kernel<bf16_t>, grid, block, lds, s, px, (bf16_t*)out, B, C, Himg, Wimg, patch, gh, gw, n_pad, k_pad, run_if); break;
+        case DT_F16: hipLaunchKernelGGL(im2col_kernel<f16_t>, grid, block, lds, s, px, (f16_t*)out, B, C, Himg, Wimg, patch, gh, gw, n_pad, k_pad, run_if); break;
         default: return hipErrorInvalidValue;
     }
     return hipGetLastError();
@@ -469,16 +471,29 @@ hipError_t launch_image_features(const float* tokens, int64_t image_stride, int 
 
 // ---- compact copy of the valid tokens: [B][Npad][D] -> [B][N][D] ----
 __global__ __launch_bounds__(256) void copy_tokens_kernel(const float* __restrict__ src, float* __restrict__ dst, int n_valid,
-                                                          int n_pad, int D4) {
+                                                          int n_pad, int D4, const unsigned* __restrict__ run_if) {
+    if (run_if && *run_if == 0) return;      // predicated launch (fp32 mode's overflow guard)
     const int tok = blockIdx.x, b = blockIdx.y;
     const f32x4* s4 = reinterpret_cast<const f32x4*>(src) + ((int64_t)b * n_pad + tok) * D4;
     f32x4* d4 = reinterpret_cast<f32x4*>(dst) + ((int64_t)b * n_valid + tok) * D4;
     for (int i = threadIdx.x; i < D4; i += blockDim.x) d4[i] = s4[i];
 }
 
-hipError_t launch_copy_tokens(const float* src, float* dst, int B, int n_valid, int n_pad, int D, hipStream_t s) {
+hipError_t launch_copy_tokens(const float* src, float* dst, int B, int n_valid, int n_pad, int D, hipStream_t s, const unsigned* run_if) {
     if (D % 4) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(copy_tokens_kernel, dim3(n_valid, B), dim3(192), 0, s, src, dst, n_valid, n_pad, D / 4);
+    hipLaunchKernelGGL(copy_tokens_kernel, dim3(n_valid, B), dim3(192), 0, s, src, dst, n_valid, n_pad, D / 4, run_if);
+    return hipGetLastError();
+}
+
+// ---- fp32 mode's overflow guard words (rz_kernels.h launch_guard_word) ----
+__global__ void guard_word_kernel(unsigned* __restrict__ words, int op) {
+    if (op == 0) words[0] = 0;
+    else if (words[0]) words[4] += 1;
+}
+
+hipError_t launch_guard_word(unsigned* words, int op, hipStream_t s) {
+    if (!words || (op != 0 && op != 1)) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(guard_word_kernel, dim3(1), dim3(1), 0, s, words, op);
     return hipGetLastError();
 }
 

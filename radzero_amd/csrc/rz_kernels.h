@@ -45,6 +45,7 @@ struct GemmArgs {
     int64_t plane_off = 0;        // hi/lo-split outputs (fp32 mode, EPI_HEADS / EPI_VT): elements from the hi plane to the lo plane
     unsigned* ovf_flag = nullptr; // hi/lo-split outputs: word that receives 1 when a value leaves the f16 range (rz_common.h flag_f16_range)
     int mx_w_e8_hi = 123, mx_w_e8_lo = 112;   // fp32 mode, MX form: E8M0 scale bytes (127 + log2 scale) of THIS weight matrix's hi8 / lo8 planes; defaults = 2^-4 / 2^-15 (rz_common.h)
+    const unsigned* run_if = nullptr;  // exact-fp32 kernels only (fp32 mode's overflow guard, api.hip rz_vision_forward): non-null => the launch does nothing unless *run_if != 0
     int raster = 0;               // gemm12.hip tile order inside an XCD: 0 = gemm8's (4 x tiles_n groups) | S > 0 = slab walk, slabs of <= S n tiles
     int variant = 0;              // kernel choice: 0 auto | 1 128x128 two-stage | 3 256x256 two-stage | 7 staggered 8-phase (gemm7.hip) | 8 persistent (gemm8.hip) | 10 persistent, 4 waves x 128x128, asm K loop (gemm10.hip) | 11 persistent, 8 waves, one phase per K tile (gemm11.hip)
 };
@@ -88,7 +89,7 @@ hipError_t launch_flash_attn_split_planes(const void* q_hi, const void* k_hi, co
                                           int mx_out = 0, int mxa = 0, int abl = 0);      // mx_out: ctx in the MX form (4 bytes per element) instead of [hi | lo | hi] f16;
                                                                              // mxa: the second planes are e4m3 pair planes (attention.hip "MXA")
 hipError_t launch_flash_attn(int dtype, const void* q, const void* k, const void* vT, void* ctx,
-                             int64_t qk_batch_stride, int B, int H, int n_valid, int n_pad, int waves, hipStream_t s);
+                             int64_t qk_batch_stride, int B, int H, int n_valid, int n_pad, int waves, hipStream_t s, const unsigned* run_if = nullptr);   // run_if: fp32 operands only, see GemmArgs::run_if
 
 // MPNet self-attention for short sequences: qkv [T*L][3*H*64] (q|k|v), additive relative-position bias expanded by the
 // host to rel_bias[H][L][L], key-padding mask [T][L]; ctx [T*L][H*64].
@@ -115,12 +116,16 @@ hipError_t launch_image_features(const float* tokens, int64_t image_stride, int 
 // fp32 (out_f32, may alias in).
 hipError_t launch_layernorm_split3(const float* in, const float* gamma, const float* beta, float eps, void* out3, int64_t rows, int D, unsigned* ovf_flag, hipStream_t s, int mx = 0);   // mx: the MX form (rz_common.h), 4 D bytes per row
 hipError_t launch_layernorm(int dtype, const float* in, const float* gamma, const float* beta, float eps,
-                            void* out_t, float* out_f32, int64_t rows, int D, hipStream_t s);
+                            void* out_t, float* out_f32, int64_t rows, int D, hipStream_t s, const unsigned* run_if = nullptr);
+
+// fp32 mode's overflow guard (api.hip rz_vision_forward): words[0] = the flag the plane producers raise, words[4] = forwards repeated so far.
+// op 0: words[0] = 0 (start of a forward); op 1: if (words[0]) ++words[4] (behind the predicated exact-fp32 pass)
+hipError_t launch_guard_word(unsigned* words, int op, hipStream_t s);
 
 // im2col for the 14x14/stride-14 patch conv: pixels fp32 [B][C][H][W] -> A<T>[B][Npad][Kpad];
 // row 0 (CLS) and rows >= 1+gh*gw are zero; columns >= C*14*14 are zero.
 hipError_t launch_im2col(int dtype, const float* px, void* out, int B, int C, int Himg, int Wimg, int patch,
-                         int gh, int gw, int n_pad, int k_pad, hipStream_t s);
+                         int gh, int gw, int n_pad, int k_pad, hipStream_t s, const unsigned* run_if = nullptr);
 
 // MPNet embeddings: word_emb[ids] + pos_emb[pos_ids(ids)] -> LN -> h fp32 + T copy.
 hipError_t launch_text_embed(int dtype, const int64_t* ids, const float* word_emb, const float* pos_emb,
@@ -165,6 +170,6 @@ hipError_t launch_preprocess_batch(const void* descs_host, int n, int max_ph, in
                                    unsigned char* ws, float* out, int minmax_normalize, hipStream_t s);
 
 // strided gather of valid tokens: src [B][Npad][D] -> dst [B][N][D]
-hipError_t launch_copy_tokens(const float* src, float* dst, int B, int n_valid, int n_pad, int D, hipStream_t s);
+hipError_t launch_copy_tokens(const float* src, float* dst, int B, int n_valid, int n_pad, int D, hipStream_t s, const unsigned* run_if = nullptr);
 
 }  // namespace rz

@@ -51,6 +51,23 @@ def test_launcher_terminates_ranks_left_waiting_for_a_dead_one():
     assert time.time() - t0 < 60
 
 
+def test_launcher_overall_timeout_when_every_rank_hangs():
+    """ranks that all deadlock without any of them exiting must not hang the launcher forever."""
+    src = f"import bench, sys; sys.exit(bench.launch_ranks(2, [], child_cmd={STUB!r}, grace_s=1.0, overall_timeout_s=3.0))"
+    t0 = time.time()
+    r = subprocess.run([sys.executable, "-c", src], capture_output=True, text=True, timeout=120, cwd=ROOT,
+                       env=dict(os.environ, RZ_STUB_HANG="all"))
+    assert r.returncode != 0 and "no rank has finished after 3 s" in r.stderr and "terminating rank 0" in r.stderr and "terminating rank 1" in r.stderr, r.stderr
+    assert r.stdout.strip() == "" and time.time() - t0 < 60
+
+
+def test_visible_gpu_count_loads_no_gpu_library():
+    """the launcher parent counts GPUs from the KFD topology (or skips the check), never through torch.cuda / HIP."""
+    src = "import bench, torch; n = bench.visible_gpu_count(); assert n is None or n >= 0; assert not torch.cuda.is_initialized(); print('ok', n)"
+    r = subprocess.run([sys.executable, "-c", src], capture_output=True, text=True, timeout=120, cwd=ROOT)
+    assert r.returncode == 0 and r.stdout.startswith("ok"), r.stderr
+
+
 def test_single_rank_through_the_launcher():
     r = _run(["--gpus", "1", "--launch", "--force-dist"])
     assert r.returncode == 0, r.stderr
