@@ -406,6 +406,40 @@ def short_run(sd, cfg, device, dtype, B, S, T, maps, min_len, max_len, steps=5, 
         torch.cuda.empty_cache()
 
 
+def driver_leg(sd, cfg, device, dtype="bf16", B=64, S=518, T=14, n_batches=24):
+    """The reference's evaluation loop at its own operating point (calculate_similarities over a DataLoader of 518^2 x 64 batches:
+    exp/cxr_pt/inference/utils.py:70-106, configs/radzero.yaml:19, config.yaml:55) through radzero_amd.inference.calculate_similarities, with and
+    without batch shaping (the stream of 64-image batches re-cut into forwards of model.preferred_batch(64, 518, 518) = 62 images: whole rounds
+    of the persistent GEMM's 256 tiles).  Pixels resident in HBM; timed: the whole driver call, logits on the host at the end."""
+    from radzero_amd.inference import calculate_similarities
+    from radzero_amd.modeling import RadZeroModel
+    model = RadZeroModel.from_state_dict(sd, cfg, torch_dtype=DTYPES[dtype], device=device).eval()
+    try:
+        g = torch.Generator(device=device).manual_seed(99)
+        px = torch.randn((B, 3, S, S), generator=g, device=device, dtype=torch.float32)
+        ids, mask = synthetic_prompts(T, 6, 10, 4321)
+        tb = {"encoded_key_phrases": {"input_ids": torch.from_numpy(ids).to(device), "attention_mask": torch.from_numpy(mask).to(device)}}
+        res, logits = {}, {}
+        for shaping in (False, True, False, True):
+            calculate_similarities([px] * 2, tb, model, batch_shaping=shaping)            # warm-up: workspaces for this forward size
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            logits[shaping] = calculate_similarities([px] * n_batches, tb, model, batch_shaping=shaping)
+            dt = time.perf_counter() - t0
+            res.setdefault(shaping, []).append(B * n_batches / dt)
+        same = bool((logits[True] == logits[False]).all())
+        pref = model.preferred_batch(B, S, S)
+        return {"workload": f"batch driver calculate_similarities over {n_batches} batches of {B} x {S}x{S} images, {T} cached prompts, {dtype}; pixels resident in HBM, "
+                            f"logits to the host at the end (the reference's evaluation loop at its own operating point)",
+                "images_per_s_as_batched": round(max(res[False]), 1), "images_per_s_batch_shaping": round(max(res[True]), 1),
+                "forward_size_with_shaping": pref, "gain": round(max(res[True]) / max(res[False]), 4), "logits_bit_identical": same,
+                "all_runs_images_per_s": {"as_batched": [round(v, 1) for v in res[False]], "batch_shaping": [round(v, 1) for v in res[True]]}}
+    finally:
+        model.close()
+        del model
+        torch.cuda.empty_cache()
+
+
 def request_leg(sd, cfg, device, dtype="bf16", S=1024, steps=24, warmup=6):
     """The reference's per-request path (eval_refer_grounding, exp/cxr_pt/inference/grounding_utils.py:283-326; extract_similarity_map,
     visualization/attention_map_base.py:12-42): ONE image and ONE text that the model has never seen per request, compute_logits + the
@@ -885,6 +919,7 @@ def main():
             res["per_request"] = request_leg(sd, cfg, device)
             res["per_request_518"] = request_leg(sd, cfg, device, S=518)      # the released model's own resolution (radzero.yaml:19): the README's single-image call
             # the same two requests in the mode that meets north_star's 1e-3 (the reference's own inference precision: run.py:135-137, inference/utils.py:37)
+            res["batch_driver_518"] = driver_leg(sd, cfg, device)      # 518^2 x 64 through the batch driver, with / without batch shaping
             res["per_request_f32"] = request_leg(sd, cfg, device, dtype="f32", steps=12, warmup=4)
             res["per_request_518_f32"] = request_leg(sd, cfg, device, dtype="f32", S=518, steps=12, warmup=4)
             # north_star's tolerance (1e-3 on logits and maps) is met by the fp32 mode only: its throughput on the SAME shape,

@@ -80,6 +80,11 @@ int rz_set_position_table(rz_handle_t h, int grid_h, int grid_w, const float* po
 /* Workspace for up to max_batch images of max_tokens (= 1 + grid_h*grid_w) tokens, max_prompts prompts of
  * max_prompt_len tokens.  Re-callable (grows only). */
 int rz_reserve(rz_handle_t h, int max_batch, int max_tokens, int max_prompts, int max_prompt_len);
+/* Token rows per image that rz_vision_forward gives a batch of `batch` images of n_tokens (= 1 + grid_h*grid_w) tokens under the handle's
+ * "pad_rows" rule (batch = 0: the batch-independent upper bound that sizes tables and workspaces).  Host arithmetic only; it lets a batch
+ * driver price a batch's GEMM tile rounds (radzero_amd/inference.py batch shaping; the reference's drivers take the DataLoader's batch as
+ * it comes: exp/cxr_pt/inference/utils.py:81-100) without re-implementing the rule. */
+int rz_padded_tokens(rz_handle_t h, int n_tokens, int batch, int* n_pad_out);
 
 /* ---- CxrAlignModel.forward_vision_model (modeling.py:96-123): Dinov2Model + AlignTransformer ----
  * pixel_values_dev: fp32 (batch, channels, height, width).  The aligned tokens stay inside the handle

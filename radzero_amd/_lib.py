@@ -139,6 +139,7 @@ SYMBOLS = {
     "rz_weights_ready": (_I, [_P]),
     "rz_set_position_table": (_I, [_P, _I, _I, _P]),
     "rz_reserve": (_I, [_P, _I, _I, _I, _I]),
+    "rz_padded_tokens": (_I, [_P, _I, _I, ctypes.POINTER(_I)]),
     "rz_vision_forward": (_I, [_P, _P, _I, _I, _I, _I, _P, _P]),
     "rz_text_forward": (_I, [_P, _P, _P, _I, _I, _P, _P, _P]),
     "rz_vlcabs": (_I, [_P, _P, _I, _I, _P, _P, _P, _P]),

@@ -827,6 +827,12 @@ int rz_set_position_table(rz_handle_t m, int gh, int gw, const float* pos_host) 
     return 0;
 }
 
+int rz_padded_tokens(rz_handle_t m, int n_tokens, int batch, int* n_pad_out) {
+    if (!m || !n_pad_out || n_tokens <= 0 || batch < 0) return fail(RZ_ERR_INVALID, "rz_padded_tokens: bad argument");
+    *n_pad_out = m->pad_tokens(n_tokens, batch);
+    return 0;
+}
+
 int rz_reserve(rz_handle_t m, int max_batch, int max_tokens, int max_prompts, int max_len) {
     if (!m || max_batch < 0 || max_tokens < 0 || max_prompts < 0 || max_len < 0) return fail(RZ_ERR_INVALID, "rz_reserve: bad argument");
     const size_t es = dsize(m->dt), D = m->D, F = m->F;

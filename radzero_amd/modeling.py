@@ -682,6 +682,25 @@ class RadZeroModel:
         for k, v in self.F32_PRECISIONS[level].items():
             self.set_model_option(k, v)
 
+    # ---- batch shaping (host logic) ---------------------------------------------------------------
+    def padded_tokens(self, n_tokens: int, batch: int = 0) -> int:
+        """Token rows per image a batch of `batch` images gets (rz_padded_tokens: the handle's pad_rows rule)."""
+        v = ctypes.c_int(0)
+        _lib.check(self._lib.rz_padded_tokens(self._h, int(n_tokens), int(batch), ctypes.byref(v)), "rz_padded_tokens")
+        return int(v.value)
+
+    def preferred_batch(self, batch: int, height: int, width: int, max_drop: Optional[int] = None, min_gain: float = 0.02) -> int:
+        """The forward size <= `batch` a batch driver should use when images of this size arrive in batches of `batch`
+        (radzero_amd/shaping.py: whole rounds of the persistent GEMM's 256 tiles; 518^2 x 64 -> 62)."""
+        from .shaping import preferred_batch
+        p = self.config.patch_size
+        return preferred_batch(int(batch), (height // p) * (width // p) + 1, self.padded_tokens, self.config.hidden_size, self.config.mlp_ratio, max_drop, min_gain)
+
+    def gemm_tile_cost(self, batch: int, n_tokens: int) -> float:
+        """radzero_amd/shaping.py gemm_tile_cost under this handle's padding rule (diagnostics: tools/shaping_sweep.py)."""
+        from .shaping import gemm_tile_cost
+        return gemm_tile_cost(int(batch), int(n_tokens), self.padded_tokens, self.config.hidden_size, self.config.mlp_ratio)
+
     def guard_reruns(self) -> int:
         """fp32 mode: forwards repeated on the exact-fp32 kernels because a value left the f16 planes' range (a checkpoint that trips the
         guard on every forward runs at a quarter of the speed: the batch driver warns once, bench.py prints the count)."""

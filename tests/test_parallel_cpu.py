@@ -333,3 +333,70 @@ def test_batch_driver_with_projected_text_features_gloo():
         p.join(timeout=60)
         assert p.exitcode == 0
     assert res[1] is None and res[2] is None and np.array_equal(np.asarray(res[0], np.float32), want)
+
+
+# ---- batch shaping (round 6): host logic only -------------------------------------------------------------------------------------------
+def _pad_rule(nv, batch=0):
+    """csrc/api.hip rz_model::pad_tokens, default rule (test-side restatement: the product asks the library, rz_padded_tokens)"""
+    p128, p256 = (nv + 127) // 128 * 128, (nv + 255) // 256 * 256
+    if (p256 - nv) * 50 <= nv:
+        return p256
+    odd = p128 != p256 and (p256 - p128) * 10 <= p128
+    return p256 if odd and (batch == 0 or ((batch & 1) and batch * p256 >= 4 * 256)) else p128
+
+
+def test_preferred_batch_picks_whole_tile_rounds():
+    from radzero_amd.shaping import gemm_tile_cost, preferred_batch
+    # the reference's evaluation point: 518^2 (N = 1370), batch 64 -> 62 (341 row tiles x 3 = 1023 tiles = 4 rounds of 256; 64: 1056 -> 5)
+    assert preferred_batch(64, 1370, _pad_rule) == 62
+    assert gemm_tile_cost(62, 1370, _pad_rule) < 0.92 * gemm_tile_cost(64, 1370, _pad_rule)
+    # the headline shape is already whole rounds (672 row tiles: 7.9 / 23.6 / 31.5 rounds): untouched; so are tiny batches and shapes below the model's range
+    assert preferred_batch(32, 5330, _pad_rule) == 32 and preferred_batch(16, 5330, _pad_rule) == 16
+    assert preferred_batch(1, 11882, _pad_rule) == 1 and preferred_batch(4, 1370, _pad_rule) == 4 and preferred_batch(64, 257, _pad_rule) == 64
+    for b in (8, 24, 40, 64, 96, 128, 200):
+        for n in (257, 1370, 5330):
+            p = preferred_batch(b, n, _pad_rule)
+            assert b - max(2, b // 16) <= p <= b                       # never larger than the caller's batch, never far below it
+
+
+class _ShapedModel(_FakeModel):
+    def __init__(self, target):
+        super().__init__()
+        self.target, self.forward_sizes = target, []
+
+    def preferred_batch(self, batch, height, width):
+        return self.target if batch > self.target else batch
+
+    def compute_logits(self, pixel_values, encoded_key_phrases, text_features=None, **kw):
+        self.forward_sizes.append(int(pixel_values.shape[0]))
+        return super().compute_logits(pixel_values, encoded_key_phrases, text_features=text_features, **kw)
+
+
+def test_reshape_batches_keeps_order_rows_and_results():
+    """`_reshape_batches` re-cuts 64, 64, 64, 10 images into forwards of 62, 62, 62, 16 — same images, same order; the SOURCE batch sizes are what
+    the distributed interleave receives; a size that is already good passes through untouched."""
+    import numpy as np
+    import torch
+
+    from radzero_amd.inference import _reshape_batches
+    sizes = [64, 64, 64, 10]
+    tag = 0
+    batches = []
+    for s in sizes:
+        batches.append(torch.arange(tag, tag + s, dtype=torch.float32).view(s, 1, 1, 1).expand(s, 3, 2, 2).contiguous())
+        tag += s
+    m = _ShapedModel(62)
+    rows = []
+    out = list(_reshape_batches(iter(batches), m, rows, enabled=True))
+    assert [int(o.shape[0]) for o in out] == [62, 62, 62, 16] and rows == sizes
+    assert np.array_equal(torch.cat(out)[:, 0, 0, 0].numpy(), np.arange(202, dtype=np.float32))
+    rows2 = []
+    same = list(_reshape_batches(iter(batches), _ShapedModel(64), rows2, enabled=True))
+    assert all(a is b for a, b in zip(same, batches)) and rows2 == sizes
+    rows3 = []
+    off = list(_reshape_batches(iter(batches), m, rows3, enabled=False))
+    assert all(a is b for a, b in zip(off, batches)) and rows3 == sizes
+    # a change of resolution inside the stream flushes what is pending first (order kept)
+    mixed = [batches[0], torch.zeros((5, 3, 4, 4)), batches[1]]
+    got = list(_reshape_batches(iter(mixed), _ShapedModel(62), [], enabled=True))
+    assert [tuple(g.shape) for g in got] == [(62, 3, 2, 2), (2, 3, 2, 2), (5, 3, 4, 4), (62, 3, 2, 2), (2, 3, 2, 2)]
