@@ -197,6 +197,12 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel_v8(GemmArgs g) {
 
     auto tile_origin = [&](int idx, int& m0, int& n0) {
         int tm, tn;
+#ifdef RZ_EXPERIMENTS
+        // tile-walk experiment (option gemm_raster = 100 + G): groups of G row tiles instead of 4 — G = 1: the workgroups of an XCD take
+        // the N / 256 column tiles of ONE 256-row A panel back to back (the panel is fetched once per XCD and stays in its L2)
+        if (g.raster >= 100) tile_coords_rt(g.raster - 100, lo + idx, tiles_m, tiles_n, tm, tn);
+        else
+#endif
         tile_coords<4>(lo + idx, tiles_m, tiles_n, tm, tn);
         m0 = tm * V8_BM;
         n0 = tn * V8_BN;

@@ -25,6 +25,17 @@ __device__ __forceinline__ void tile_coords(int id, int tiles_m, int tiles_n, in
     tn = r / gsz;
 }
 
+// the same with GROUP_M chosen at run time (gemm8.hip's tile-walk experiment, GemmArgs::raster >= 100)
+__device__ __forceinline__ void tile_coords_rt(int group_m, int id, int tiles_m, int tiles_n, int& tm, int& tn) {
+    const int per_group = group_m * tiles_n;
+    const int grp = id / per_group;
+    const int first_m = grp * group_m;
+    const int gsz = min(tiles_m - first_m, group_m);
+    const int r = id - grp * per_group;
+    tm = first_m + r % gsz;
+    tn = r / gsz;
+}
+
 // Read-modify-write epilogues on the fp32 residual stream (EPI_RESID_SCALE, EPI_RESID_ADD) and the patch-embedding table
 // add (EPI_PATCH) for one wave's 64x64 block.  These epilogues are LATENCY bound if written as "load, wait, compute,
 // store" per MFMA tile (what the generic loop below compiles to: `if (g.bias)` per tile + s_waitcnt vmcnt(0) before every
