@@ -99,8 +99,41 @@ def pmc_traffic(kernel, batch, side, dtype):
     return None, None
 
 
+def physical_cores():
+    """Physical cores of the host: distinct (physical id, core id) pairs of /proc/cpuinfo (SMT siblings share one); logical count if unreadable."""
+    try:
+        seen, phys, core = set(), None, None
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("physical id"):
+                phys = line.split(":", 1)[1].strip()
+            elif line.startswith("core id"):
+                core = line.split(":", 1)[1].strip()
+            elif not line.strip():
+                if phys is not None and core is not None:
+                    seen.add((phys, core))
+                phys = core = None
+        if phys is not None and core is not None:
+            seen.add((phys, core))
+        if seen:
+            return len(seen)
+    except OSError:
+        pass
+    return os.cpu_count() or 1
+
+
+def recorded_thread_sweep():
+    """profiles/r06/cpu_threads_sweep.json (tools/cpu_threads_sweep.py, run once on the GPU box's host): images/s of this CPU leg at 16 / 32 / 64 / 128 threads."""
+    for rnd in ("r06",):
+        try:
+            return json.load(open(os.path.join(ROOT, "profiles", rnd, "cpu_threads_sweep.json"))), f"profiles/{rnd}/cpu_threads_sweep.json"
+        except (OSError, ValueError):
+            pass
+    return None, None
+
+
 def usable_cores():
-    """CPU cores this process may actually use: affinity mask and cgroup quota, not the host's core count."""
+    """Threads of the CPU baseline: what this process may use (affinity mask, cgroup quota); on an unconstrained view of a big host the thread count that
+    MEASURED fastest in the recorded sweep (a measurement, not a choice), 16 if no sweep is committed."""
     n = os.cpu_count() or 1
     try:
         n = min(n, len(os.sched_getaffinity(0)))
@@ -112,8 +145,9 @@ def usable_cores():
             n = min(n, max(1, int(int(quota) / int(period))))
     except (OSError, ValueError):
         pass
-    if n > 64:          # unconstrained view of a big host (no affinity mask, no cgroup quota): use the GPU box's per-GPU share.
-        n = 16          # gpurun's process guard sizes a one-GPU call to 16 workers; the other cores belong to the other 7 GPUs' jobs
+    if n > 64:
+        sweep, _ = recorded_thread_sweep()
+        n = min(n, int(sweep["fastest_threads"])) if sweep else 16
     return n
 
 
@@ -125,9 +159,15 @@ def cores_note():
     except (AttributeError, OSError):
         aff = host
     used = usable_cores()
-    why = ("all of them" if used == min(host, aff) else
-           "by choice: one GPU's share of an 8-GPU host (16 workers per GPU is also gpurun's process-guard sizing); the affinity mask / cgroup do not restrict this process")
-    return f"host exposes {host} logical CPUs, affinity mask {aff}; {used} threads used ({why})"
+    sweep, src = recorded_thread_sweep()
+    if used == min(host, aff):
+        why = "all of them"
+    elif sweep:
+        why = (f"the fastest of the recorded sweep on this CPU model ({src}: " + ", ".join(f"{k} threads {v} images/s" for k, v in sweep["images_per_s_by_threads"].items()) +
+               "): more threads are SLOWER on this 2-socket host shared with the other GPUs' jobs")
+    else:
+        why = "no thread sweep is committed: one GPU's share of an 8-GPU host"
+    return f"host exposes {host} logical CPUs = {physical_cores()} physical cores, affinity mask {aff}; {used} threads used ({why})"
 
 
 def cpu_model_name():
@@ -193,7 +233,7 @@ def cpu_baseline(cfg, sd, side, n_prompts, ids, mask, eager=False, all_cores=Fal
         finally:
             torch.set_num_threads(cores)
     recorded = "" if (eager and all_cores) else "; " + CPU_RECORDED
-    return {"value": round(res[best][0], 5), "unit": "images/s", "cores": cores, "kind": "port",
+    return {"value": round(res[best][0], 5), "unit": "images/s", "cores": cores, "physical_cores_of_host": physical_cores(), "kind": "port",
             "sample": f"{side}x{side} x {n_prompts} cached prompts, fp32, torch CPU, {cores} threads on {cpu_model_name()} [{cores_note()}], "
                       f"1 warm-up + median of 3; {desc}; value = {best}{all_note}{recorded}"}
 

@@ -32,6 +32,12 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_cfg5 -- pytho
 echo "[profile] cfg5 trace done"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_f32 -- python3 bench.py --dtype f32 --steps 3 --warmup 1 --no-cpu-baseline --no-other-configs > $OUT/bench_f32_under_rocprof.json 2> $OUT/trace_f32.err
 echo "[profile] fp32-mode trace done"
+# 5. (round 6) the fp32 (1e-3) mode's HBM traffic: FETCH / WRITE passes of `bench.py --dtype f32` -> hbm_traffic_pmc_f32.json (bench.py's fp32 `roofline.traffic`)
+PMCF="python3 bench.py --dtype f32 --steps 2 --warmup 1 --no-cpu-baseline --no-other-configs --no-kernel-events"
+rocprofv3 --kernel-trace --mangled-kernels --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch_f32 -- $PMCF > $OUT/pmc_fetch_f32.json 2> $OUT/pmc_fetch_f32.err
+rocprofv3 --kernel-trace --mangled-kernels --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write_f32 -- $PMCF > $OUT/pmc_write_f32.json 2> $OUT/pmc_write_f32.err
+python3 tools/pmc_summary_f32.py $OUT > /dev/null
+echo "[profile] fp32-mode FETCH / WRITE passes done"
 for c in cfg4 cfg5 f32; do f=$(find $OUT/trace_$c -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $OUT/summary/kernel_stats_$c.csv; cp $OUT/bench_${c}_under_rocprof.json $OUT/summary/ || true; done
 # drop the bulky per-dispatch traces, keep the summaries (gpurun merges <= 64 MiB back)
 find $OUT -name "*kernel_trace.csv" -size +20M -delete || true
