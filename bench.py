@@ -131,20 +131,28 @@ def recorded_thread_sweep():
     return None, None
 
 
+def cpu_limits():
+    """(logical CPUs of the host, CPUs in this process's affinity mask, cgroup CPU quota in CPUs or None)"""
+    host = os.cpu_count() or 1
+    try:
+        aff = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        aff = host
+    quota = None
+    try:
+        q, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            quota = max(1, int(int(q) / int(period)))
+    except (OSError, ValueError):
+        pass
+    return host, aff, quota
+
+
 def usable_cores():
     """Threads of the CPU baseline: what this process may use (affinity mask, cgroup quota); on an unconstrained view of a big host the thread count that
     MEASURED fastest in the recorded sweep (a measurement, not a choice), 16 if no sweep is committed."""
-    n = os.cpu_count() or 1
-    try:
-        n = min(n, len(os.sched_getaffinity(0)))
-    except (AttributeError, OSError):
-        pass
-    try:
-        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
-        if quota != "max":
-            n = min(n, max(1, int(int(quota) / int(period))))
-    except (OSError, ValueError):
-        pass
+    host, aff, quota = cpu_limits()
+    n = min(host, aff, quota if quota is not None else host)
     if n > 64:
         sweep, _ = recorded_thread_sweep()
         n = min(n, int(sweep["fastest_threads"])) if sweep else 16
@@ -153,21 +161,20 @@ def usable_cores():
 
 def cores_note():
     """Where the thread count of the CPU baseline comes from (BASELINE.md §3 asks for the core count to be stated)."""
-    host = os.cpu_count() or 1
-    try:
-        aff = len(os.sched_getaffinity(0))
-    except (AttributeError, OSError):
-        aff = host
+    host, aff, quota = cpu_limits()
     used = usable_cores()
     sweep, src = recorded_thread_sweep()
-    if used == min(host, aff):
+    sweep_txt = ("; recorded thread sweep on this CPU model (" + src + "): " + ", ".join(f"{k} threads {v} images/s" for k, v in sweep["images_per_s_by_threads"].items())) if sweep else ""
+    if quota is not None and used == quota:
+        why = f"the cgroup's CPU quota ({quota} CPUs: more threads only oversubscribe it{sweep_txt})"
+    elif used == min(host, aff):
         why = "all of them"
     elif sweep:
-        why = (f"the fastest of the recorded sweep on this CPU model ({src}: " + ", ".join(f"{k} threads {v} images/s" for k, v in sweep["images_per_s_by_threads"].items()) +
-               "): more threads are SLOWER on this 2-socket host shared with the other GPUs' jobs")
+        why = "the fastest of the recorded sweep" + sweep_txt
     else:
         why = "no thread sweep is committed: one GPU's share of an 8-GPU host"
-    return f"host exposes {host} logical CPUs = {physical_cores()} physical cores, affinity mask {aff}; {used} threads used ({why})"
+    return (f"host exposes {host} logical CPUs = {physical_cores()} physical cores, affinity mask {aff}, cgroup CPU quota {quota if quota is not None else 'none'}; "
+            f"{used} threads used ({why})")
 
 
 def cpu_model_name():

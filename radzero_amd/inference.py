@@ -95,36 +95,77 @@ def _collate_default(items, model, preprocessor):
 
 def _reshape_batches(batches, model, src_rows: list, enabled: bool):
     """Batch shaping: re-cut a stream of pixel batches into forwards of `model.preferred_batch(...)` images where the caller's
-    batch size leaves the persistent GEMM's last round of 256 tiles nearly empty (518^2 x 64 -> forwards of 62: +3 % images per second).  Order is
-    preserved (the logits are concatenated in the order the images came), `src_rows` receives the SOURCE batch sizes (what the distributed
-    interleave needs), at most one source batch is held back, and the tail goes out as one last, smaller forward.  Images are independent on
-    this path: no result bit changes in the 16-bit modes; in the fp32 mode the operand form follows the forward's size as it always has
-    (DESIGN.md §4.4).  Runs in the caller's stream context (the side stream of `calculate_similarities` when it overlaps)."""
-    pending, have, target = [], 0, None
+    batch size leaves the persistent GEMM's last round of 256 tiles nearly empty (518^2 x 64 -> forwards of 62: +3 % images per second).
+    Yields (pixel_values, ranges): `ranges` = [(first row in the stream, count), ...] says where the forward's rows belong in the source order.
+    Copy-free in the steady state: the first `target` images of every source batch go out as a VIEW of that batch; the few images left over are
+    carried, and once `target` of them have gathered they go out as one forward (one copy of `target` images per ~target / leftover source
+    batches instead of one per batch); the tail goes out as one last, smaller forward.  `src_rows` receives the SOURCE batch sizes (what the
+    distributed interleave needs).  Images are independent on this path: no result bit changes in the 16-bit modes; in the fp32 mode the operand
+    form follows the forward's size as it always has.  Runs in the caller's stream context (the side stream of
+    `calculate_similarities` when it overlaps)."""
+    carry, carried, target, pos = [], 0, None, 0          # carry: (tensor, first row) pieces in stream order
+
+    def drain(limit):
+        """pieces of the carry adding up to `limit` rows -> (tensor, ranges)"""
+        nonlocal carry, carried
+        take, ranges, got = [], [], 0
+        while got < limit:
+            t, first = carry[0]
+            k = min(int(t.shape[0]), limit - got)
+            take.append(t[:k])
+            ranges.append((first, k))
+            got += k
+            if k == int(t.shape[0]):
+                carry.pop(0)
+            else:
+                carry[0] = (t[k:], first + k)
+        carried -= limit
+        return (torch.cat(take, dim=0) if len(take) > 1 else take[0]), ranges
+
     for px in batches:
-        src_rows.append(int(px.shape[0]))
-        if not enabled or px.dim() != 4:
-            yield px
-            continue
-        if target is None:
+        n = int(px.shape[0])
+        src_rows.append(n)
+        if enabled and px.dim() == 4 and target is None:
             pick = getattr(model, "preferred_batch", None)
-            target = int(pick(int(px.shape[0]), int(px.shape[2]), int(px.shape[3]))) if pick is not None else int(px.shape[0])
-            if target >= int(px.shape[0]):
-                enabled = False              # the caller's size is already a good one: pass everything through untouched
-                yield px
-                continue
-        if pending and (pending[0].shape[1:] != px.shape[1:] or pending[0].dtype != px.dtype):
-            yield torch.cat(pending, dim=0) if len(pending) > 1 else pending[0]      # the resolution changed: flush, keep the order
-            pending, have = [], 0
-        pending.append(px.to(model.device, non_blocking=True))
-        have += int(px.shape[0])
-        while have >= target:
-            buf = torch.cat(pending, dim=0) if len(pending) > 1 else pending[0]
-            yield buf[:target]
-            rest = buf[target:]
-            pending, have = ([rest], int(rest.shape[0])) if rest.shape[0] else ([], 0)
-    if have:
-        yield torch.cat(pending, dim=0) if len(pending) > 1 else pending[0]
+            target = int(pick(n, int(px.shape[2]), int(px.shape[3]))) if pick is not None else n
+            if target >= n:
+                enabled = False                  # the caller's size is already a good one: everything passes through untouched
+        if not enabled or px.dim() != 4:
+            yield px, [(pos, n)]
+            pos += n
+            continue
+        if carry and (carry[0][0].shape[1:] != px.shape[1:] or carry[0][0].dtype != px.dtype):
+            yield drain(carried)                 # the resolution changed: what was carried goes out first
+        px = px.to(model.device, non_blocking=True)
+        off = 0
+        while n - off >= target:
+            yield px[off:off + target], [(pos + off, target)]
+            off += target
+        if off < n:
+            carry.append((px[off:], pos + off))
+            carried += n - off
+        pos += n
+        while carried >= target:
+            yield drain(target)
+    if carried:
+        yield drain(carried)
+
+
+def _place_rows(pieces, n_prompts, device):
+    """[(logits (k, T), ranges)] -> (rows, T) in source order"""
+    total = sum(c for _, ranges in pieces for _, c in ranges)
+    if not pieces:
+        return torch.zeros((0, n_prompts), dtype=torch.float32, device=device)
+    in_order = all(len(r) == 1 for _, r in pieces) and all(pieces[i][1][0][0] + pieces[i][1][0][1] == pieces[i + 1][1][0][0] for i in range(len(pieces) - 1))
+    if in_order:
+        return torch.cat([lg for lg, _ in pieces], dim=0)
+    out = torch.empty((total, pieces[0][0].shape[1]), dtype=pieces[0][0].dtype, device=pieces[0][0].device)
+    for lg, ranges in pieces:
+        off = 0
+        for first, count in ranges:
+            out[first:first + count] = lg[off:off + count]
+            off += count
+    return out
 
 
 _guard_warned = False
@@ -199,7 +240,7 @@ def calculate_similarities(source, text_batch, model, distributed: bool = False,
     else:
         batches = (px for i, px in enumerate(source) if i % world == rank)
 
-    out, rows = [], []          # rows: SOURCE batch sizes (the distributed interleave deals source batches), not forward sizes
+    out, rows = [], []          # out: (logits, where its rows belong); rows: SOURCE batch sizes (the distributed interleave deals source batches)
     batches = _reshape_batches(batches, model, rows, enabled=bool(batch_shaping) and cuda)
     if cuda and overlap:
         # produce batch k + 1 (dataset reads, H2D, device preprocessing) on a side stream while batch k computes on the current one
@@ -209,27 +250,27 @@ def calculate_similarities(source, text_batch, model, distributed: bool = False,
         def produce():
             with torch.cuda.stream(side):
                 try:
-                    px = next(batches)
+                    px, ranges = next(batches)
                 except StopIteration:
                     return None
                 px = px.to(model.device, non_blocking=True)
                 ev = torch.cuda.Event()
                 ev.record(side)
-            return px, ev
+            return px, ranges, ev
 
         nxt = produce()
         while nxt is not None:
-            px, ev = nxt
+            px, ranges, ev = nxt
             main.wait_event(ev)
             px.record_stream(main)
             logits = model.compute_logits(pixel_values=px, encoded_key_phrases=[enc], text_features=feats)["logits"]
-            out.append(logits.reshape(px.shape[0], -1).clone())
+            out.append((logits.reshape(px.shape[0], -1).clone(), ranges))
             nxt = produce()
     else:
-        for px in batches:
+        for px, ranges in batches:
             logits = model.compute_logits(pixel_values=px.to(model.device), encoded_key_phrases=[enc], text_features=feats)["logits"]
-            out.append(logits.reshape(px.shape[0], -1))
-    logits = torch.cat(out, dim=0) if out else torch.zeros((0, n_prompts), dtype=torch.float32, device=feats.device)
+            out.append((logits.reshape(px.shape[0], -1), ranges))
+    logits = _place_rows(out, n_prompts, feats.device)
     _warn_guard_reruns(model, len(rows))
     if dist_on:
         all_rows = [None] * world

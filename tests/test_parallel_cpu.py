@@ -373,12 +373,13 @@ class _ShapedModel(_FakeModel):
 
 
 def test_reshape_batches_keeps_order_rows_and_results():
-    """`_reshape_batches` re-cuts 64, 64, 64, 10 images into forwards of 62, 62, 62, 16 — same images, same order; the SOURCE batch sizes are what
-    the distributed interleave receives; a size that is already good passes through untouched."""
+    """`_reshape_batches` re-cuts 64, 64, 64, 10 images into forwards of 62, 62, 62, 16: the first 62 images of a source batch go out as a VIEW of it (no
+    copy), the leftovers gather into a later forward, and `ranges` says where every forward's rows belong — `_place_rows` restores the source order.
+    The SOURCE batch sizes are what the distributed interleave receives; a size that is already good passes through untouched."""
     import numpy as np
     import torch
 
-    from radzero_amd.inference import _reshape_batches
+    from radzero_amd.inference import _place_rows, _reshape_batches
     sizes = [64, 64, 64, 10]
     tag = 0
     batches = []
@@ -388,15 +389,25 @@ def test_reshape_batches_keeps_order_rows_and_results():
     m = _ShapedModel(62)
     rows = []
     out = list(_reshape_batches(iter(batches), m, rows, enabled=True))
-    assert [int(o.shape[0]) for o in out] == [62, 62, 62, 16] and rows == sizes
-    assert np.array_equal(torch.cat(out)[:, 0, 0, 0].numpy(), np.arange(202, dtype=np.float32))
+    assert [int(o.shape[0]) for o, _ in out] == [62, 62, 62, 16] and rows == sizes
+    for k in range(3):                                               # steady state: views of the source batches, not copies
+        assert out[k][0].data_ptr() == batches[k].data_ptr() and out[k][1] == [(64 * k, 62)]
+    assert out[3][1] == [(62, 2), (126, 2), (190, 2), (192, 10)]
+    placed = _place_rows([(o[:, 0, 0, :1] * 1.0, r) for o, r in out], 1, torch.device("cpu"))       # "logits" = the image's tag
+    assert np.array_equal(placed[:, 0].numpy(), np.arange(202, dtype=np.float32))
+    # many batches: the carry reaches the target and goes out as a forward of its own (one copy per 31 source batches at 64 -> 62)
+    many = [batches[0]] * 33
+    got = list(_reshape_batches(iter(many), _ShapedModel(62), [], enabled=True))
+    assert [int(o.shape[0]) for o, _ in got] == [62] * 31 + [62] + [62, 62] + [4]
+    assert sum(c for _, r in got for _, c in r) == 33 * 64 and sorted(f for _, r in got for f, _ in r)[0] == 0
     rows2 = []
     same = list(_reshape_batches(iter(batches), _ShapedModel(64), rows2, enabled=True))
-    assert all(a is b for a, b in zip(same, batches)) and rows2 == sizes
+    assert all(a is b for (a, _), b in zip(same, batches)) and rows2 == sizes and [r for _, r in same] == [[(0, 64)], [(64, 64)], [(128, 64)], [(192, 10)]]
     rows3 = []
     off = list(_reshape_batches(iter(batches), m, rows3, enabled=False))
-    assert all(a is b for a, b in zip(off, batches)) and rows3 == sizes
-    # a change of resolution inside the stream flushes what is pending first (order kept)
+    assert all(a is b for (a, _), b in zip(off, batches)) and rows3 == sizes
+    # a change of resolution inside the stream sends what was carried out first
     mixed = [batches[0], torch.zeros((5, 3, 4, 4)), batches[1]]
     got = list(_reshape_batches(iter(mixed), _ShapedModel(62), [], enabled=True))
-    assert [tuple(g.shape) for g in got] == [(62, 3, 2, 2), (2, 3, 2, 2), (5, 3, 4, 4), (62, 3, 2, 2), (2, 3, 2, 2)]
+    assert [tuple(g.shape) for g, _ in got] == [(62, 3, 2, 2), (2, 3, 2, 2), (5, 3, 4, 4), (62, 3, 2, 2), (2, 3, 2, 2)]
+    assert [r for _, r in got] == [[(0, 62)], [(62, 2)], [(64, 5)], [(69, 62)], [(131, 2)]]
