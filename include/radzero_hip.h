@@ -248,11 +248,13 @@ int rz_gemm_f32_split(int form, const float* a_dev, const float* w_dev, const fl
  *                      always runs).  Other values run the default (the retired shapes live in the RZ_EXPERIMENTS tools library)
  *   "attn_f32_split"   1 (default) = fp32 mode runs attention as hi/lo-split f16 MFMAs; 0 = exact-fp32 MFMAs (16x16x4_f32)
  *   "gemm_f32_split"   1 (default) = fp32 mode runs the vision encoder's GEMMs as hi/lo-split f16 MFMAs; 0 = exact-fp32 MFMAs
- *   "gemm_f32_mx"      fp32 mode, hi/lo-split GEMMs: 1 (default) = for large batches (>= 64 row tiles of 256) the two correction terms
+ *   "gemm_f32_mx"      fp32 mode, hi/lo-split GEMMs: 1 (default) = wherever the shape allows (a launch's token rows a multiple of 256: every batch at 1024^2 and 518^2,
+ *                      even batches at 224^2) the two correction terms
  *                      a_lo b_hi + a_hi b_lo run as ONE block-scaled fp8 MFMA (v_mfma_scale_f32_16x16x128_f8f6f4, e4m3 planes with power-of-two
  *                      scales: fixed for activations, chosen per weight matrix from its largest |w|) beside the f16 a_hi b_hi MFMAs: 4 MFMA-units per 64 K instead of 6, 4 bytes per operand element
  *                      instead of 6, and the attention's second planes (q, k, V^T, P) likewise (32 f16 + 16 block-scaled MFMAs per wave and
- *                      64-key tile instead of 96); 2 = wherever the shape allows (token rows a multiple of 256); 0 = three f16 planes everywhere
+ *                      64-key tile instead of 96); 2 = the same as 1 (rounds 4-5: "wherever the shape allows" against their default, which started the form at 64 row
+ *                      tiles of 256); 3 = that former default (A/B); 0 = three f16 planes everywhere
  *   "attn_f32_mx"      fp32 mode, where "gemm_f32_mx" applies: 1 (default) = the attention's P V correction terms as block-scaled e4m3 MFMAs, the
  *                      scores Q K^T stay on three f16 planes (a score's error is exponentiated: 22 bits there); 2 = the scores' correction
  *                      terms too (2^-16 sum |q_d k_d| of error in a score: fine on small logits — the synthetic checkpoint's — only);

@@ -39,7 +39,7 @@ struct Options {
     int sim_op;           // VL-CABS similarity: 0 = "cos" (released config), 1 = "dot" (losses.py:214-215)
     int pad_rows;         // token rows per image: 0 = multiple of 128, of 256 when that costs < 2 % more rows | 128 | 256 = always that multiple
     int f32_split_guard;  // fp32 mode: 1 = a forward whose f16 planes overflowed is repeated on the exact-fp32 kernels (default)
-    int gemm_f32_mx;      // fp32 mode: 1 (default) = the split GEMMs' two correction terms run as one block-scaled fp8 MFMA (MX form, rz_common.h) for large batches; 2 = wherever the shape allows; 0 = three f16 planes
+    int gemm_f32_mx;      // fp32 mode: 1 (default) = the split GEMMs' two correction terms run as one block-scaled fp8 MFMA (MX form, rz_common.h) wherever the launch's rows are a multiple of 256; 2 = the same; 3 = only from 64 row tiles of 256 on (the default of rounds 4-5); 0 = three f16 planes
     int attn_f32_mx;      // fp32 mode, with the MX GEMM form: 1 (default) = the attention's P V correction terms as block-scaled fp8 MFMAs, scores at 22 bits; 2 = scores too; 0 = f16 planes
     int gemm_raster;      // gemm12.hip: tile order inside an XCD (GemmArgs::raster): 0 = 4 x tiles_n groups | S > 0 = slab walk, <= S n tiles per slab
     int attn_f32_pv;      // fp32 mode: 1 = the attention's P V product on the hi planes alone (f16 P and V, row sums of the rounded P on the matrix pipe); 0 = with its correction terms ("f32_precision high")
@@ -939,9 +939,11 @@ static int vision_forward_once(rz_handle_t m, const float* px, int B, int C, int
         // a GEMM: [hi | lo | hi] along K; 4 where they feed the attention: hi plane, lo plane)
         const bool sp = m->dt == RZ_F32 && m->o_gemm_f32_split() && m->o_attn_f32_split() && !m->split_w.empty();
         // MX form of the split GEMMs (rz_common.h): every GEMM of the chunk or none (the producers write ONE operand form).  The 256 x 256
-        // kernel that runs it needs M % 256 == 0; option 1 (default) takes it where that kernel's grid fills the chip, 2 wherever it applies
+        // kernel that runs it needs M % 256 == 0.  Round 6: options 1 (default) and 2 take it wherever it applies — rounds 4-5 started it at 64 row tiles
+        // ("where that kernel's grid fills the chip"; kept as option 3), but the step says otherwise: 1024^2 x 1 / 2 / 3 images +11 / +19 / +22 %,
+        // 518^2 x 4 / 8 +13 / +27 %, 224^2 x 32 +30 % (profiles/r06/fp32_operand_form_small_batches_step_ab.txt), and one arithmetic for (nearly) every batch
         const int mxo = m->o_gemm_f32_mx();
-        const bool mxg = sp && mxo != 0 && m->mx_weights_ok && M % 256 == 0 && (mxo == 2 || M >= 256 * 64);
+        const bool mxg = sp && mxo != 0 && m->mx_weights_ok && M % 256 == 0 && (mxo != 3 || M >= 256 * 64);
         if (!m->force_exact) m->last_f32_form = mxg ? 2 : sp ? 1 : 0;
         const int mxa = mxg ? m->o_attn_f32_mx() : 0;                         // the attention's MX form rides on the GEMMs' (its ctx leaves in the MX form)
         // which of the attention's correction terms are dropped (flash_attn_split_kernel ABL): none by default; P V on the hi planes alone only with
