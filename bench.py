@@ -962,7 +962,7 @@ def main():
                 short_run(sd, cfg, device, "bf16", 32, 1024, 14, "none", 6, 10, pipeline="host"),
                 short_run(sd, cfg, device, "bf16", 32, 1024, 14, "none", 6, 10, pipeline="raw"),
                 short_run(sd, cfg, device, "bf16", 32, 1024, 14, "none", 6, 10, pipeline="rawhost"),
-                short_run(sd, cfg, device, "bf16", 64, 518, 14, "none", 6, 10),      # the released model's own resolution and eval batch
+                short_run(sd, cfg, device, "bf16", 64, 518, 14, "none", 6, 10, steps=10, warmup=3),      # the released model's own resolution and eval batch
                 short_run(sd, cfg, device, "f32", 32, 1024, 14, "none", 6, 10, f32_precision="fast"),      # the 1e-3 mode's opt-in level: P V on the f16 hi planes alone
                 # round 6: the 1e-3 mode with its input pipeline inside the step — possible since the fp32 forward no longer synchronises the stream (predicated guard)
                 short_run(sd, cfg, device, "f32", 32, 1024, 14, "none", 6, 10, pipeline="rawhost"),
