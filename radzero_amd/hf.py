@@ -80,6 +80,15 @@ class RadZeroHFModel(RadZeroModel):
             raise ValueError("from_pretrained: `device` and `device_map` name different devices")
         dev = _resolve_device(device if device is not None else device_map)
         path = str(pretrained_model_name_or_path)
+        if not os.path.exists(path):
+            raise FileNotFoundError(f"RadZeroHFModel.from_pretrained: {path!r} is not a local checkpoint directory or file.  Hub ids (e.g. \"Deepnoid/RadZero\") are not "
+                                    "resolved here: download the repository first (huggingface_hub.snapshot_download) and pass its directory.")
+        known = {"trust_remote_code", "low_cpu_mem_usage", "attn_implementation", "revision", "cache_dir", "local_files_only", "token", "use_safetensors",
+                 "force_download", "proxies", "subfolder", "_from_auto", "_commit_hash", "adapter_kwargs", "code_revision", "name_or_path", "_name_or_path", "use_auth_token", "weights_only"}
+        extra = sorted(k for k in kwargs if k not in known)
+        if extra:
+            import warnings
+            warnings.warn(f"RadZeroHFModel.from_pretrained: ignoring unexpected keyword argument(s) {extra}", RuntimeWarning, stacklevel=2)
         sd = load_checkpoint(path)
         if isinstance(config, PretrainedConfig):
             rz_cfg = config_from_hf(config.to_dict(), state_dict=sd)
@@ -140,14 +149,20 @@ def register() -> None:
     AutoModel.register(RadZeroHFConfig, RadZeroHFModel, exist_ok=True)
 
 
-def export_auto_map(checkpoint_dir: str, out_dir: Optional[str] = None, link_weights: bool = True) -> str:
+def export_auto_map(checkpoint_dir: str, out_dir: Optional[str] = None, link_weights: bool = True, in_place: bool = False) -> str:
     """Make a CxrAlignModel checkpoint directory loadable by the README's `AutoModel.from_pretrained(dir, trust_remote_code=True, ...)`
-    as the HIP model.  In place by default; with `out_dir` the original stays untouched (weights are symlinked, or copied with
-    link_weights=False).  Returns the directory to pass to from_pretrained."""
+    as the HIP model.  Writes into `out_dir` (weights symlinked, or copied with link_weights=False): the original stays untouched and the
+    reference's own loader keeps reading it.  `in_place=True` (explicit: it rewrites the checkpoint's config.json — model_type, architectures,
+    auto_map — after which `CxrAlignConfig.from_pretrained` sees a foreign model_type) modifies `checkpoint_dir` itself.  Returns the directory to
+    pass to from_pretrained."""
     src = os.path.abspath(checkpoint_dir)
     cfg_path = os.path.join(src, "config.json")
     if not os.path.isfile(cfg_path):
         raise FileNotFoundError(f"{cfg_path}: not a save_pretrained directory")
+    if out_dir is None and not in_place:
+        raise ValueError("export_auto_map: pass out_dir= (the original checkpoint stays untouched) or in_place=True to rewrite the checkpoint's own config.json")
+    if out_dir is not None and in_place and os.path.abspath(out_dir) != src:
+        raise ValueError("export_auto_map: out_dir and in_place=True name two different targets")
     dst = os.path.abspath(out_dir) if out_dir else src
     if dst != src:
         os.makedirs(dst, exist_ok=True)

@@ -63,7 +63,12 @@ def test_hf_config_gives_the_kernels_config(tmp_path):
     from radzero_amd.hf import RadZeroHFConfig, export_auto_map
     from transformers import AutoConfig
     cfg, src = _layout(tmp_path)
-    export_auto_map(str(src))                                  # in place
+    import pytest
+    with pytest.raises(ValueError, match="out_dir"):           # mutating the source checkpoint must be asked for explicitly
+        export_auto_map(str(src))
+    before = open(src / "config.json").read()
+    assert export_auto_map(str(src), str(tmp_path / "exported")) != str(src) and open(src / "config.json").read() == before      # out_dir: the original is untouched
+    export_auto_map(str(src), in_place=True)
     c = AutoConfig.from_pretrained(str(src))                   # model_type is registered by importing radzero_amd.hf: no remote code needed
     assert isinstance(c, RadZeroHFConfig)
     assert c.to_radzero(load_checkpoint(str(src))) == cfg
@@ -93,3 +98,15 @@ def test_save_pretrained_round_trip(tmp_path):
         assert config_from_hf(d, state_dict=back) == cfg
         c = AutoConfig.from_pretrained(d)
         assert isinstance(c, RadZeroHFConfig) and c.to_radzero(back) == cfg and c.dtype in ("float32", torch.float32)
+
+
+def test_from_pretrained_names_what_it_cannot_load_and_warns_on_unknown_kwargs(tmp_path):
+    """a hub id gets a clear error (no network resolution here), unknown keyword arguments are not swallowed silently."""
+    import pytest
+    from radzero_amd.hf import RadZeroHFModel
+    with pytest.raises(FileNotFoundError, match="snapshot_download"):
+        RadZeroHFModel.from_pretrained("Deepnoid/RadZero", torch_dtype="float32", device_map="cuda")
+    cfg, src = _layout(tmp_path)
+    with pytest.warns(RuntimeWarning, match="frobnicate"):
+        with pytest.raises(Exception):                          # no HIP device here: construction raises AFTER the warning
+            RadZeroHFModel.from_pretrained(str(src), torch_dtype="float32", device_map="cuda", frobnicate=1)
