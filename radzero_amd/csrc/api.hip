@@ -470,7 +470,11 @@ int gemm_f32_split(rz_model* m, int epi, GemmArgs g, int a_mode, bool out_split,
                              ((epi == EPI_VT && (mx & 2)) || (epi == EPI_HEADS && (mx & 4))) ? 3 : 1;       // 3: hi f16 + e4m3 pair planes (MX attention)
         if ((out_kind != 0) != out_split) return fail(RZ_ERR_STATE, "MX GEMM: output form mismatch");
         g.variant = m->o_gemm_variant();
-        if (g.variant != 7 && gemm_v8_mx_ok(epi, out_kind, g)) RZ_HIP(launch_gemm_v8_mx(epi, out_kind, g, s));       // persistent loop: the epilogue's stores under the next tile's K loop
+        // which kernel: 0 auto — the 128 x 128 kernel where the 16-bit kernels' cost model prefers small tiles (round 6: one 1024^2 image is 63 big tiles for
+        // an N = 768 GEMM on 256 CUs), else the persistent loop; 1 / 7 / 8 force the 128 x 128 / one-tile-per-workgroup / persistent kernel (same bits)
+        const bool small_ok = gemm_small_mx_ok(epi, out_kind, g);
+        if (small_ok && (g.variant == 1 || (g.variant == 0 && gemm_small_mx_pays(epi, g)))) RZ_HIP(launch_gemm_small_mx(epi, g, out_kind, s));
+        else if (g.variant != 7 && gemm_v8_mx_ok(epi, out_kind, g)) RZ_HIP(launch_gemm_v8_mx(epi, out_kind, g, s));       // persistent loop: the epilogue's stores under the next tile's K loop
         else RZ_HIP(launch_gemm_v7_mx(epi, g, out_kind, s));
         *done = true;
         return 0;

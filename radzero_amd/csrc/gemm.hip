@@ -23,7 +23,11 @@ namespace rz {
 
 // OT = type of the outputs the epilogue writes (default: the operand type).  <f16_t, EPI, float> = 16-bit operands, fp32 outputs: the
 // fp32 mode's hi/lo-split GEMMs (launch_gemm_split_f32out below).
-template <typename T, int EPI, typename OT = T>
+// MXK (round 6; T = f16_t): the fp32 mode's MX form on the 128 x 128 tile (gemm7.hip gemm_kernel_v7 "MXK" is the 256 x 256 form): operand rows are
+// [K f16 | K / 64 pair blocks of 128 bytes], g.K = 2 K counts 128-byte panels x 64; the first half of the panels runs the f16 MFMAs (a_hi b_hi), the
+// second half ONE block-scaled e4m3 MFMA per accumulator tile (both correction terms), its 32-byte operands = the two 16-byte fragments of the panel.
+// Same products, same order as the 256 x 256 kernels: bit-identical to them (tests/test_gpu_model.py forced-variant checks).
+template <typename T, int EPI, typename OT = T, bool MXK = false>
 __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs g) {
     __shared__ __attribute__((aligned(1024))) char lds[4 * PANEL_BYTES];  // A0 A1 B0 B1
     if constexpr (sizeof(T) == 4) {      // exact-fp32 instantiations: predicated launch (fp32 mode's overflow guard, rz_kernels.h GemmArgs::run_if)
@@ -47,6 +51,9 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs g) {
     const char* Wb = reinterpret_cast<const char*>(g.W) + (int64_t)n0 * g.ldw * sizeof(T);
     const int64_t lda_b = g.lda * (int64_t)sizeof(T), ldw_b = g.ldw * (int64_t)sizeof(T);
     const int nk = (g.K * (int)sizeof(T)) / 128;
+    // MXK: E8M0 scale byte of this lane's 32-element block (block index = lane >> 4): A rows = [lo8 | hi8], W rows = [hi8 | lo8] (per weight matrix, api.hip)
+    [[maybe_unused]] const int sa_mx = lg < 2 ? MX_E8_A_LO : MX_E8_A_HI, sw_mx = lg < 2 ? g.mx_w_e8_hi : g.mx_w_e8_lo;
+    [[maybe_unused]] const int nkh = MXK ? nk / 2 : nk;
 
     auto stage = [&](int kt, int buf) {
         char* sa = lds + buf * PANEL_BYTES;
@@ -83,6 +90,28 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs g) {
         for (int i = 0; i < 4; ++i) {
             fa[0][i] = lds_frag<T>(sa, wm * 64 + i * 16 + l15, lg);
             fb[0][i] = lds_frag<T>(sb, wn * 64 + i * 16 + l15, lg);
+        }
+        if constexpr (MXK) {
+            if (kt >= nkh) {          // a pair-block panel: both 16-byte fragments of every row, then 16 block-scaled MFMAs
+                static_assert(!MXK || std::is_same<T, f16_t>::value, "the MX form's hi plane is f16");
+                if constexpr (std::is_same<T, f16_t>::value) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        fa[1][i] = lds_frag<T>(sa, wm * 64 + i * 16 + l15, 4 + lg);
+                        fb[1][i] = lds_frag<T>(sb, wn * 64 + i * 16 + l15, 4 + lg);
+                    }
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            if (SWAP) acc[i][j] = mma_mx(fb[0][j], fb[1][j], fa[0][i], fa[1][i], acc[i][j], sw_mx, sa_mx);
+                            else acc[i][j] = mma_mx(fa[0][i], fa[1][i], fb[0][j], fb[1][j], acc[i][j], sa_mx, sw_mx);
+                        }
+                }
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+                continue;
+            }
         }
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
@@ -377,6 +406,34 @@ hipError_t launch_gemm_split_f32out(int epi, const GemmArgs& g, hipStream_t s, b
         default: return hipErrorInvalidValue;
     }
 #undef RZ_CASE
+    return hipGetLastError();
+}
+
+// fp32 mode, MX form on the 128 x 128 kernel (small shapes: the persistent 256 x 256 kernel leaves most CUs idle — 63 tiles for an N = 768 GEMM of one
+// 1024^2 image): out_kind as launch_gemm_v7_mx (0 fp32 RMW / table, 1 hi/lo f16 planes, 2 the next GEMM's MX A operand, 3 hi f16 + e4m3 pair plane: V^T only here)
+bool gemm_small_mx_ok(int epi, int out_kind, const GemmArgs& g) {
+    if (g.M <= 0 || g.M % BM || g.N % BN || g.K % 128 || g.K < 256) return false;
+    if (out_kind == 0) return epi == EPI_RESID_SCALE || epi == EPI_PATCH;
+    if (out_kind == 1) return epi == EPI_HEADS || epi == EPI_VT;
+    if (out_kind == 2) return epi == EPI_GELU;
+    return out_kind == 3 && epi == EPI_VT;
+}
+// would the 128 x 128 kernel be the faster one for this MX GEMM?  The 16-bit kernels' fitted model (big_tiles_pay) on the MX operand's K' = 2 K panels
+bool gemm_small_mx_pays(int epi, const GemmArgs& g) { return !big_tiles_pay(g, epi); }
+hipError_t launch_gemm_small_mx(int epi, const GemmArgs& g, int out_kind, hipStream_t s) {
+    if (!gemm_small_mx_ok(epi, out_kind, g)) return hipErrorInvalidValue;
+    dim3 grid((g.M / BM) * (g.N / BN)), block(256);
+#define RZ_CASEM(E, OT) case E: hipLaunchKernelGGL((gemm_kernel<f16_t, E, OT, true>), grid, block, 0, s, g); break;
+    if (out_kind == 0) {
+        switch (epi) { RZ_CASEM(EPI_RESID_SCALE, f16_t) RZ_CASEM(EPI_PATCH, f16_t) default: return hipErrorInvalidValue; }
+    } else if (out_kind == 1) {
+        switch (epi) { RZ_CASEM(EPI_HEADS, split_f16) RZ_CASEM(EPI_VT, split_f16) default: return hipErrorInvalidValue; }
+    } else if (out_kind == 3) {
+        switch (epi) { RZ_CASEM(EPI_VT, split_mxa) default: return hipErrorInvalidValue; }
+    } else {
+        switch (epi) { RZ_CASEM(EPI_GELU, split_mx) default: return hipErrorInvalidValue; }
+    }
+#undef RZ_CASEM
     return hipGetLastError();
 }
 

@@ -297,6 +297,18 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, const f32x4 (&a
                     f16_t* o = reinterpret_cast<f16_t*>(g.out) + idx;
                     *reinterpret_cast<f16x4*>(o) = hi;
                     *reinterpret_cast<f16x4*>(o + g.plane_off) = lo;
+                } else if constexpr (std::is_same<T, split_mxa>::value) {
+                    // V^T for the MX attention (gemm_epilogue_tile_split FORM 2): hi f16 plane + pair plane `plane_off` elements behind it, 128 bytes
+                    // [hi8 x 64 | lo8 x 64] per (feature, 64-token block), the block's tokens in the order the attention's score accumulators hand keys to a lane
+                    f16x4 hi;
+                    uint32_t lo8, hi8;
+                    split4_mx((f32x4){a[0] + bv, a[1] + bv, a[2] + bv, a[3] + bv}, hi, lo8, hi8, MX_A_HI_SCALE, MX_A_LO_SCALE, g.ovf_flag);
+                    f16_t* o = reinterpret_cast<f16_t*>(g.out) + idx;
+                    *reinterpret_cast<f16x4*>(o) = hi;
+                    const int kq = tok & 63, pos = 16 * ((kq & 31) >> 3) + 8 * (kq >> 5) + (kq & 7);
+                    char* pr = reinterpret_cast<char*>(reinterpret_cast<f16_t*>(g.out) + g.plane_off + (idx - kq)) + pos;
+                    *reinterpret_cast<uint32_t*>(pr) = hi8;
+                    *reinterpret_cast<uint32_t*>(pr + 64) = lo8;
                 } else {
                     T* o = reinterpret_cast<T*>(g.out) + idx;
                     *reinterpret_cast<typename Traits<T>::vec4*>(o) = pack4<T>(a[0] + bv, a[1] + bv, a[2] + bv, a[3] + bv);

@@ -76,6 +76,9 @@ hipError_t launch_gemm_v7(int variant, int dtype, int epi, const GemmArgs& g, hi
 hipError_t launch_gemm_v7_f16_out(int epi, const GemmArgs& g, bool split_out, hipStream_t s);   // f16 operands, fp32 / hi-lo-split outputs
 // fp32 mode, MX form (rz_common.h "MX form"): f16 hi plane + block-scaled fp8 correction planes; out_kind 0 fp32 RMW / table, 1 hi/lo planes, 2 MX A operand
 bool gemm_v7_mx_ok(const GemmArgs& g);
+bool gemm_small_mx_ok(int epi, int out_kind, const GemmArgs& g);      // the same form on the 128 x 128 kernel (gemm.hip; round 6): small shapes
+bool gemm_small_mx_pays(int epi, const GemmArgs& g);
+hipError_t launch_gemm_small_mx(int epi, const GemmArgs& g, int out_kind, hipStream_t s);
 hipError_t launch_gemm_v7_mx(int epi, const GemmArgs& g, int out_kind, hipStream_t s);
 
 // Flash attention over per-head tensors: q,k [B][H][Npad][64], vT [B][H][64][Npad] -> ctx [B*Npad][H*64].

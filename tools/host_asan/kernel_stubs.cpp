@@ -144,6 +144,13 @@ hipError_t launch_gemm_v7_mx(int epi, const GemmArgs& g, int out_kind, hipStream
     return hipSuccess;
 }
 hipError_t launch_gemm_v8_mx(int epi, int out_kind, const GemmArgs& g, hipStream_t s) { return launch_gemm_v7_mx(epi, g, out_kind, s); }      // same operands, same outputs
+// round 6: the same form on the 128 x 128 kernel (gemm.hip launch_gemm_small_mx): same operands, same outputs; taken for small shapes
+bool gemm_small_mx_ok(int epi, int out_kind, const GemmArgs& g) {
+    if (g.M <= 0 || g.M % 128 || g.N % 128 || g.K % 128 || g.K < 256) return false;
+    return (out_kind == 0 && (epi == EPI_RESID_SCALE || epi == EPI_PATCH)) || (out_kind == 1 && (epi == EPI_HEADS || epi == EPI_VT)) || (out_kind == 2 && epi == EPI_GELU) || (out_kind == 3 && epi == EPI_VT);
+}
+bool gemm_small_mx_pays(int, const GemmArgs& g) { return (int64_t)(g.M / 256) * (g.N / 256) < 128; }
+hipError_t launch_gemm_small_mx(int epi, const GemmArgs& g, int out_kind, hipStream_t s) { return gemm_small_mx_ok(epi, out_kind, g) && gemm_v7_mx_ok(g) ? launch_gemm_v7_mx(epi, g, out_kind, s) : hipErrorInvalidValue; }
 static bool big_tiles_pay(const GemmArgs& g) {          // gemm.hip
     if (g.M % 256 || g.M < 1024 || g.N % 256) return false;
     const int64_t t = (int64_t)(g.M / 256) * (g.N / 256);
