@@ -418,12 +418,12 @@ bool gemm_small_mx_ok(int epi, int out_kind, const GemmArgs& g) {
     if (out_kind == 2) return epi == EPI_GELU;
     return out_kind == 3 && epi == EPI_VT;
 }
-// would the 128 x 128 kernel be the faster one for this MX GEMM?  Measured in the step (profiles/r06/f32_small_mx_kernel_step_ab.txt): yes below half a round
-// of the persistent kernel's 256 workgroups (one 1024^2 image: q|k 126, v / out-proj / fc2 63 big tiles; one or two 518^2 images; 224^2 up to 8 images:
+// would the 128 x 128 kernel be the faster one for this MX GEMM?  Measured in the step (profiles/r06/f32_small_mx_kernel_step_ab.txt): yes below ~0.4 rounds
+// of the persistent kernel's 256 workgroups (one 1024^2 image: v / out-proj / fc2 63 big tiles; one or two 518^2 images; 224^2 up to 8 images:
 // +3 ... +14 % in the step), no from there on — the 16-bit kernels' fitted model (big_tiles_pay) would also send 264 tiles (518^2 x 16: -7 %) to it
 bool gemm_small_mx_pays(int epi, const GemmArgs& g) {
     (void)epi;
-    return (int64_t)((g.M + BM2 - 1) / BM2) * ((g.N + BN3 - 1) / BN3) < 128;
+    return (int64_t)((g.M + BM2 - 1) / BM2) * ((g.N + BN3 - 1) / BN3) < 100;      // 126 tiles (1024^2: q|k of one image, N = 768 of two): -0.8 % with the small kernel
 }
 hipError_t launch_gemm_small_mx(int epi, const GemmArgs& g, int out_kind, hipStream_t s) {
     if (!gemm_small_mx_ok(epi, out_kind, g)) return hipErrorInvalidValue;
