@@ -220,8 +220,11 @@ struct rz_model {
     DevBuf h, xn, qk, vt, ctx, mid, vws, qhat, lnpart, lnstat, lnmu;      // xn doubles as the residual's T copy on the fused-LayerNorm path
     DevBuf th, txn, tqkv, tctx, tmid, tsum;
     DevBuf asplit;                       // fp32 mode: [hi | lo | hi] f16 planes of the A operand of the GEMM in flight (3 x max K per token row)
+    DevBuf tasplit;                      // the same for the text encoder's GEMMs (round 6: its fp32 GEMMs run on the three-plane f16 form too)
+    bool text_split_ok = false;          // the text encoder's matrices have [hi | hi | lo] copies
     DevBuf ovf;                          // fp32 mode, 8 words: [0] the hi/lo-split producers OR into it when a value leaves a plane's range, [1..3] weight checks
-                                         // (rz_weights_ready), [4] forwards repeated on the exact-fp32 kernels since rz_create (counted on the device)
+                                         // (rz_weights_ready), [4] forwards repeated on the exact-fp32 kernels since rz_create (counted on the device), [5] / [6] the same flag and
+                                         // counter for the TEXT encoder (its own words: a prompt encode on a side stream must not trip the vision forward's guard)
     unsigned* ovf_host = nullptr;        // pinned mirror of words [0..3] (weight checks only: no forward reads it)
     struct SplitW { const char* p; size_t bytes; const char* p3; const char* p4; int e8_hi; };      // e8_hi: E8M0 scale byte of the MX copy's hi8 plane (lo8: 11 below)
     std::vector<SplitW> split_w;         // fp32 weight matrix -> its split copy
@@ -504,6 +507,25 @@ int gemm_f32_split(rz_model* m, int epi, GemmArgs g, int a_mode, bool out_split,
     return 0;
 }
 
+// fp32 mode, text encoder (round 6): the MPNet GEMMs (EPI_STORE q|k|v, EPI_RESID_ADD o / fc2, EPI_GELU fc1; A = one of the text workspaces, row 0) on the
+// three-plane f16 form — A is split here into `tasplit`, the weight's [hi | hi | lo] copy was built by rz_weights_ready; fp32 outputs (exact-erf GELU).
+// Plane overflows raise the TEXT guard word (ovf[5]): rz_text_forward repeats the encode on the exact kernels behind a predicate, as the vision forward does.
+int gemm_text_split(rz_model* m, int epi, GemmArgs g, hipStream_t s, bool* done) {
+    *done = false;
+    if (!m->text_split_ok || !m->tasplit.p || g.M % 128 || g.lda != g.K || g.ldw != g.K) return 0;
+    if (!(g.A == m->txn.p || g.A == m->tctx.p || g.A == m->tmid.p)) return 0;
+    const char* w3 = nullptr;
+    for (const auto& e : m->split_w)
+        if ((const char*)g.W == e.p && !e.p4) { w3 = e.p3; break; }
+    if (!w3 || (size_t)g.M * 3 * g.K * 2 > m->tasplit.bytes) return 0;
+    g.ovf_flag = (unsigned*)m->ovf.p + 5;
+    RZ_HIP(launch_split3((const float*)g.A, g.lda, m->tasplit.p, g.M, g.K, 0, g.ovf_flag, s));
+    g.A = m->tasplit.p; g.W = w3; g.lda = g.ldw = 3 * (int64_t)g.K; g.K = 3 * g.K;
+    RZ_HIP(launch_gemm_split_f32out(epi, g, s, false));
+    *done = true;
+    return 0;
+}
+
 // a_mode / out_split / plane_off: fp32 mode's hi/lo-split path only (see gemm_f32_split); with A_SPLIT or out_split the call MUST take it
 int gemm(rz_model* m, int epi, const void* A, int64_t lda, const void* W, int64_t ldw, int M, int N, int K, const float* bias,
          void* out, int64_t ldo, const float* scale, float* resid, int64_t ldr, int rpi, int heads, hipStream_t s, int a_mode = A_F32,
@@ -515,7 +537,8 @@ int gemm(rz_model* m, int epi, const void* A, int64_t lda, const void* W, int64_
     ProfScope ps(m, RZ_PROF_GEMM, s);
     if (m->dt == RZ_F32 && m->o_gemm_f32_split()) {
         bool done = false;
-        int rc = gemm_f32_split(m, epi, g, a_mode, out_split, s, &done, mx);
+        int rc = (epi == EPI_STORE || epi == EPI_RESID_ADD || (epi == EPI_GELU && g.A == m->txn.p && m->txn.p)) ? gemm_text_split(m, epi, g, s, &done)
+                                                                                                                  : gemm_f32_split(m, epi, g, a_mode, out_split, s, &done, mx);
         if (rc || done) return rc;
     }
     if (a_mode == A_SPLIT || out_split) return fail(RZ_ERR_STATE, "split GEMM requested but not applicable");
@@ -805,8 +828,24 @@ int rz_weights_ready(rz_handle_t m) {
         for (auto& b : m->blocks) {
             if ((rc = split(b.wqkv, 3 * D, D)) || (rc = split(b.wo, D, D)) || (rc = split(b.w1, F, D)) || (rc = split(b.w2, D, F))) return rc;
         }
+        // round 6: the text encoder's matrices in the three-plane form only (its GEMMs have 128-row operands: no MX form) — its exact-fp32 GEMMs were 4.8 ms of
+        // a request's latency chain (72 launches of 56-224 us), longer than the whole vision forward of a 518^2 image
+        auto split3_only = [&](Tensor& t, size_t N, size_t K) -> int {
+            if (!t.p3) {
+                RZ_HIP(hipMalloc(&t.p3, N * 3 * K * 2));
+                m->allocs.push_back(t.p3);
+            }
+            RZ_HIP(launch_split3((const float*)t.p, (int64_t)K, t.p3, (int64_t)N, (int)K, 1, (unsigned*)m->ovf.p + 1, nullptr));
+            m->split_w.push_back({(const char*)t.p, N * K * 4, (const char*)t.p3, nullptr, 123});
+            return 0;
+        };
+        const size_t TFs = m->cfg.text_intermediate_size;
+        for (auto& l : m->tlayers) {
+            if ((rc = split3_only(l.wqkv, 3 * D, D)) || (rc = split3_only(l.wo, D, D)) || (rc = split3_only(l.w1, TFs, D)) || (rc = split3_only(l.w2, D, TFs))) return rc;
+        }
         RZ_HIP(hipDeviceSynchronize());
         RZ_HIP(hipMemcpy(m->ovf_host, m->ovf.p, 16, hipMemcpyDeviceToHost));
+        m->text_split_ok = !m->ovf_host[1] && !m->tlayers.empty();
         if (m->ovf_host[1]) m->split_w.clear();      // a weight beyond the f16 range: this checkpoint runs on the exact-fp32 GEMM kernels
         m->mx_weights_ok = !m->ovf_host[2];          // a weight beyond the hi8 plane's range: the three-plane f16 form only
         m->split_dirty = false;
@@ -873,6 +912,7 @@ int rz_reserve(rz_handle_t m, int max_batch, int max_tokens, int max_prompts, in
             RZ_HIP(m->txn.ensure((size_t)trows * D * es, true));
             RZ_HIP(m->tqkv.ensure((size_t)trows * 3 * D * es, true));
             RZ_HIP(m->tctx.ensure((size_t)trows * D * es, true));
+            if (m->dt == RZ_F32) RZ_HIP(m->tasplit.ensure((size_t)trows * 3 * std::max((size_t)D, TF) * 2, false));
             RZ_HIP(m->tmid.ensure((size_t)trows * TF * es, true));
             m->cap_trows = trows;
         }
@@ -1146,6 +1186,40 @@ static int vision_forward_once(rz_handle_t m, const float* px, int B, int C, int
     return 0;
 }
 
+static int text_forward_once(rz_handle_t m, const int64_t* ids, const int64_t* mask, int T, int L, const float* rel_bias, hipStream_t s) {
+    int rc = 0;
+    const int D = m->D, H = m->H, TF = m->cfg.text_intermediate_size;
+    const int rows = T * L, Mp = round_up(rows, 128);
+    const float eps = m->cfg.text_layer_norm_eps;
+    float* th = (float*)m->th.p;
+    float* tsum = (float*)m->tsum.p;
+    {
+        ProfScope ps(m, RZ_PROF_ROWOPS, s);
+        RZ_HIP(launch_text_embed(m->dt, ids, (const float*)m->word_emb.p, (const float*)m->pos_emb.p, (const float*)m->temb_ln_g.p,
+                                 (const float*)m->temb_ln_b.p, eps, th, m->txn.p, T, L, D, m->cfg.vocab_size,
+                                 m->cfg.max_position_embeddings, m->cfg.pad_token_id, s, m->run_if));
+    }
+    for (const TextLayer& l : m->tlayers) {
+        if ((rc = gemm(m, EPI_STORE, m->txn.p, D, l.wqkv.p, D, Mp, 3 * D, D, (const float*)l.bqkv.p, m->tqkv.p, 3 * D, nullptr, nullptr, 0, Mp, 0, s))) return rc;
+        {
+            ProfScope ps(m, RZ_PROF_ATTN, s);
+            RZ_HIP(launch_text_attn(m->dt, m->tqkv.p, rel_bias, mask, m->tctx.p, T, L, H, s, m->run_if));
+        }
+        if ((rc = gemm(m, EPI_RESID_ADD, m->tctx.p, D, l.wo.p, D, Mp, D, D, (const float*)l.bo.p, tsum, D, nullptr, th, D, Mp, 0, s))) return rc;
+        {
+            ProfScope ps(m, RZ_PROF_ROWOPS, s);
+            RZ_HIP(launch_layernorm(m->dt, tsum, (const float*)l.lna_g.p, (const float*)l.lna_b.p, eps, m->txn.p, th, rows, D, s, m->run_if));
+        }
+        if ((rc = gemm(m, EPI_GELU, m->txn.p, D, l.w1.p, D, Mp, TF, D, (const float*)l.b1.p, m->tmid.p, TF, nullptr, nullptr, 0, Mp, 0, s))) return rc;
+        if ((rc = gemm(m, EPI_RESID_ADD, m->tmid.p, TF, l.w2.p, TF, Mp, D, TF, (const float*)l.b2.p, tsum, D, nullptr, th, D, Mp, 0, s))) return rc;
+        {
+            ProfScope ps(m, RZ_PROF_ROWOPS, s);
+            RZ_HIP(launch_layernorm(m->dt, tsum, (const float*)l.lno_g.p, (const float*)l.lno_b.p, eps, m->txn.p, th, rows, D, s, m->run_if));
+        }
+    }
+    return 0;
+}
+
 int rz_text_forward(rz_handle_t m, const int64_t* ids, const int64_t* mask, int T, int L, const float* rel_bias, float* out, void* stream) {
     if (!m || !ids || !mask || !rel_bias || !out) return fail(RZ_ERR_INVALID, "rz_text_forward: null argument");
     if (T <= 0 || L <= 0) return fail(RZ_ERR_INVALID, "rz_text_forward: empty prompt batch");
@@ -1154,39 +1228,28 @@ int rz_text_forward(rz_handle_t m, const int64_t* ids, const int64_t* mask, int 
     int rc = rz_weights_ready(m);
     if (rc) return rc;
     hipStream_t s = (hipStream_t)stream;
-    const int D = m->D, H = m->H, TF = m->cfg.text_intermediate_size;
+    const int D = m->D;
     const int rows = T * L, Mp = round_up(rows, 128);
     if (Mp > m->cap_trows) return fail(RZ_ERR_STATE, "rz_text_forward: workspace too small (rz_reserve)");
-    const float eps = m->cfg.text_layer_norm_eps;
-    float* th = (float*)m->th.p;
-    float* tsum = (float*)m->tsum.p;
-    {
-        ProfScope ps(m, RZ_PROF_ROWOPS, s);
-        RZ_HIP(launch_text_embed(m->dt, ids, (const float*)m->word_emb.p, (const float*)m->pos_emb.p, (const float*)m->temb_ln_g.p,
-                                 (const float*)m->temb_ln_b.p, eps, th, m->txn.p, T, L, D, m->cfg.vocab_size,
-                                 m->cfg.max_position_embeddings, m->cfg.pad_token_id, s));
-    }
-    for (const TextLayer& l : m->tlayers) {
-        if ((rc = gemm(m, EPI_STORE, m->txn.p, D, l.wqkv.p, D, Mp, 3 * D, D, (const float*)l.bqkv.p, m->tqkv.p, 3 * D, nullptr, nullptr, 0, Mp, 0, s))) return rc;
-        {
-            ProfScope ps(m, RZ_PROF_ATTN, s);
-            RZ_HIP(launch_text_attn(m->dt, m->tqkv.p, rel_bias, mask, m->tctx.p, T, L, H, s));
-        }
-        if ((rc = gemm(m, EPI_RESID_ADD, m->tctx.p, D, l.wo.p, D, Mp, D, D, (const float*)l.bo.p, tsum, D, nullptr, th, D, Mp, 0, s))) return rc;
-        {
-            ProfScope ps(m, RZ_PROF_ROWOPS, s);
-            RZ_HIP(launch_layernorm(m->dt, tsum, (const float*)l.lna_g.p, (const float*)l.lna_b.p, eps, m->txn.p, th, rows, D, s));
-        }
-        if ((rc = gemm(m, EPI_GELU, m->txn.p, D, l.w1.p, D, Mp, TF, D, (const float*)l.b1.p, m->tmid.p, TF, nullptr, nullptr, 0, Mp, 0, s))) return rc;
-        if ((rc = gemm(m, EPI_RESID_ADD, m->tmid.p, TF, l.w2.p, TF, Mp, D, TF, (const float*)l.b2.p, tsum, D, nullptr, th, D, Mp, 0, s))) return rc;
-        {
-            ProfScope ps(m, RZ_PROF_ROWOPS, s);
-            RZ_HIP(launch_layernorm(m->dt, tsum, (const float*)l.lno_g.p, (const float*)l.lno_b.p, eps, m->txn.p, th, rows, D, s));
-        }
+    // fp32 mode (round 6): the GEMMs run on the three-plane f16 form (gemm_text_split); a value beyond the planes' range raises the text guard word and the
+    // encode is repeated on the exact-fp32 kernels behind that word as a predicate — the vision forward's scheme (rz_vision_forward), on words of its own
+    const bool split = m->dt == RZ_F32 && m->o_gemm_f32_split() && m->text_split_ok && m->tasplit.p && m->ovf.p;
+    const bool guard = split && m->o_guard();
+    if (split) RZ_HIP(launch_guard_word((unsigned*)m->ovf.p, 0, s, 5, 6));
+    rc = text_forward_once(m, ids, mask, T, L, rel_bias, s);
+    if (rc) return rc;
+    if (guard) {
+        m->force_exact = true;
+        m->run_if = (const unsigned*)m->ovf.p + 5;
+        rc = text_forward_once(m, ids, mask, T, L, rel_bias, s);
+        m->force_exact = false;
+        m->run_if = nullptr;
+        if (rc) return rc;
+        RZ_HIP(launch_guard_word((unsigned*)m->ovf.p, 1, s, 5, 6));
     }
     {
         ProfScope ps(m, RZ_PROF_ROWOPS, s);
-        RZ_HIP(launch_masked_meanpool(th, mask, out, T, L, D, s));
+        RZ_HIP(launch_masked_meanpool((const float*)m->th.p, mask, out, T, L, D, s));
     }
     return 0;
 }
@@ -1527,7 +1590,9 @@ int rz_get_model_option(rz_handle_t m, const char* name, int* value_out) {
         unsigned n = 0;
         if (m->ovf.p && m->ovf.bytes >= 32) {
             RZ_HIP(hipDeviceSynchronize());
-            RZ_HIP(hipMemcpy(&n, (const unsigned*)m->ovf.p + 4, 4, hipMemcpyDeviceToHost));
+            unsigned w[3] = {0, 0, 0};
+            RZ_HIP(hipMemcpy(w, (const unsigned*)m->ovf.p + 4, 12, hipMemcpyDeviceToHost));
+            n = w[0] + w[2];                 // vision forwards + prompt encodes repeated on the exact kernels
         }
         *value_out = (int)std::min<unsigned>(n, (unsigned)INT32_MAX);
         return 0;

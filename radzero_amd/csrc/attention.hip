@@ -1433,7 +1433,8 @@ hipError_t launch_flash_attn(int dtype, const void* q, const void* k, const void
 // ---------------------------------------------------------------------------------------------
 template <typename T>
 __global__ void text_attn_kernel(const T* __restrict__ qkv, const float* __restrict__ bias,
-                                 const int64_t* __restrict__ mask, T* __restrict__ ctx, int Tn, int L, int H) {
+                                 const int64_t* __restrict__ mask, T* __restrict__ ctx, int Tn, int L, int H, const unsigned* __restrict__ run_if) {
+    if (run_if && *run_if == 0) return;      // predicated launch (fp32 mode's text guard)
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     const int h = blockIdx.y, t = blockIdx.z;
     if (i >= L) return;
@@ -1475,8 +1476,9 @@ __global__ void text_attn_kernel(const T* __restrict__ qkv, const float* __restr
 // of the text encoder (now ~8 us).  Same arithmetic up to summation order (plain max / exp / sum instead of the online form).
 template <typename T>
 __global__ __launch_bounds__(256) void text_attn_small_kernel(const T* __restrict__ qkv, const float* __restrict__ bias, const int64_t* __restrict__ mask,
-                                                              T* __restrict__ ctx, int L, int H) {
+                                                              T* __restrict__ ctx, int L, int H, const unsigned* __restrict__ run_if) {
     constexpr int LMAX = 32, LD = 65;
+    if (run_if && *run_if == 0) return;      // predicated launch (fp32 mode's text guard): workgroup-uniform, before any barrier
     __shared__ float qs[LMAX * LD], ks[LMAX * LD], vs[LMAX * 64], ss[LMAX * (LMAX + 1)];
     const int h = blockIdx.x, t = blockIdx.y, tid = threadIdx.x;
     const int D3 = 3 * H * 64, D = H * 64;
@@ -1517,14 +1519,14 @@ __global__ __launch_bounds__(256) void text_attn_small_kernel(const T* __restric
 }
 
 hipError_t launch_text_attn(int dtype, const void* qkv, const float* rel_bias, const int64_t* attn_mask, void* ctx, int T, int L,
-                            int H, hipStream_t s) {
+                            int H, hipStream_t s, const unsigned* run_if) {
     if (T <= 0 || L <= 0) return hipErrorInvalidValue;
     if (L <= 32) {
         const dim3 g(H, T), b(256);
         switch (dtype) {
-            case DT_F32: hipLaunchKernelGGL(text_attn_small_kernel<float>, g, b, 0, s, (const float*)qkv, rel_bias, attn_mask, (float*)ctx, L, H); break;
-            case DT_BF16: hipLaunchKernelGGL(text_attn_small_kernel<bf16_t>, g, b, 0, s, (const bf16_t*)qkv, rel_bias, attn_mask, (bf16_t*)ctx, L, H); break;
-            case DT_F16: hipLaunchKernelGGL(text_attn_small_kernel<f16_t>, g, b, 0, s, (const f16_t*)qkv, rel_bias, attn_mask, (f16_t*)ctx, L, H); break;
+            case DT_F32: hipLaunchKernelGGL(text_attn_small_kernel<float>, g, b, 0, s, (const float*)qkv, rel_bias, attn_mask, (float*)ctx, L, H, run_if); break;
+            case DT_BF16: hipLaunchKernelGGL(text_attn_small_kernel<bf16_t>, g, b, 0, s, (const bf16_t*)qkv, rel_bias, attn_mask, (bf16_t*)ctx, L, H, run_if); break;
+            case DT_F16: hipLaunchKernelGGL(text_attn_small_kernel<f16_t>, g, b, 0, s, (const f16_t*)qkv, rel_bias, attn_mask, (f16_t*)ctx, L, H, run_if); break;
             default: return hipErrorInvalidValue;
         }
         return hipGetLastError();
@@ -1533,15 +1535,15 @@ hipError_t launch_text_attn(int dtype, const void* qkv, const float* rel_bias, c
     switch (dtype) {
         case DT_F32:
             hipLaunchKernelGGL(text_attn_kernel<float>, grid, block, 0, s, (const float*)qkv, rel_bias, attn_mask,
-                               (float*)ctx, T, L, H);
+                               (float*)ctx, T, L, H, run_if);
             break;
         case DT_BF16:
             hipLaunchKernelGGL(text_attn_kernel<bf16_t>, grid, block, 0, s, (const bf16_t*)qkv, rel_bias, attn_mask,
-                               (bf16_t*)ctx, T, L, H);
+                               (bf16_t*)ctx, T, L, H, run_if);
             break;
         case DT_F16:
             hipLaunchKernelGGL(text_attn_kernel<f16_t>, grid, block, 0, s, (const f16_t*)qkv, rel_bias, attn_mask,
-                               (f16_t*)ctx, T, L, H);
+                               (f16_t*)ctx, T, L, H, run_if);
             break;
         default: return hipErrorInvalidValue;
     }

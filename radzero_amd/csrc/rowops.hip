@@ -338,8 +338,9 @@ template <typename T, int NV>
 __global__ __launch_bounds__(256) void text_embed_kernel(const int64_t* __restrict__ ids, const float* __restrict__ word_emb,
                                                          const float* __restrict__ pos_emb, const float* __restrict__ gamma,
                                                          const float* __restrict__ beta, float eps, float* __restrict__ h,
-                                                         T* __restrict__ xn, int Tn, int L, int vocab, int max_pos, int pad_id) {
+                                                         T* __restrict__ xn, int Tn, int L, int vocab, int max_pos, int pad_id, const unsigned* __restrict__ run_if) {
     constexpr int D = 256 * NV;
+    if (run_if && *run_if == 0) return;      // predicated launch (fp32 mode's text guard)
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= (int64_t)Tn * L) return;
@@ -366,13 +367,13 @@ __global__ __launch_bounds__(256) void text_embed_kernel(const int64_t* __restri
 
 hipError_t launch_text_embed(int dtype, const int64_t* ids, const float* word_emb, const float* pos_emb,
                              const float* gamma, const float* beta, float eps, float* h, void* xn, int T, int L, int D,
-                             int vocab, int max_pos, int pad_id, hipStream_t s) {
+                             int vocab, int max_pos, int pad_id, hipStream_t s, const unsigned* run_if) {
     if (D != 768 || T <= 0 || L <= 0) return hipErrorInvalidValue;
     dim3 grid((unsigned)(((int64_t)T * L + 3) / 4)), block(256);
     switch (dtype) {
-        case DT_F32: hipLaunchKernelGGL((text_embed_kernel<float, 3>), grid, block, 0, s, ids, word_emb, pos_emb, gamma, beta, eps, h, (float*)xn, T, L, vocab, max_pos, pad_id); break;
-        case DT_BF16: hipLaunchKernelGGL((text_embed_kernel<bf16_t, 3>), grid, block, 0, s, ids, word_emb, pos_emb, gamma, beta, eps, h, (bf16_t*)xn, T, L, vocab, max_pos, pad_id); break;
-        case DT_F16: hipLaunchKernelGGL((text_embed_kernel<f16_t, 3>), grid, block, 0, s, ids, word_emb, pos_emb, gamma, beta, eps, h, (f16_t*)xn, T, L, vocab, max_pos, pad_id); break;
+        case DT_F32: hipLaunchKernelGGL((text_embed_kernel<float, 3>), grid, block, 0, s, ids, word_emb, pos_emb, gamma, beta, eps, h, (float*)xn, T, L, vocab, max_pos, pad_id, run_if); break;
+        case DT_BF16: hipLaunchKernelGGL((text_embed_kernel<bf16_t, 3>), grid, block, 0, s, ids, word_emb, pos_emb, gamma, beta, eps, h, (bf16_t*)xn, T, L, vocab, max_pos, pad_id, run_if); break;
+        case DT_F16: hipLaunchKernelGGL((text_embed_kernel<f16_t, 3>), grid, block, 0, s, ids, word_emb, pos_emb, gamma, beta, eps, h, (f16_t*)xn, T, L, vocab, max_pos, pad_id, run_if); break;
         default: return hipErrorInvalidValue;
     }
     return hipGetLastError();
@@ -486,14 +487,14 @@ hipError_t launch_copy_tokens(const float* src, float* dst, int B, int n_valid, 
 }
 
 // ---- fp32 mode's overflow guard words (rz_kernels.h launch_guard_word) ----
-__global__ void guard_word_kernel(unsigned* __restrict__ words, int op) {
-    if (op == 0) words[0] = 0;
-    else if (words[0]) words[4] += 1;
+__global__ void guard_word_kernel(unsigned* __restrict__ words, int op, int flag_idx, int count_idx) {
+    if (op == 0) words[flag_idx] = 0;
+    else if (words[flag_idx]) words[count_idx] += 1;
 }
 
-hipError_t launch_guard_word(unsigned* words, int op, hipStream_t s) {
-    if (!words || (op != 0 && op != 1)) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(guard_word_kernel, dim3(1), dim3(1), 0, s, words, op);
+hipError_t launch_guard_word(unsigned* words, int op, hipStream_t s, int flag_idx, int count_idx) {
+    if (!words || (op != 0 && op != 1) || flag_idx < 0 || flag_idx > 7 || count_idx < 0 || count_idx > 7) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(guard_word_kernel, dim3(1), dim3(1), 0, s, words, op, flag_idx, count_idx);
     return hipGetLastError();
 }
 

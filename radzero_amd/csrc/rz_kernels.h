@@ -97,7 +97,7 @@ hipError_t launch_flash_attn(int dtype, const void* q, const void* k, const void
 // MPNet self-attention for short sequences: qkv [T*L][3*H*64] (q|k|v), additive relative-position bias expanded by the
 // host to rel_bias[H][L][L], key-padding mask [T][L]; ctx [T*L][H*64].
 hipError_t launch_text_attn(int dtype, const void* qkv, const float* rel_bias, const int64_t* attn_mask, void* ctx, int T, int L,
-                            int H, hipStream_t s);
+                            int H, hipStream_t s, const unsigned* run_if = nullptr);
 
 // Fused-LayerNorm support (rowops.hip).  The T copy of a residual row is CENTRED before rounding: (x - c_m) * gain with c_m a
 // per-row constant close to the row mean (its mean before the last residual update, kept in mu[rows]); consumers get
@@ -122,8 +122,8 @@ hipError_t launch_layernorm(int dtype, const float* in, const float* gamma, cons
                             void* out_t, float* out_f32, int64_t rows, int D, hipStream_t s, const unsigned* run_if = nullptr);
 
 // fp32 mode's overflow guard (api.hip rz_vision_forward): words[0] = the flag the plane producers raise, words[4] = forwards repeated so far.
-// op 0: words[0] = 0 (start of a forward); op 1: if (words[0]) ++words[4] (behind the predicated exact-fp32 pass)
-hipError_t launch_guard_word(unsigned* words, int op, hipStream_t s);
+// op 0: words[flag_idx] = 0 (start of a forward); op 1: if (words[flag_idx]) ++words[count_idx] (behind the predicated exact-fp32 pass)
+hipError_t launch_guard_word(unsigned* words, int op, hipStream_t s, int flag_idx = 0, int count_idx = 4);      // (5, 6): the text encoder's flag / counter
 
 // im2col for the 14x14/stride-14 patch conv: pixels fp32 [B][C][H][W] -> A<T>[B][Npad][Kpad];
 // row 0 (CLS) and rows >= 1+gh*gw are zero; columns >= C*14*14 are zero.
@@ -133,7 +133,7 @@ hipError_t launch_im2col(int dtype, const float* px, void* out, int B, int C, in
 // MPNet embeddings: word_emb[ids] + pos_emb[pos_ids(ids)] -> LN -> h fp32 + T copy.
 hipError_t launch_text_embed(int dtype, const int64_t* ids, const float* word_emb, const float* pos_emb,
                              const float* gamma, const float* beta, float eps, float* h, void* xn,
-                             int T, int L, int D, int vocab, int max_pos, int pad_id, hipStream_t s);
+                             int T, int L, int D, int vocab, int max_pos, int pad_id, hipStream_t s, const unsigned* run_if = nullptr);
 
 // masked mean pool: h [T][L][D] fp32, mask [T][L] -> out [T][D]
 hipError_t launch_masked_meanpool(const float* h, const int64_t* mask, float* out, int T, int L, int D, hipStream_t s);

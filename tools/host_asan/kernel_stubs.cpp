@@ -199,7 +199,8 @@ hipError_t launch_flash_attn_split_planes(const void* q_hi, const void* k_hi, co
     wr(ctx3, (size_t)B * np * (mx_out ? 4 : 6) * H * 64, "split attention ctx planes");
     return hipSuccess;
 }
-hipError_t launch_text_attn(int dtype, const void* qkv, const float* rel_bias, const int64_t* mask, void* ctx, int T, int L, int H, hipStream_t) {
+hipError_t launch_text_attn(int dtype, const void* qkv, const float* rel_bias, const int64_t* mask, void* ctx, int T, int L, int H, hipStream_t, const unsigned* run_if) {
+    if (run_if) { rd(run_if, 4, "text attention predicate"); if (*run_if == 0) return hipSuccess; }
     rd(qkv, (size_t)T * L * 3 * H * 64 * esz(dtype), "text attention qkv");
     rd(rel_bias, (size_t)H * L * L * 4, "text attention bias");
     rd(mask, (size_t)T * L * 8, "text attention mask");
@@ -236,7 +237,8 @@ hipError_t launch_im2col(int dtype, const float* px, void* out, int B, int C, in
     rd(px, (size_t)B * C * H * W * 4, "im2col pixels"); wr(out, (size_t)B * n_pad * k_pad * esz(dtype), "im2col matrix");
     return hipSuccess;
 }
-hipError_t launch_text_embed(int dtype, const int64_t* ids, const float* we, const float* pe, const float* g, const float* b, float, float* h, void* xn, int T, int L, int D, int vocab, int max_pos, int, hipStream_t) {
+hipError_t launch_text_embed(int dtype, const int64_t* ids, const float* we, const float* pe, const float* g, const float* b, float, float* h, void* xn, int T, int L, int D, int vocab, int max_pos, int, hipStream_t, const unsigned* run_if) {
+    if (run_if) { rd(run_if, 4, "text embed predicate"); if (*run_if == 0) return hipSuccess; }
     rd(ids, (size_t)T * L * 8, "text ids"); rd(we, (size_t)vocab * D * 4, "word embeddings"); rd(pe, (size_t)max_pos * D * 4, "position embeddings");
     rd(g, (size_t)D * 4, "gamma"); rd(b, (size_t)D * 4, "beta");
     wr(h, (size_t)T * L * D * 4, "text h"); wr(xn, (size_t)T * L * D * esz(dtype), "text xn");
@@ -268,11 +270,11 @@ hipError_t launch_copy_tokens(const float* src, float* dst, int B, int nv, int n
     return hipSuccess;
 }
 
-hipError_t launch_guard_word(unsigned* words, int op, hipStream_t) {      // rowops.hip: the fp32 mode's overflow-guard words (8 x u32)
-    if (!words || (op != 0 && op != 1)) return hipErrorInvalidValue;
+hipError_t launch_guard_word(unsigned* words, int op, hipStream_t, int flag_idx, int count_idx) {      // rowops.hip: the fp32 mode's overflow-guard words (8 x u32)
+    if (!words || (op != 0 && op != 1) || flag_idx < 0 || flag_idx > 7 || count_idx < 0 || count_idx > 7) return hipErrorInvalidValue;
     rd(words, 32, "guard words"); wr(words, 32, "guard words");
-    if (op == 0) words[0] = 0;
-    else if (words[0]) words[4] += 1;
+    if (op == 0) words[flag_idx] = 0;
+    else if (words[flag_idx]) words[count_idx] += 1;
     return hipSuccess;
 }
 
