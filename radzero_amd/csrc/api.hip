@@ -507,22 +507,19 @@ int gemm_f32_split(rz_model* m, int epi, GemmArgs g, int a_mode, bool out_split,
     return 0;
 }
 
-// fp32 mode, text encoder (round 6): the MPNet GEMMs (EPI_STORE q|k|v, EPI_RESID_ADD o / fc2, EPI_GELU fc1; A = one of the text workspaces, row 0) on the
-// three-plane f16 form — A is split here into `tasplit`, the weight's [hi | hi | lo] copy was built by rz_weights_ready; fp32 outputs (exact-erf GELU).
+// fp32 mode, text encoder (round 6): the MPNet GEMMs (EPI_STORE q|k|v, EPI_RESID_ADD o / fc2, EPI_GELU fc1) on the three-plane f16 form —
+// the weight's [hi | hi | lo] copy was built by rz_weights_ready; fp32 outputs, or planes again for fc1 (exact-erf GELU).
 // Plane overflows raise the TEXT guard word (ovf[5]): rz_text_forward repeats the encode on the exact kernels behind a predicate, as the vision forward does.
-int gemm_text_split(rz_model* m, int epi, GemmArgs g, hipStream_t s, bool* done) {
-    *done = false;
-    if (!m->text_split_ok || !m->tasplit.p || g.M % 128 || g.lda != g.K || g.ldw != g.K) return 0;
-    if (!(g.A == m->txn.p || g.A == m->tctx.p || g.A == m->tmid.p)) return 0;
+// A is ALREADY in planes (its producer wrote them: the LayerNorm, the attention, fc1's GELU epilogue) inside `tasplit`; out_split: EPI_GELU writes planes too.
+int gemm_text_split(rz_model* m, int epi, GemmArgs g, hipStream_t s, bool out_split) {
     const char* w3 = nullptr;
     for (const auto& e : m->split_w)
         if ((const char*)g.W == e.p && !e.p4) { w3 = e.p3; break; }
-    if (!w3 || (size_t)g.M * 3 * g.K * 2 > m->tasplit.bytes) return 0;
+    if (!w3 || g.M % 128) return fail(RZ_ERR_STATE, "text GEMM: no three-plane copy of this weight");
     g.ovf_flag = (unsigned*)m->ovf.p + 5;
-    RZ_HIP(launch_split3((const float*)g.A, g.lda, m->tasplit.p, g.M, g.K, 0, g.ovf_flag, s));
-    g.A = m->tasplit.p; g.W = w3; g.lda = g.ldw = 3 * (int64_t)g.K; g.K = 3 * g.K;
-    RZ_HIP(launch_gemm_split_f32out(epi, g, s, false));
-    *done = true;
+    g.W = w3; g.lda = g.ldw = 3 * (int64_t)g.K; g.K = 3 * g.K;
+    ProfScope ps(m, RZ_PROF_GEMM, s);
+    RZ_HIP(launch_gemm_split_f32out(epi, g, s, out_split));
     return 0;
 }
 
@@ -537,8 +534,7 @@ int gemm(rz_model* m, int epi, const void* A, int64_t lda, const void* W, int64_
     ProfScope ps(m, RZ_PROF_GEMM, s);
     if (m->dt == RZ_F32 && m->o_gemm_f32_split()) {
         bool done = false;
-        int rc = (epi == EPI_STORE || epi == EPI_RESID_ADD || (epi == EPI_GELU && g.A == m->txn.p && m->txn.p)) ? gemm_text_split(m, epi, g, s, &done)
-                                                                                                                  : gemm_f32_split(m, epi, g, a_mode, out_split, s, &done, mx);
+        int rc = gemm_f32_split(m, epi, g, a_mode, out_split, s, &done, mx);
         if (rc || done) return rc;
     }
     if (a_mode == A_SPLIT || out_split) return fail(RZ_ERR_STATE, "split GEMM requested but not applicable");
@@ -912,7 +908,7 @@ int rz_reserve(rz_handle_t m, int max_batch, int max_tokens, int max_prompts, in
             RZ_HIP(m->txn.ensure((size_t)trows * D * es, true));
             RZ_HIP(m->tqkv.ensure((size_t)trows * 3 * D * es, true));
             RZ_HIP(m->tctx.ensure((size_t)trows * D * es, true));
-            if (m->dt == RZ_F32) RZ_HIP(m->tasplit.ensure((size_t)trows * 3 * std::max((size_t)D, TF) * 2, false));
+            if (m->dt == RZ_F32) RZ_HIP(m->tasplit.ensure((size_t)trows * (6 * (size_t)D + 3 * TF) * 2, true));      // [hi | lo | hi] planes of txn, tctx, tmid
             RZ_HIP(m->tmid.ensure((size_t)trows * TF * es, true));
             m->cap_trows = trows;
         }
@@ -1186,7 +1182,9 @@ static int vision_forward_once(rz_handle_t m, const float* px, int B, int C, int
     return 0;
 }
 
-static int text_forward_once(rz_handle_t m, const int64_t* ids, const int64_t* mask, int T, int L, const float* rel_bias, hipStream_t s) {
+// planes: the fp32 mode's three-plane form — every GEMM operand travels as [hi | lo | hi] f16 planes written by its producer (one split pass for the
+// embeddings, then the LayerNorms, the attention and fc1's epilogue write them): 7 launches per layer, as the 16-bit modes
+static int text_forward_once(rz_handle_t m, const int64_t* ids, const int64_t* mask, int T, int L, const float* rel_bias, hipStream_t s, bool planes) {
     int rc = 0;
     const int D = m->D, H = m->H, TF = m->cfg.text_intermediate_size;
     const int rows = T * L, Mp = round_up(rows, 128);
@@ -1198,6 +1196,41 @@ static int text_forward_once(rz_handle_t m, const int64_t* ids, const int64_t* m
         RZ_HIP(launch_text_embed(m->dt, ids, (const float*)m->word_emb.p, (const float*)m->pos_emb.p, (const float*)m->temb_ln_g.p,
                                  (const float*)m->temb_ln_b.p, eps, th, m->txn.p, T, L, D, m->cfg.vocab_size,
                                  m->cfg.max_position_embeddings, m->cfg.pad_token_id, s, m->run_if));
+    }
+    if (planes) {
+        unsigned* flag = (unsigned*)m->ovf.p + 5;
+        char* txn3 = (char*)m->tasplit.p;                                   // f16 planes: 2 bytes per element
+        char* tctx3 = txn3 + (size_t)m->cap_trows * 3 * D * 2;
+        char* tmid3 = tctx3 + (size_t)m->cap_trows * 3 * D * 2;
+        {
+            ProfScope ps(m, RZ_PROF_ROWOPS, s);
+            RZ_HIP(launch_split3((const float*)m->txn.p, D, txn3, Mp, D, 0, flag, s));
+        }
+        auto tg = [&](int epi, const void* A, const Tensor& W, int N, int K, const Tensor& bias, void* out, int64_t ldo, float* resid, bool out_split) {
+            GemmArgs g;
+            g.A = A; g.lda = K; g.W = W.p; g.ldw = K; g.M = Mp; g.N = N; g.K = K; g.bias = (const float*)bias.p; g.out = out; g.ldo = ldo;
+            g.scale = nullptr; g.resid = resid; g.ldr = D; g.rows_per_image = Mp; g.heads_total = 0; g.variant = m->o_gemm_variant(); g.raster = m->o_gemm_raster();
+            return gemm_text_split(m, epi, g, s, out_split);
+        };
+        for (const TextLayer& l : m->tlayers) {
+            if ((rc = tg(EPI_STORE, txn3, l.wqkv, 3 * D, D, l.bqkv, m->tqkv.p, 3 * D, nullptr, false))) return rc;
+            {
+                ProfScope ps(m, RZ_PROF_ATTN, s);
+                RZ_HIP(launch_text_attn(m->dt, m->tqkv.p, rel_bias, mask, m->tctx.p, T, L, H, s, nullptr, tctx3, flag));
+            }
+            if ((rc = tg(EPI_RESID_ADD, tctx3, l.wo, D, D, l.bo, tsum, D, th, false))) return rc;
+            {
+                ProfScope ps(m, RZ_PROF_ROWOPS, s);
+                RZ_HIP(launch_layernorm_split3(tsum, (const float*)l.lna_g.p, (const float*)l.lna_b.p, eps, txn3, rows, D, flag, s, 0, th));
+            }
+            if ((rc = tg(EPI_GELU, txn3, l.w1, TF, D, l.b1, tmid3, TF, nullptr, true))) return rc;
+            if ((rc = tg(EPI_RESID_ADD, tmid3, l.w2, D, TF, l.b2, tsum, D, th, false))) return rc;
+            {
+                ProfScope ps(m, RZ_PROF_ROWOPS, s);
+                RZ_HIP(launch_layernorm_split3(tsum, (const float*)l.lno_g.p, (const float*)l.lno_b.p, eps, txn3, rows, D, flag, s, 0, th));
+            }
+        }
+        return 0;
     }
     for (const TextLayer& l : m->tlayers) {
         if ((rc = gemm(m, EPI_STORE, m->txn.p, D, l.wqkv.p, D, Mp, 3 * D, D, (const float*)l.bqkv.p, m->tqkv.p, 3 * D, nullptr, nullptr, 0, Mp, 0, s))) return rc;
@@ -1236,12 +1269,12 @@ int rz_text_forward(rz_handle_t m, const int64_t* ids, const int64_t* mask, int 
     const bool split = m->dt == RZ_F32 && m->o_gemm_f32_split() && m->text_split_ok && m->tasplit.p && m->ovf.p;
     const bool guard = split && m->o_guard();
     if (split) RZ_HIP(launch_guard_word((unsigned*)m->ovf.p, 0, s, 5, 6));
-    rc = text_forward_once(m, ids, mask, T, L, rel_bias, s);
+    rc = text_forward_once(m, ids, mask, T, L, rel_bias, s, split);
     if (rc) return rc;
     if (guard) {
         m->force_exact = true;
         m->run_if = (const unsigned*)m->ovf.p + 5;
-        rc = text_forward_once(m, ids, mask, T, L, rel_bias, s);
+        rc = text_forward_once(m, ids, mask, T, L, rel_bias, s, false);
         m->force_exact = false;
         m->run_if = nullptr;
         if (rc) return rc;

@@ -1431,9 +1431,22 @@ hipError_t launch_flash_attn(int dtype, const void* q, const void* k, const void
 // mask_add = 0 for attended keys, -FLT_MAX otherwise (HF additive mask) -> fully masked rows become
 // uniform exactly like the reference.
 // ---------------------------------------------------------------------------------------------
+// fp32 mode: 64 context values of one (token, head) as [hi | lo | hi] f16 planes of the out-projection's A operand (rz_common.h split4 semantics)
+__device__ __forceinline__ void text_ctx_planes(f16_t* row, int D, const float (&o)[64], float inv, unsigned* ovf_flag) {
+#pragma unroll
+    for (int d = 0; d < 64; d += 4) {
+        f16x4 hi, lo;
+        split4((f32x4){o[d] * inv, o[d + 1] * inv, o[d + 2] * inv, o[d + 3] * inv}, hi, lo, ovf_flag);
+        *reinterpret_cast<f16x4*>(row + d) = hi;
+        *reinterpret_cast<f16x4*>(row + D + d) = lo;
+        *reinterpret_cast<f16x4*>(row + 2 * D + d) = hi;
+    }
+}
+
 template <typename T>
 __global__ void text_attn_kernel(const T* __restrict__ qkv, const float* __restrict__ bias,
-                                 const int64_t* __restrict__ mask, T* __restrict__ ctx, int Tn, int L, int H, const unsigned* __restrict__ run_if) {
+                                 const int64_t* __restrict__ mask, T* __restrict__ ctx, int Tn, int L, int H, const unsigned* __restrict__ run_if,
+                                 f16_t* __restrict__ planes, unsigned* ovf_flag) {
     if (run_if && *run_if == 0) return;      // predicated launch (fp32 mode's text guard)
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     const int h = blockIdx.y, t = blockIdx.z;
@@ -1465,6 +1478,10 @@ __global__ void text_attn_kernel(const T* __restrict__ qkv, const float* __restr
         m = mn;
     }
     const float inv = 1.f / l;
+    if (planes) {
+        text_ctx_planes(planes + ((int64_t)t * L + i) * 3 * D + h * 64, D, o, inv, ovf_flag);
+        return;
+    }
     T* op = ctx + ((int64_t)t * L + i) * D + h * 64;
 #pragma unroll
     for (int d = 0; d < 64; ++d) op[d] = from_f32<T>(o[d] * inv);
@@ -1476,7 +1493,8 @@ __global__ void text_attn_kernel(const T* __restrict__ qkv, const float* __restr
 // of the text encoder (now ~8 us).  Same arithmetic up to summation order (plain max / exp / sum instead of the online form).
 template <typename T>
 __global__ __launch_bounds__(256) void text_attn_small_kernel(const T* __restrict__ qkv, const float* __restrict__ bias, const int64_t* __restrict__ mask,
-                                                              T* __restrict__ ctx, int L, int H, const unsigned* __restrict__ run_if) {
+                                                              T* __restrict__ ctx, int L, int H, const unsigned* __restrict__ run_if,
+                                                              f16_t* __restrict__ planes, unsigned* ovf_flag) {
     constexpr int LMAX = 32, LD = 65;
     if (run_if && *run_if == 0) return;      // predicated launch (fp32 mode's text guard): workgroup-uniform, before any barrier
     __shared__ float qs[LMAX * LD], ks[LMAX * LD], vs[LMAX * 64], ss[LMAX * (LMAX + 1)];
@@ -1514,19 +1532,27 @@ __global__ __launch_bounds__(256) void text_attn_small_kernel(const T* __restric
         const int i = e >> 6, d = e & 63;
         float o = 0.f;
         for (int j = 0; j < L; ++j) o = fmaf(ss[i * (LMAX + 1) + j], vs[j * 64 + d], o);
+        if (planes) {          // [hi | lo | hi] of the out-projection's A operand (element-wise: rz_common.h split4's arithmetic)
+            const f16_t hi = (f16_t)o;
+            f16_t* pr = planes + ((int64_t)t * L + i) * 3 * D + h * 64 + d;
+            pr[0] = hi; pr[D] = (f16_t)(o - (float)hi); pr[2 * D] = hi;
+            if ((__float_as_uint(o) & 0x7fffffffu) > 0x477fe000u && ovf_flag) atomicOr(ovf_flag, 1u);      // |o| > 65504 or NaN (integer compare: this file is built with -fno-honor-nans)
+            continue;
+        }
         ctx[((int64_t)t * L + i) * D + h * 64 + d] = from_f32<T>(o);
     }
 }
 
 hipError_t launch_text_attn(int dtype, const void* qkv, const float* rel_bias, const int64_t* attn_mask, void* ctx, int T, int L,
-                            int H, hipStream_t s, const unsigned* run_if) {
-    if (T <= 0 || L <= 0) return hipErrorInvalidValue;
+                            int H, hipStream_t s, const unsigned* run_if, void* planes_out, unsigned* ovf_flag) {
+    if (T <= 0 || L <= 0 || (planes_out && dtype != DT_F32)) return hipErrorInvalidValue;
+    f16_t* planes = (f16_t*)planes_out;
     if (L <= 32) {
         const dim3 g(H, T), b(256);
         switch (dtype) {
-            case DT_F32: hipLaunchKernelGGL(text_attn_small_kernel<float>, g, b, 0, s, (const float*)qkv, rel_bias, attn_mask, (float*)ctx, L, H, run_if); break;
-            case DT_BF16: hipLaunchKernelGGL(text_attn_small_kernel<bf16_t>, g, b, 0, s, (const bf16_t*)qkv, rel_bias, attn_mask, (bf16_t*)ctx, L, H, run_if); break;
-            case DT_F16: hipLaunchKernelGGL(text_attn_small_kernel<f16_t>, g, b, 0, s, (const f16_t*)qkv, rel_bias, attn_mask, (f16_t*)ctx, L, H, run_if); break;
+            case DT_F32: hipLaunchKernelGGL(text_attn_small_kernel<float>, g, b, 0, s, (const float*)qkv, rel_bias, attn_mask, (float*)ctx, L, H, run_if, planes, ovf_flag); break;
+            case DT_BF16: hipLaunchKernelGGL(text_attn_small_kernel<bf16_t>, g, b, 0, s, (const bf16_t*)qkv, rel_bias, attn_mask, (bf16_t*)ctx, L, H, run_if, nullptr, nullptr); break;
+            case DT_F16: hipLaunchKernelGGL(text_attn_small_kernel<f16_t>, g, b, 0, s, (const f16_t*)qkv, rel_bias, attn_mask, (f16_t*)ctx, L, H, run_if, nullptr, nullptr); break;
             default: return hipErrorInvalidValue;
         }
         return hipGetLastError();
@@ -1535,15 +1561,15 @@ hipError_t launch_text_attn(int dtype, const void* qkv, const float* rel_bias, c
     switch (dtype) {
         case DT_F32:
             hipLaunchKernelGGL(text_attn_kernel<float>, grid, block, 0, s, (const float*)qkv, rel_bias, attn_mask,
-                               (float*)ctx, T, L, H, run_if);
+                               (float*)ctx, T, L, H, run_if, planes, ovf_flag);
             break;
         case DT_BF16:
             hipLaunchKernelGGL(text_attn_kernel<bf16_t>, grid, block, 0, s, (const bf16_t*)qkv, rel_bias, attn_mask,
-                               (bf16_t*)ctx, T, L, H, run_if);
+                               (bf16_t*)ctx, T, L, H, run_if, nullptr, nullptr);
             break;
         case DT_F16:
             hipLaunchKernelGGL(text_attn_kernel<f16_t>, grid, block, 0, s, (const f16_t*)qkv, rel_bias, attn_mask,
-                               (f16_t*)ctx, T, L, H, run_if);
+                               (f16_t*)ctx, T, L, H, run_if, nullptr, nullptr);
             break;
         default: return hipErrorInvalidValue;
     }

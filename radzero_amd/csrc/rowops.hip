@@ -64,7 +64,8 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
 // fp32 mode, hi/lo-split path: the LayerNorm output leaves as the next GEMM's A operand [rows][3D] f16 = [hi | lo | hi] (rz_common.h split4)
 template <int NV>
 __global__ __launch_bounds__(256) void layernorm_split3_kernel(const float* __restrict__ in, const float* __restrict__ gamma,
-                                                               const float* __restrict__ beta, float eps, f16_t* __restrict__ out3, int64_t rows, unsigned* ovf_flag) {
+                                                               const float* __restrict__ beta, float eps, f16_t* __restrict__ out3, int64_t rows, unsigned* ovf_flag,
+                                                               float* __restrict__ out_f32) {
     constexpr int D = 256 * NV;
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -73,6 +74,7 @@ __global__ __launch_bounds__(256) void layernorm_split3_kernel(const float* __re
     row_layernorm<NV>(r, gamma, beta, eps, lane);
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
+        if (out_f32) *reinterpret_cast<f32x4*>(out_f32 + row * D + (lane + 64 * i) * 4) = r.v[i];      // the text encoder's post-LN residual (MPNet)
         f16x4 hi, lo;
         split4(r.v[i], hi, lo, ovf_flag);
         f16_t* o = out3 + row * 3 * D + (lane + 64 * i) * 4;
@@ -106,10 +108,10 @@ __global__ __launch_bounds__(256) void layernorm_split_mx_kernel(const float* __
     }
 }
 
-hipError_t launch_layernorm_split3(const float* in, const float* gamma, const float* beta, float eps, void* out3, int64_t rows, int D, unsigned* ovf_flag, hipStream_t s, int mx) {
-    if (D != 768 || rows <= 0) return hipErrorInvalidValue;
+hipError_t launch_layernorm_split3(const float* in, const float* gamma, const float* beta, float eps, void* out3, int64_t rows, int D, unsigned* ovf_flag, hipStream_t s, int mx, float* out_f32) {
+    if (D != 768 || rows <= 0 || (mx && out_f32)) return hipErrorInvalidValue;
     if (mx) hipLaunchKernelGGL((layernorm_split_mx_kernel<3>), dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, in, gamma, beta, eps, (char*)out3, rows, ovf_flag);
-    else hipLaunchKernelGGL((layernorm_split3_kernel<3>), dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, in, gamma, beta, eps, (f16_t*)out3, rows, ovf_flag);
+    else hipLaunchKernelGGL((layernorm_split3_kernel<3>), dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, in, gamma, beta, eps, (f16_t*)out3, rows, ovf_flag, out_f32);
     return hipGetLastError();
 }
 

@@ -97,7 +97,7 @@ hipError_t launch_flash_attn(int dtype, const void* q, const void* k, const void
 // MPNet self-attention for short sequences: qkv [T*L][3*H*64] (q|k|v), additive relative-position bias expanded by the
 // host to rel_bias[H][L][L], key-padding mask [T][L]; ctx [T*L][H*64].
 hipError_t launch_text_attn(int dtype, const void* qkv, const float* rel_bias, const int64_t* attn_mask, void* ctx, int T, int L,
-                            int H, hipStream_t s, const unsigned* run_if = nullptr);
+                            int H, hipStream_t s, const unsigned* run_if = nullptr, void* planes_out = nullptr, unsigned* ovf_flag = nullptr);      // planes_out (fp32 operands only): ctx leaves as [rows][3 H 64] f16 = [hi | lo | hi] instead (the text encoder's out-projection operand in the fp32 mode)
 
 // Fused-LayerNorm support (rowops.hip).  The T copy of a residual row is CENTRED before rounding: (x - c_m) * gain with c_m a
 // per-row constant close to the row mean (its mean before the last residual update, kept in mu[rows]); consumers get
@@ -117,7 +117,7 @@ hipError_t launch_image_features(const float* tokens, int64_t image_stride, int 
 
 // LayerNorm over rows of 768: fp32 in; writes T-typed normalized copy (out_t, may be null) and/or
 // fp32 (out_f32, may alias in).
-hipError_t launch_layernorm_split3(const float* in, const float* gamma, const float* beta, float eps, void* out3, int64_t rows, int D, unsigned* ovf_flag, hipStream_t s, int mx = 0);   // mx: the MX form (rz_common.h), 4 D bytes per row
+hipError_t launch_layernorm_split3(const float* in, const float* gamma, const float* beta, float eps, void* out3, int64_t rows, int D, unsigned* ovf_flag, hipStream_t s, int mx = 0, float* out_f32 = nullptr);   // mx: the MX form (rz_common.h), 4 D bytes per row
 hipError_t launch_layernorm(int dtype, const float* in, const float* gamma, const float* beta, float eps,
                             void* out_t, float* out_f32, int64_t rows, int D, hipStream_t s, const unsigned* run_if = nullptr);
 
