@@ -199,12 +199,14 @@ hipError_t launch_flash_attn_split_planes(const void* q_hi, const void* k_hi, co
     wr(ctx3, (size_t)B * np * (mx_out ? 4 : 6) * H * 64, "split attention ctx planes");
     return hipSuccess;
 }
-hipError_t launch_text_attn(int dtype, const void* qkv, const float* rel_bias, const int64_t* mask, void* ctx, int T, int L, int H, hipStream_t, const unsigned* run_if) {
+hipError_t launch_text_attn(int dtype, const void* qkv, const float* rel_bias, const int64_t* mask, void* ctx, int T, int L, int H, hipStream_t, const unsigned* run_if, void* planes, unsigned* flag) {
     if (run_if) { rd(run_if, 4, "text attention predicate"); if (*run_if == 0) return hipSuccess; }
+    if (flag) rd(flag, 4, "text guard word");
+    if (planes) { if (dtype != DT_F32) return hipErrorInvalidValue; wr(planes, (size_t)T * L * 3 * H * 64 * 2, "text attention planes"); ctx = nullptr; }
     rd(qkv, (size_t)T * L * 3 * H * 64 * esz(dtype), "text attention qkv");
     rd(rel_bias, (size_t)H * L * L * 4, "text attention bias");
     rd(mask, (size_t)T * L * 8, "text attention mask");
-    wr(ctx, (size_t)T * L * H * 64 * esz(dtype), "text attention ctx");
+    if (ctx) wr(ctx, (size_t)T * L * H * 64 * esz(dtype), "text attention ctx");
     return hipSuccess;
 }
 
@@ -220,8 +222,9 @@ hipError_t launch_ln_prepare(int dtype, const float* in, const float* g, const f
     wr(copy_t, (size_t)rows * D * esz(dtype), "ln_prepare copy"); wr(mu, (size_t)rows * 4, "ln_prepare mu"); wr(stat, (size_t)rows * 8, "ln_prepare stat");
     return hipSuccess;
 }
-hipError_t launch_layernorm_split3(const float* in, const float* g, const float* b, float, void* out3, int64_t rows, int D, unsigned*, hipStream_t, int mx) {
+hipError_t launch_layernorm_split3(const float* in, const float* g, const float* b, float, void* out3, int64_t rows, int D, unsigned*, hipStream_t, int mx, float* out_f32) {
     rd(in, (size_t)rows * D * 4, "layernorm_split3 in"); rd(g, (size_t)D * 4, "gamma"); rd(b, (size_t)D * 4, "beta");
+    if (out_f32) wr(out_f32, (size_t)rows * D * 4, "layernorm_split3 fp32 out");
     wr(out3, (size_t)rows * (mx ? 4 : 6) * D, "layernorm_split3 planes");
     return hipSuccess;
 }
