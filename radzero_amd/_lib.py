@@ -44,9 +44,30 @@ def _all_deps() -> list:
     return deps
 
 
+STAMP_PATH = LIB_PATH + ".stamp"
+
+
+def _source_digest() -> str:
+    """sha256 over the CONTENTS of every source / header the library is built from (+ the build flavour and extra flags): the rebuild decision must not
+    depend on file times — a snapshot copied to another machine (gpurun, the driver's round-end run) keeps contents, not necessarily mtime order."""
+    import hashlib
+    h = hashlib.sha256()
+    h.update(("experiments" if EXPERIMENTS else "product").encode() + os.environ.get("RZ_CXXFLAGS", "").encode())
+    for d in sorted(os.path.abspath(p) for p in _all_deps() if os.path.isfile(p)):
+        h.update(os.path.basename(d).encode())
+        with open(d, "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()
+
+
 def _needs_rebuild() -> bool:
     if not os.path.exists(LIB_PATH):
         return True
+    try:
+        return open(STAMP_PATH).read().strip() != _source_digest()
+    except OSError:
+        pass
+    # a library without a stamp (built by an older tree): fall back to file times
     t = os.path.getmtime(LIB_PATH)
     return any(os.path.getmtime(d) > t for d in _all_deps() if os.path.exists(d))
 
@@ -100,6 +121,9 @@ def _build_locked(obj_dir: str, verbose: bool, force: bool = False) -> str:
     if r.returncode != 0:
         raise RuntimeError(f"link failed:\n{r.stderr}")
     os.replace(LIB_PATH + tag, LIB_PATH)
+    with open(STAMP_PATH + tag, "w") as f:
+        f.write(_source_digest() + "\n")
+    os.replace(STAMP_PATH + tag, STAMP_PATH)
     return LIB_PATH
 
 
