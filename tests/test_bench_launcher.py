@@ -129,3 +129,15 @@ def test_collective_log_counts_what_the_process_group_carried():
     for rank, n_exchange, gather_bytes, n_steps, n_barriers, shape, n_after in res:
         assert n_exchange == 1 and n_steps == 0 and n_barriers == 1 and n_after == 1 and shape == (14, 768)
         assert gather_bytes == 7 * 768 * 4                  # gloo path: a list all_gather of (7, 768) fp32 shards (the NCCL path gathers into one tensor)
+
+
+def test_roofline_fractions_are_against_the_hardware_peak():
+    """every MFMA roofline block prices `frac` against the 2500 TFLOP/s hardware peak; the fp32 mode's derating by issued MFMA units is a
+    separate field (`frac_of_issue_bound` = frac x units), never the peak."""
+    import bench
+    r = bench.roofline_mfma("flash_attn_kernel", 1068.0, None, {"traffic": None})
+    assert r["peak"] == 2500.0 and r["frac"] == round(1068.0 / 2500.0, 4) and "frac_of_issue_bound" not in r
+    f = bench.roofline_mfma("flash_attn_split_kernel", 436.0, 2.5, {"traffic": 123})
+    assert f["peak"] == 2500.0 and f["frac"] == round(436.0 / 2500.0, 4) == 0.1744
+    assert f["issued_units_per_product"] == 2.5 and f["frac_of_issue_bound"] == round(436.0 * 2.5 / 2500.0, 4)
+    assert f["exact_fp32_matrix_peak"] == 157.3 and f["traffic"] == 123
