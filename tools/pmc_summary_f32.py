@@ -53,3 +53,37 @@ rec["algorithmic_bytes_note"] = {"flash_attn_split_kernel": int(32 * n * d * 4 *
                                  "how": "B x N x 768 x 4 bytes per operand element (q | k hi + lo f16 planes, V^T hi f16 + e4m3 pair plane, ctx in the MX form) x 4 tensors"}
 json.dump(rec, open(os.path.join(summ, "hbm_traffic_pmc_f32.json"), "w"), indent=1)
 print(json.dumps(rec["kernels"], indent=1))
+
+# ---- MFMA busy / VALU active / wait fractions / shader clock of the fp32 mode's kernels (pass pmc_sq_f32), as tools/pmc_summary.py computes them for the bf16 step
+sq = defaultdict(lambda: defaultdict(list))
+dur = defaultdict(list)
+for path in glob.glob(os.path.join(out, "pmc_sq_f32", "**", "*counter_collection.csv"), recursive=True):
+    for row in csv.DictReader(open(path)):
+        k = short(row["Kernel_Name"])
+        if k:
+            sq[k][row["Counter_Name"]].append(float(row["Counter_Value"]))
+for path in glob.glob(os.path.join(out, "pmc_sq_f32", "**", "*kernel_trace.csv"), recursive=True):
+    for row in csv.DictReader(open(path)):
+        k = short(row["Kernel_Name"])
+        if k:
+            dur[k].append(float(row["End_Timestamp"]) - float(row["Start_Timestamp"]))
+util = {"command": "rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU --output-format csv -- "
+                   "python3 bench.py --dtype f32 --steps 2 --warmup 1 --no-cpu-baseline --no-other-configs --no-kernel-events (B=32, 1024^2, fp32 mode, default options)",
+        "notes": "as profiles/*/mfma_utilisation_pmc.json; launches with less than half the kernel's longest duration are dropped (the text encoder's small launches, the guard's empty ones)",
+        "kernels": {}}
+for key, c in sq.items():
+    d = dur.get(key, [])
+    if not c.get("GRBM_GUI_ACTIVE") or not d:
+        continue
+    keep = [i for i, v in enumerate(d) if v > 0.5 * max(d)] if len(d) == len(c["GRBM_GUI_ACTIVE"]) else list(range(len(c["GRBM_GUI_ACTIVE"])))
+    mean = lambda name: (sum(c[name][i] for i in keep if i < len(c[name])) / max(1, len([i for i in keep if i < len(c[name])]))) if c.get(name) else 0.0
+    gui = mean("GRBM_GUI_ACTIVE") / 8.0
+    d_ns = sum(d[i] for i in keep if i < len(d)) / max(1, len([i for i in keep if i < len(d)]))
+    util["kernels"][key] = {"launches": len(keep), "mean_duration_us": round(d_ns / 1e3, 1), "shader_clock_GHz": round(gui / d_ns, 3) if d_ns else None,
+                            "mfma_busy_frac_of_simd_cycles": round(mean("SQ_VALU_MFMA_BUSY_CYCLES") / (1024.0 * gui), 4) if gui else None,
+                            "valu_active_frac": round(mean("SQ_ACTIVE_INST_VALU") / max(1.0, mean("SQ_WAVE_CYCLES")), 4),
+                            "wave_cycles_waiting_frac": round(mean("SQ_WAIT_ANY") / max(1.0, mean("SQ_WAVE_CYCLES")), 4),
+                            "wave_cycles_issue_stall_frac": round(mean("SQ_WAIT_INST_ANY") / max(1.0, mean("SQ_WAVE_CYCLES")), 4)}
+if util["kernels"]:
+    json.dump(util, open(os.path.join(summ, "mfma_utilisation_pmc_f32.json"), "w"), indent=1)
+    print(json.dumps(util["kernels"], indent=1))

@@ -36,6 +36,7 @@ echo "[profile] fp32-mode trace done"
 PMCF="python3 bench.py --dtype f32 --steps 2 --warmup 1 --no-cpu-baseline --no-other-configs --no-kernel-events"
 rocprofv3 --kernel-trace --mangled-kernels --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch_f32 -- $PMCF > $OUT/pmc_fetch_f32.json 2> $OUT/pmc_fetch_f32.err
 rocprofv3 --kernel-trace --mangled-kernels --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write_f32 -- $PMCF > $OUT/pmc_write_f32.json 2> $OUT/pmc_write_f32.err
+rocprofv3 --kernel-trace --mangled-kernels --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU --output-format csv -d $OUT/pmc_sq_f32 -- $PMCF > $OUT/pmc_sq_f32.json 2> $OUT/pmc_sq_f32.err
 python3 tools/pmc_summary_f32.py $OUT > /dev/null
 echo "[profile] fp32-mode FETCH / WRITE passes done"
 for c in cfg4 cfg5 f32; do f=$(find $OUT/trace_$c -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $OUT/summary/kernel_stats_$c.csv; cp $OUT/bench_${c}_under_rocprof.json $OUT/summary/ || true; done
