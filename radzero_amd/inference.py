@@ -243,7 +243,7 @@ def calculate_similarities(source, text_batch, model, distributed: bool = False,
         batches = (px for i, px in enumerate(source) if i % world == rank)
 
     out, rows = [], []          # out: (logits, where its rows belong); rows: SOURCE batch sizes (the distributed interleave deals source batches)
-    batches = _reshape_batches(batches, model, rows, enabled=bool(batch_shaping) and cuda)
+    batches = _reshape_batches(batches, model, rows, enabled=bool(batch_shaping))      # a model without preferred_batch() passes through untouched
     if cuda and overlap:
         # produce batch k + 1 (dataset reads, H2D, device preprocessing) on a side stream while batch k computes on the current one
         main = torch.cuda.current_stream(model.device)

@@ -411,3 +411,42 @@ def test_reshape_batches_keeps_order_rows_and_results():
     got = list(_reshape_batches(iter(mixed), _ShapedModel(62), [], enabled=True))
     assert [tuple(g.shape) for g, _ in got] == [(62, 3, 2, 2), (2, 3, 2, 2), (5, 3, 4, 4), (62, 3, 2, 2), (2, 3, 2, 2)]
     assert [r for _, r in got] == [[(0, 62)], [(62, 2)], [(64, 5)], [(69, 62)], [(131, 2)]]
+
+
+def _shaped_driver_worker(rank, world, port, n_images, batch, target, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from radzero_amd.inference import calculate_similarities
+        g = torch.Generator().manual_seed(1)
+        enc = {"input_ids": torch.randint(4, 30000, (5, 7), generator=g), "attention_mask": torch.ones(5, 7, dtype=torch.long)}
+        m = _ShapedModel(target)
+        got = calculate_similarities(_LoggingDataset(n_images), {"encoded_key_phrases": enc}, m, distributed=True, batch_size=batch)
+        q.put((rank, None if got is None else got.tolist(), m.forward_sizes))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_batch_shaping_under_the_distributed_driver():
+    """Batch shaping + source sharding together (what an N > 1 GPU run of calculate_similarities does): every rank re-cuts ITS OWN stream of batches
+    (batch 8 -> forwards of 6 + the carried leftovers), rank 0 still receives exactly the single-process, un-shaped result in source order."""
+    from radzero_amd.inference import calculate_similarities
+    world, n_images, batch, target = 2, 45, 8, 6
+    g = torch.Generator().manual_seed(1)
+    enc = {"input_ids": torch.randint(4, 30000, (5, 7), generator=g), "attention_mask": torch.ones(5, 7, dtype=torch.long)}
+    want = calculate_similarities(_batches(n_images, batch), {"encoded_key_phrases": enc}, _FakeModel())
+    shaped_single = calculate_similarities(_batches(n_images, batch), {"encoded_key_phrases": enc}, _ShapedModel(target))
+    assert np.array_equal(shaped_single, want)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_shaped_driver_worker, args=(r, world, port, n_images, batch, target, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=180) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert np.array_equal(np.array(res[0][1], np.float32), want) and res[1][1] is None
+    # rank 0 owns batches 0, 2, 4 (8 + 8 + 8 images) -> 6, 6, 6 as views and the 6 carried; rank 1 batches 1, 3, 5 (8 + 8 + 5) -> 6, 6, then 9 left
+    assert res[0][2] == [6, 6, 6, 6] and res[1][2] == [6, 6, 6, 3]
