@@ -95,7 +95,10 @@ int rz_vision_forward(rz_handle_t h, const float* pixel_values_dev, int batch, i
 /* ---- CxrAlignModel.forward_text_model, MPNet branch (modeling.py:128-156): encoder + masked mean pool ----
  * input_ids_dev / attention_mask_dev: int64 (n_prompts, len).  rel_bias_dev: fp32 (heads, len, len) =
  * relative_attention_bias[bucket(j - i)] (MPNetEncoder.compute_position_bias, computed once by the host).
- * text_features_out_dev: fp32 (n_prompts, hidden) = "text_features_wo_l2_norm". */
+ * text_features_out_dev: fp32 (n_prompts, hidden) = "text_features_wo_l2_norm".
+ * fp32 mode (round 6): the GEMMs run on the three-plane f16 form (option "gemm_f32_split"; 2.5e-5 from the exact kernels' result) with a predicated
+ * overflow guard of their own ("f32_split_guard": a prompt encode never trips the vision forward's guard, its repeats are counted into the same
+ * "f32_split_guard_reruns"). */
 int rz_text_forward(rz_handle_t h, const int64_t* input_ids_dev, const int64_t* attention_mask_dev, int n_prompts,
                     int len, const float* rel_bias_dev, float* text_features_out_dev, void* stream);
 
@@ -190,8 +193,8 @@ int rz_flash_attention(int dtype, const void* q_dev, const void* k_dev, const vo
 size_t rz_flash_attention_split_workspace(int batch, int heads, int n_pad);
 int rz_flash_attention_f32_split(const float* q_dev, const float* k_dev, const float* v_t_dev, float* ctx_dev, void* workspace_dev,
                                  int batch, int heads, int n_valid, int n_pad, void* stream);
-/* the same with the two correction terms of every product as ONE block-scaled e4m3 MFMA (the "MX" form the fp32 mode runs for large
- * batches, option "gemm_f32_mx"): hi f16 planes + e4m3 pair planes are built in the same workspace */
+/* the same with the two correction terms of every product as ONE block-scaled e4m3 MFMA (the "MX" form the fp32 mode runs wherever
+ * a launch's rows are a multiple of 256, option "gemm_f32_mx"): hi f16 planes + e4m3 pair planes are built in the same workspace */
 int rz_flash_attention_f32_mx(const float* q_dev, const float* k_dev, const float* v_t_dev, float* ctx_dev, void* workspace_dev,
                               int batch, int heads, int n_valid, int n_pad, void* stream);
 
