@@ -97,8 +97,8 @@ int rz_vision_forward(rz_handle_t h, const float* pixel_values_dev, int batch, i
  * relative_attention_bias[bucket(j - i)] (MPNetEncoder.compute_position_bias, computed once by the host).
  * text_features_out_dev: fp32 (n_prompts, hidden) = "text_features_wo_l2_norm".
  * fp32 mode (round 6): the GEMMs run on the three-plane f16 form (option "gemm_f32_split"; 2.5e-5 from the exact kernels' result) with a predicated
- * overflow guard of their own ("f32_split_guard": a prompt encode never trips the vision forward's guard, its repeats are counted into the same
- * "f32_split_guard_reruns"). */
+ * overflow guard of their own (option "f32_split_guard": a prompt encode never trips the vision forward's guard; its repeats are counted into the
+ * same re-run counter that rz_get_model_option reports). */
 int rz_text_forward(rz_handle_t h, const int64_t* input_ids_dev, const int64_t* attention_mask_dev, int n_prompts,
                     int len, const float* rel_bias_dev, float* text_features_out_dev, void* stream);
 
