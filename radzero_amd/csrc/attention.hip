@@ -305,7 +305,11 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : ((QT == 4 || sizeof(T) == 4)
                 for (int kt = 0; kt < 4; ++kt) sacc[qt][kt] -= mx[qt];
             }
         } else if constexpr (TRACK) {
-        if (__builtin_expect(__any((QT == 4 ? fmaxf(fmaxf(mx[0], mx[1]), fmaxf(mx[QT - 2], mx[QT - 1])) : fmaxf(mx[0], mx[1])) > FA_DEFER), 0)) {
+        float mtop;
+        if constexpr (QT == 4) mtop = fmaxf(fmaxf(mx[0], mx[1]), fmaxf(mx[2], mx[3]));
+        else if constexpr (QT == 1) mtop = mx[0];
+        else mtop = fmaxf(mx[0], mx[1]);
+        if (__builtin_expect(__any(mtop > FA_DEFER), 0)) {
             asm volatile("" ::: "memory");   // keeps hipcc from if-converting the rare path into the hot one
 #pragma unroll
             for (int qt = 0; qt < QT; ++qt) {
@@ -1350,6 +1354,10 @@ hipError_t launch_flash_attn_split_planes(const void* q_hi, const void* k_hi, co
 hipError_t launch_flash_attn(int dtype, const void* q, const void* k, const void* vT, void* ctx,
                              int64_t qk_batch_stride, int B, int H, int n_valid, int n_pad, int variant, hipStream_t s, const unsigned* run_if) {
     if (n_pad % FA_QROWS || n_valid <= 0 || n_valid > n_pad || B <= 0 || H <= 0) return hipErrorInvalidValue;
+    // Round 6: 64 query rows per workgroup (16 per wave, QT = 1) where 128-row blocks leave most of the chip idle — one 518^2 image is 132 blocks for 256 CUs,
+    // 768 resident workgroups: twice the workgroups, each row's arithmetic unchanged (same bits unless the bf16 kernel's per-workgroup overflow re-run strikes).
+    // Automatic below 384 blocks of 128 rows; attn_variant 401 / 402 force the 64- / 128-row form (tests, A/B).
+    const bool small_blocks = dtype != DT_F32 && (variant == 401 || (variant != 402 && variant != 417 && (int64_t)B * H * (n_pad / FA_QROWS) * 2 <= 768));
     // `variant` = option attn_variant.  Every 16-bit kernel: 4 waves per workgroup, row sums on the matrix pipe (LS); bf16 without the
     // running maximum in the hot loop (NOMAX), f16 with it.
     //   0 / 4 (default)  32 query rows per wave (128 per workgroup), 3 waves per SIMD
@@ -1407,6 +1415,7 @@ hipError_t launch_flash_attn(int dtype, const void* q, const void* k, const void
             if (!ls) { RZ_FA(bf16_t, 4, 2, false, false, 0, 2); break; }
             if (qt == 4) { if (track) RZ_FA(bf16_t, 4, 4, true, false, 0, 2); else RZ_FA(bf16_t, 4, 4, true, true, 0, 2); break; }
 #endif
+            if (small_blocks) { RZ_FA(bf16_t, 4, 1, true, true, 0, 2); break; }
             if (track) RZ_FA(bf16_t, 4, 2, true, false, 0, 2); else RZ_FA(bf16_t, 4, 2, true, true, 0, 2);
             break;
         case DT_F16:
@@ -1416,6 +1425,7 @@ hipError_t launch_flash_attn(int dtype, const void* q, const void* k, const void
             if (!ls) { RZ_FA(f16_t, 4, 2, false, false, 0, 2); break; }
             if (qt == 4) { RZ_FA(f16_t, 4, 4, true, false, 0, 2); break; }
 #endif
+            if (small_blocks) { RZ_FA(f16_t, 4, 1, true, false, 0, 2); break; }
             RZ_FA(f16_t, 4, 2, true, false, 0, 2);
             break;
         default: return hipErrorInvalidValue;

@@ -89,10 +89,11 @@ def _attn_ref(q, k, v):
     return torch.einsum("bhqk,bhkd->bhqd", torch.softmax(s, -1), v)
 
 
-@pytest.fixture(params=[0, 417] + ([64] if EXPERIMENTS else []), ids=["default", "trackedMax"] + (["rows64"] if EXPERIMENTS else []))
+@pytest.fixture(params=[0, 417, 401, 402] + ([64] if EXPERIMENTS else []), ids=["default", "trackedMax", "qblock64", "qblock128"] + (["rows64"] if EXPERIMENTS else []))
 def attn_variant(request, lib):
     """Every selectable shape of the flash-attention kernel must pass every attention test: 0 = the default (32 query rows per wave; for
-    bf16 no running maximum in the hot loop + overflow check), 417 = the default shape with the running maximum tracked in every tile.
+    bf16 no running maximum in the hot loop + overflow check; round 6: 16 rows per wave = 64-row workgroups below 384 blocks of 128 rows),
+    417 = the 128-row shape with the running maximum tracked in every tile, 401 / 402 = the 64- / 128-row workgroup forced.
     The retired shapes (64 query rows per wave, VALU row sums, 8 waves, three resident tiles) live behind -DRZ_EXPERIMENTS: 64 is tested
     when the suite runs against that library (RZ_EXPERIMENTS=1)."""
     lib.rz_set_option(b"attn_variant", request.param)
@@ -129,6 +130,36 @@ def test_flash_attention(lib, dt, case, attn_variant):
     err = (got - ref).abs().max().item()
     tol = {"f32": 2e-5, "bf16": 2.5e-2, "f16": 3e-3}[dt]
     assert err <= tol, (dt, case, err)
+
+
+@pytest.mark.parametrize("dt", ["bf16", "f16"])
+@pytest.mark.parametrize("case", [(1, 12, 1370), (2, 12, 257), (1, 3, 5330)])
+def test_flash_attention_query_block_forms_are_bit_identical(lib, dt, case):
+    """Round 6: the 64-row workgroup (16 query rows per wave: small grids — one 518^2 image is 132 blocks of 128 rows for 256 CUs) computes every row
+    exactly as the 128-row one does: same key-tile order, same MFMAs per row -> torch.equal on random data (the bf16 kernel's per-WORKGROUP overflow
+    re-run is the one place where a row's path could depend on its neighbours; it needs scores ~100 binades apart)."""
+    code, tdt = DT[dt]
+    B, H, n = case
+    npad = (n + 127) // 128 * 128
+    g = torch.Generator(device="cpu").manual_seed(7 * n + H)
+    q = torch.zeros(B, H, npad, 64); k = torch.zeros(B, H, npad, 64); v = torch.zeros(B, H, npad, 64)
+    q[:, :, :n] = torch.randn(B, H, n, 64, generator=g) * 0.65
+    k[:, :, :n] = torch.randn(B, H, n, 64, generator=g)
+    v[:, :, :n] = torch.randn(B, H, n, 64, generator=g)
+    qd, kd = q.to(tdt).cuda(), k.to(tdt).cuda()
+    vtd = v.to(tdt).transpose(2, 3).contiguous().cuda()
+    outs = []
+    try:
+        for variant in (401, 402, 0):
+            lib.rz_set_option(b"attn_variant", variant)
+            ctx = torch.full((B * npad, H * 64), float("nan"), dtype=tdt, device="cuda")
+            check(lib, lib.rz_flash_attention(code, P(qd), P(kd), P(vtd), P(ctx), B, H, n, npad, stream()))
+            torch.cuda.synchronize()
+            outs.append(ctx.view(B, npad, H * 64)[:, :n].clone())
+    finally:
+        lib.rz_set_option(b"attn_variant", 0)
+    assert torch.isfinite(outs[0].float()).all()
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[2], outs[0])
 
 
 @pytest.mark.parametrize("npad", [384, 512], ids=["rows32shape", "rows64shape"])
