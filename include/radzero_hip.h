@@ -247,7 +247,7 @@ int rz_gemm_f32_split(int form, const float* a_dev, const float* w_dev, const fl
  *                      inside the step, compiled into the RZ_EXPERIMENTS tools library only — the product library runs 8 for them
  *   "gemm_v1_only"     (process-wide only) 1 = same as gemm_variant 1
  *   "attn_variant"     0 default (16x16x32 MFMA, 4 waves x 32 query rows, row sums on the matrix pipe; bf16 without the running
- *                      maximum in the hot loop; round 6: 4 waves x 16 query rows — 64-row workgroups, same bits per row — where the grid
+ *                      maximum in the hot loop; round 6, bf16: 4 waves x 16 query rows — 64-row workgroups, same bits per row — where the grid
  *                      has fewer than 384 blocks of 128 rows, e.g. one 518^2 image) | 417 = the 128-row shape with the running maximum
  *                      tracked in every tile (what f16 always runs) | 401 / 402 = the 64- / 128-row workgroup forced (tests, A/B).
  *                      Other values run the default (the retired shapes live in the RZ_EXPERIMENTS tools library)

@@ -1355,9 +1355,11 @@ hipError_t launch_flash_attn(int dtype, const void* q, const void* k, const void
                              int64_t qk_batch_stride, int B, int H, int n_valid, int n_pad, int variant, hipStream_t s, const unsigned* run_if) {
     if (n_pad % FA_QROWS || n_valid <= 0 || n_valid > n_pad || B <= 0 || H <= 0) return hipErrorInvalidValue;
     // Round 6: 64 query rows per workgroup (16 per wave, QT = 1) where 128-row blocks leave most of the chip idle — one 518^2 image is 132 blocks for 256 CUs,
-    // 768 resident workgroups: twice the workgroups, each row's arithmetic unchanged (same bits unless the bf16 kernel's per-workgroup overflow re-run strikes).
-    // Automatic below 384 blocks of 128 rows; attn_variant 401 / 402 force the 64- / 128-row form (tests, A/B).
-    const bool small_blocks = dtype != DT_F32 && (variant == 401 || (variant != 402 && variant != 417 && (int64_t)B * H * (n_pad / FA_QROWS) * 2 <= 768));
+    // 768 resident workgroups: twice the workgroups.  Automatic for bf16 only, below 384 blocks of 128 rows: its hot loop keeps no running maximum, so a row's
+    // arithmetic does not depend on which rows share its wave — bit-identical to the 128-row form (unless the per-workgroup overflow re-run strikes); the f16
+    // kernel re-centres per WAVE (a wave-uniform branch on any of its rows), so its bits would depend on the form and with it on the batch.
+    // attn_variant 401 / 402 force the 64- / 128-row form (tests, A/B; 401 also for f16: numerically equivalent, not bitwise).
+    const bool small_blocks = dtype != DT_F32 && (variant == 401 || (dtype == DT_BF16 && variant != 402 && variant != 417 && (int64_t)B * H * (n_pad / FA_QROWS) * 2 <= 768));
     // `variant` = option attn_variant.  Every 16-bit kernel: 4 waves per workgroup, row sums on the matrix pipe (LS); bf16 without the
     // running maximum in the hot loop (NOMAX), f16 with it.
     //   0 / 4 (default)  32 query rows per wave (128 per workgroup), 3 waves per SIMD

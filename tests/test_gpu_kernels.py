@@ -136,8 +136,10 @@ def test_flash_attention(lib, dt, case, attn_variant):
 @pytest.mark.parametrize("case", [(1, 12, 1370), (2, 12, 257), (1, 3, 5330)])
 def test_flash_attention_query_block_forms_are_bit_identical(lib, dt, case):
     """Round 6: the 64-row workgroup (16 query rows per wave: small grids — one 518^2 image is 132 blocks of 128 rows for 256 CUs) computes every row
-    exactly as the 128-row one does: same key-tile order, same MFMAs per row -> torch.equal on random data (the bf16 kernel's per-WORKGROUP overflow
-    re-run is the one place where a row's path could depend on its neighbours; it needs scores ~100 binades apart)."""
+    exactly as the 128-row one does in bf16: same key-tile order, same MFMAs per row, no running maximum in the hot loop -> torch.equal on random data
+    (the per-WORKGROUP overflow re-run is the one place where a row's path could depend on its neighbours; it needs scores ~100 binades apart).  The f16
+    kernel re-centres per wave, so its two forms agree numerically but not bitwise: the automatic choice never takes the 64-row form for f16 (batch
+    independence of the f16 mode's bits), and that is asserted here too."""
     code, tdt = DT[dt]
     B, H, n = case
     npad = (n + 127) // 128 * 128
@@ -159,7 +161,11 @@ def test_flash_attention_query_block_forms_are_bit_identical(lib, dt, case):
     finally:
         lib.rz_set_option(b"attn_variant", 0)
     assert torch.isfinite(outs[0].float()).all()
-    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[2], outs[0])
+    if dt == "bf16":
+        assert torch.equal(outs[0], outs[1]) and torch.equal(outs[2], outs[0])
+    else:
+        assert torch.equal(outs[2], outs[1])                                   # automatic = the 128-row form, whatever the grid size
+        assert (outs[0].float() - outs[1].float()).abs().max().item() <= 3e-3    # the forced 64-row form: same numbers up to f16 rounding of re-centred sums
 
 
 @pytest.mark.parametrize("npad", [384, 512], ids=["rows32shape", "rows64shape"])
