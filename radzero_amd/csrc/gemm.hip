@@ -27,25 +27,9 @@ namespace rz {
 // [K f16 | K / 64 pair blocks of 128 bytes], g.K = 2 K counts 128-byte panels x 64; the first half of the panels runs the f16 MFMAs (a_hi b_hi), the
 // second half ONE block-scaled e4m3 MFMA per accumulator tile (both correction terms), its 32-byte operands = the two 16-byte fragments of the panel.
 // Same products, same order as the 256 x 256 kernels: bit-identical to them (tests/test_gpu_model.py forced-variant checks).
-// Ring of SMALL_STAGES panel pairs in LDS (round 6; rounds 1-5: two).  This kernel runs where grids are small (one image, the text encoder: 6 .. 300 workgroups),
-// i.e. where nothing hides latency but the workgroup itself: with two stages ONE panel pair was in flight and every K panel cost a full global -> LDS round trip
-// (0.92 us per panel: fc2 of one 518^2 image = 48 panels = 51 us on 72 workgroups; every text-encoder GEMM = 12 panels = 10.8 us).  Four stages keep three pairs
-// in flight behind a counted vmcnt; 128 KB of LDS = one workgroup per CU, which is what these grids give a CU anyway.  Same products in the same order: same bits.
-#ifndef RZ_SMALL_STAGES
-#define RZ_SMALL_STAGES 4
-#endif
-constexpr int SMALL_STAGES = RZ_SMALL_STAGES;
-static_assert(SMALL_STAGES == 2 || SMALL_STAGES == 4, "ring depth: a power of two, and 8 x (SMALL_STAGES - 2) must fit vmcnt's 6 bits");
-// all but the youngest `panels` panel pairs of this wave's LDS-DMA (8 instructions per pair) have landed
-__device__ __forceinline__ void small_wait_panels(int panels) {
-    if (panels <= 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    else if (panels == 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-}
-
 template <typename T, int EPI, typename OT = T, bool MXK = false>
 __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs g) {
-    __shared__ __attribute__((aligned(1024))) char lds[2 * SMALL_STAGES * PANEL_BYTES];  // A0 .. A(S-1) B0 .. B(S-1)
+    __shared__ __attribute__((aligned(1024))) char lds[4 * PANEL_BYTES];  // A0 A1 B0 B1
     if constexpr (sizeof(T) == 4) {      // exact-fp32 instantiations: predicated launch (fp32 mode's overflow guard, rz_kernels.h GemmArgs::run_if)
         if (g.run_if && *g.run_if == 0) return;
     }
@@ -73,7 +57,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs g) {
 
     auto stage = [&](int kt, int buf) {
         char* sa = lds + buf * PANEL_BYTES;
-        char* sb = lds + (SMALL_STAGES + buf) * PANEL_BYTES;
+        char* sb = lds + (2 + buf) * PANEL_BYTES;
         const char* ga = Ab + (int64_t)kt * 128;
         const char* gb = Wb + (int64_t)kt * 128;
 #pragma unroll
@@ -90,21 +74,15 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs g) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    // prologue: panels 0 .. S-2 requested, panel 0 waited for
-#pragma unroll
-    for (int p = 0; p < SMALL_STAGES - 1; ++p)
-        if (p < nk) stage(p, p);
-    small_wait_panels(min(nk, SMALL_STAGES - 1) - 1);
+    stage(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
     for (int kt = 0; kt < nk; ++kt) {
-        const int buf = kt & (SMALL_STAGES - 1);
-        // panel kt + S - 1 goes into the buffer iteration kt - 1 consumed (every wave is past that iteration's closing barrier)
-        if (kt + SMALL_STAGES - 1 < nk) stage(kt + SMALL_STAGES - 1, (kt + SMALL_STAGES - 1) & (SMALL_STAGES - 1));
-        // panel kt + 1 must have landed before the next iteration: the pairs requested after it may stay in flight
-        const int younger = min(nk - 1, kt + SMALL_STAGES - 1) - (kt + 1);
+        const int buf = kt & 1;
+        if (kt + 1 < nk) stage(kt + 1, buf ^ 1);
         const char* sa = lds + buf * PANEL_BYTES;
-        const char* sb = lds + (SMALL_STAGES + buf) * PANEL_BYTES;
+        const char* sb = lds + (2 + buf) * PANEL_BYTES;
         // fragments of k-step ks+1 are requested before the 16 MFMAs of k-step ks (register double buffer),
         // so only the first LDS round trip of a K panel is exposed
         frag_t fa[2][4], fb[2][4];
@@ -130,7 +108,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs g) {
                             else acc[i][j] = mma_mx(fa[0][i], fa[1][i], fb[0][j], fb[1][j], acc[i][j], sa_mx, sw_mx);
                         }
                 }
-                small_wait_panels(younger);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __syncthreads();
                 continue;
             }
@@ -153,7 +131,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs g) {
                     else acc[i][j] = mma(fa[ks & 1][i], fb[ks & 1][j], acc[i][j]);        // D[row=m][col=n]
                 }
         }
-        small_wait_panels(younger);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
     }
 
