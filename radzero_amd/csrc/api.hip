@@ -43,12 +43,13 @@ struct Options {
     int attn_f32_mx;      // fp32 mode, with the MX GEMM form: 1 (default) = the attention's P V correction terms as block-scaled fp8 MFMAs, scores at 22 bits; 2 = scores too; 0 = f16 planes
     int gemm_raster;      // gemm12.hip: tile order inside an XCD (GemmArgs::raster): 0 = 4 x tiles_n groups | S > 0 = slab walk, <= S n tiles per slab
     int attn_f32_pv;      // fp32 mode: 1 = the attention's P V product on the hi planes alone (f16 P and V, row sums of the rounded P on the matrix pipe); 0 = with its correction terms ("f32_precision high")
+    int gemm_small_tile;  // 128x128-kernel family's tile (GemmArgs::small_tile): 0 = by grid size | 1 128 x 128 | 2 64 x 64 | 3 128 x 64
     int f32_drop;         // fp32 mode, ACCURACY ABLATION (tools/fp32_term_ablation.py; three-plane form): bit mask of product classes computed hi . hi only — 1 q|k projection, 2 V projection, 4 out-projection, 8 fc1, 16 fc2, 32 patch embedding; tools build also: 64 scores, 128 P (V keeps hi + lo)
 };
-Options g_opt = {0, 1, 0, 0, 0, 1, 1, 1, 0, 0, 1, 1, 1, 0, 0, 0};
+Options g_opt = {0, 1, 0, 0, 0, 1, 1, 1, 0, 0, 1, 1, 1, 0, 0, 0, 0};
 const Options kInherit = {RZ_OPT_INHERIT, RZ_OPT_INHERIT, RZ_OPT_INHERIT, RZ_OPT_INHERIT, RZ_OPT_INHERIT, RZ_OPT_INHERIT, RZ_OPT_INHERIT,
                           RZ_OPT_INHERIT, RZ_OPT_INHERIT, RZ_OPT_INHERIT, RZ_OPT_INHERIT, RZ_OPT_INHERIT, RZ_OPT_INHERIT, RZ_OPT_INHERIT,
-                          RZ_OPT_INHERIT, RZ_OPT_INHERIT};
+                          RZ_OPT_INHERIT, RZ_OPT_INHERIT, RZ_OPT_INHERIT};
 int* option_field(Options& o, const char* name) {
 #ifdef RZ_EXPERIMENTS      // measured, never a gain (profiles/NOTEBOOK.md): known to the tools build only; the product runs one pass, one stream
     if (!strcmp(name, "vision_chunk")) return &o.vision_chunk;
@@ -58,6 +59,7 @@ int* option_field(Options& o, const char* name) {
 #endif
     if (!strcmp(name, "attn_variant")) return &o.attn_variant;
     if (!strcmp(name, "gemm_variant")) return &o.gemm_variant;
+    if (!strcmp(name, "gemm_small_tile")) return &o.gemm_small_tile;
     if (!strcmp(name, "gemm_f32_split")) return &o.gemm_f32_split;
     if (!strcmp(name, "attn_f32_split")) return &o.attn_f32_split;
     if (!strcmp(name, "ln_fused")) return &o.ln_fused;
@@ -175,6 +177,7 @@ struct rz_model {
 #endif
     int o_attn_variant() const { return pick(opt.attn_variant, g_opt.attn_variant); }
     int o_gemm_variant() const { return pick(opt.gemm_variant, g_opt.gemm_variant); }
+    int o_gemm_small_tile() const { return pick(opt.gemm_small_tile, g_opt.gemm_small_tile); }
     int o_gemm_raster() const { return pick(opt.gemm_raster, g_opt.gemm_raster); }
     int o_gemm_f32_mx() const { return pick(opt.gemm_f32_mx, g_opt.gemm_f32_mx); }
     int o_attn_f32_mx() const { return pick(opt.attn_f32_mx, g_opt.attn_f32_mx); }
@@ -472,7 +475,7 @@ int gemm_f32_split(rz_model* m, int epi, GemmArgs g, int a_mode, bool out_split,
         const int out_kind = (epi == EPI_RESID_SCALE || epi == EPI_PATCH) ? 0 : epi == EPI_GELU ? 2 :
                              ((epi == EPI_VT && (mx & 2)) || (epi == EPI_HEADS && (mx & 4))) ? 3 : 1;       // 3: hi f16 + e4m3 pair planes (MX attention)
         if ((out_kind != 0) != out_split) return fail(RZ_ERR_STATE, "MX GEMM: output form mismatch");
-        g.variant = m->o_gemm_variant();
+        g.variant = m->o_gemm_variant(); g.small_tile = m->o_gemm_small_tile();
         // which kernel: 0 auto — the 128 x 128 kernel where the 16-bit kernels' cost model prefers small tiles (round 6: one 1024^2 image is 63 big tiles for
         // an N = 768 GEMM on 256 CUs), else the persistent loop; 1 / 7 / 8 force the 128 x 128 / one-tile-per-workgroup / persistent kernel (same bits)
         const bool small_ok = gemm_small_mx_ok(epi, out_kind, g);
@@ -530,7 +533,7 @@ int gemm(rz_model* m, int epi, const void* A, int64_t lda, const void* W, int64_
     GemmArgs g;
     g.A = A; g.lda = lda; g.W = W; g.ldw = ldw; g.M = M; g.N = N; g.K = K; g.bias = bias; g.out = out; g.ldo = ldo;
     g.scale = scale; g.resid = resid; g.ldr = ldr; g.rows_per_image = rpi; g.heads_total = heads; g.plane_off = plane_off;
-    g.variant = m->o_gemm_variant(); g.raster = m->o_gemm_raster(); g.ovf_flag = (unsigned*)m->ovf.p; g.run_if = m->run_if;
+    g.variant = m->o_gemm_variant(); g.small_tile = m->o_gemm_small_tile(); g.raster = m->o_gemm_raster(); g.ovf_flag = (unsigned*)m->ovf.p; g.run_if = m->run_if;
     ProfScope ps(m, RZ_PROF_GEMM, s);
     if (m->dt == RZ_F32 && m->o_gemm_f32_split()) {
         bool done = false;
@@ -590,7 +593,7 @@ int gemm_ln(rz_model* m, int epi, const void* hb, const Tensor& wf, const Tensor
     GemmArgs g;
     g.A = hb; g.lda = m->D; g.W = wf.p; g.ldw = m->D; g.M = M; g.N = N; g.K = m->D; g.bias = (const float*)c2.p; g.out = out; g.ldo = ldo;
     g.scale = (const float*)c1.p; g.resid = nullptr; g.ldr = 0; g.rows_per_image = np; g.heads_total = heads;
-    g.out2 = out2; g.heads_total2 = heads2; g.split_n = split_n; g.ln_stat = stat; g.variant = m->o_gemm_variant(); g.raster = m->o_gemm_raster();
+    g.out2 = out2; g.heads_total2 = heads2; g.split_n = split_n; g.ln_stat = stat; g.variant = m->o_gemm_variant(); g.small_tile = m->o_gemm_small_tile(); g.raster = m->o_gemm_raster();
     ProfScope ps(m, RZ_PROF_GEMM, s);
     RZ_HIP(launch_gemm(m->dt, epi, g, s));
     return 0;
@@ -603,7 +606,7 @@ int gemm_resid_ln(rz_model* m, const void* A, int64_t lda, const Tensor& W, cons
     GemmArgs g;
     g.A = A; g.lda = lda; g.W = W.p; g.ldw = K; g.M = M; g.N = m->D; g.K = K; g.bias = (const float*)bias.p; g.out = nullptr; g.ldo = 0;
     g.scale = (const float*)ls.p; g.resid = h; g.ldr = m->D; g.rows_per_image = np; g.heads_total = 0; g.ln_part = part; g.ln_hb = hb; g.ln_gamma = (const float*)next_gamma.p; g.ln_mu = mu;
-    g.variant = m->o_gemm_variant(); g.raster = m->o_gemm_raster();
+    g.variant = m->o_gemm_variant(); g.small_tile = m->o_gemm_small_tile(); g.raster = m->o_gemm_raster();
     {
         ProfScope ps(m, RZ_PROF_GEMM, s);
         RZ_HIP(launch_gemm(m->dt, EPI_RESID_SCALE_LN, g, s));
@@ -618,7 +621,7 @@ int gemm_qkv(rz_model* m, const void* xn, const DinoBlock& b, int M, int np, voi
     GemmArgs g;
     g.A = xn; g.lda = D; g.W = b.wqkv.p; g.ldw = D; g.M = M; g.N = 3 * D; g.K = D; g.bias = (const float*)b.bqkv.p;
     g.out = qk; g.ldo = 0; g.scale = nullptr; g.resid = nullptr; g.ldr = 0; g.rows_per_image = np; g.heads_total = 2 * H;
-    g.out2 = vt; g.heads_total2 = H; g.split_n = 2 * D; g.variant = m->o_gemm_variant(); g.raster = m->o_gemm_raster();
+    g.out2 = vt; g.heads_total2 = H; g.split_n = 2 * D; g.variant = m->o_gemm_variant(); g.small_tile = m->o_gemm_small_tile(); g.raster = m->o_gemm_raster();
     if (gemm_qkv_fused_ok(m->dt, g)) {
         ProfScope ps(m, RZ_PROF_GEMM, s);
         RZ_HIP(launch_gemm(m->dt, EPI_QKV, g, s));
@@ -1021,7 +1024,7 @@ static int vision_forward_once(rz_handle_t m, const float* px, int B, int C, int
             g.A = mid; g.lda = m->KPAD; g.W = m->patch_w.p; g.ldw = m->KPAD; g.M = M; g.N = D; g.K = m->KPAD; g.bias = nullptr; g.out = h; g.ldo = D;
             g.scale = (const float*)it->second.buf.p; g.resid = nullptr; g.ldr = 0; g.rows_per_image = np; g.heads_total = 0;
             g.ln_part = part; g.ln_hb = xn; g.ln_gamma = (const float*)m->blocks[0].ln1_g.p;
-            g.variant = m->o_gemm_variant(); g.raster = m->o_gemm_raster();
+            g.variant = m->o_gemm_variant(); g.small_tile = m->o_gemm_small_tile(); g.raster = m->o_gemm_raster();
             if (gemm_patch_ln_ok(m->dt, g)) {
                 patch_ln = true;
                 {
@@ -1073,7 +1076,7 @@ static int vision_forward_once(rz_handle_t m, const float* px, int B, int C, int
                 if ((rc = gemm_qkv(m, xn, b, M, np, qkb, vtb, s))) return rc;
             } else {
                 GemmArgs probe;
-                probe.A = xn; probe.lda = D; probe.W = b.wqkv.p; probe.ldw = D; probe.M = M; probe.N = 3 * D; probe.K = D; probe.out2 = vtb; probe.split_n = 2 * D; probe.variant = m->o_gemm_variant(); probe.raster = m->o_gemm_raster();
+                probe.A = xn; probe.lda = D; probe.W = b.wqkv.p; probe.ldw = D; probe.M = M; probe.N = 3 * D; probe.K = D; probe.out2 = vtb; probe.split_n = 2 * D; probe.variant = m->o_gemm_variant(); probe.small_tile = m->o_gemm_small_tile(); probe.raster = m->o_gemm_raster();
                 if (gemm_qkv_fused_ok(m->dt, probe)) {
                     if ((rc = gemm_ln(m, EPI_QKV_LN, xn, b.wqkv, b.c1qkv, b.c2qkv, stat, M, 3 * D, np, qkb, 0, 2 * H, vtb, H, 2 * D, s))) return rc;
                 } else {        // small batches: the same projection as q|k and v launches of the 128x128 kernel
@@ -1209,7 +1212,7 @@ static int text_forward_once(rz_handle_t m, const int64_t* ids, const int64_t* m
         auto tg = [&](int epi, const void* A, const Tensor& W, int N, int K, const Tensor& bias, void* out, int64_t ldo, float* resid, bool out_split) {
             GemmArgs g;
             g.A = A; g.lda = K; g.W = W.p; g.ldw = K; g.M = Mp; g.N = N; g.K = K; g.bias = (const float*)bias.p; g.out = out; g.ldo = ldo;
-            g.scale = nullptr; g.resid = resid; g.ldr = D; g.rows_per_image = Mp; g.heads_total = 0; g.variant = m->o_gemm_variant(); g.raster = m->o_gemm_raster();
+            g.scale = nullptr; g.resid = resid; g.ldr = D; g.rows_per_image = Mp; g.heads_total = 0; g.variant = m->o_gemm_variant(); g.small_tile = m->o_gemm_small_tile(); g.raster = m->o_gemm_raster();
             return gemm_text_split(m, epi, g, s, out_split);
         };
         for (const TextLayer& l : m->tlayers) {
@@ -1423,7 +1426,7 @@ int rz_gemm(int dtype, int epilogue, const void* a, const void* w, const float* 
     memset(&g, 0, sizeof g);
     g.A = a; g.lda = K; g.W = w; g.ldw = K; g.M = M; g.N = N; g.K = K; g.bias = bias; g.out = out; g.ldo = N;
     g.rows_per_image = M;
-    g.variant = g_opt.gemm_variant; g.raster = g_opt.gemm_raster;
+    g.variant = g_opt.gemm_variant; g.small_tile = g_opt.gemm_small_tile; g.raster = g_opt.gemm_raster;
     RZ_HIP(launch_gemm(dtype, epilogue, g, (hipStream_t)stream));
     return 0;
 }
@@ -1441,7 +1444,7 @@ int rz_gemm_ex(int dtype, int epilogue, const void* a, int64_t lda, const void* 
     GemmArgs g;
     g.A = a; g.lda = lda; g.W = w; g.ldw = ldw; g.M = M; g.N = N; g.K = K; g.bias = bias; g.out = out; g.ldo = ldo;
     g.scale = scale; g.resid = resid; g.ldr = ldr; g.rows_per_image = rows_per_image > 0 ? rows_per_image : M; g.heads_total = heads_total;
-    g.variant = g_opt.gemm_variant; g.raster = g_opt.gemm_raster;
+    g.variant = g_opt.gemm_variant; g.small_tile = g_opt.gemm_small_tile; g.raster = g_opt.gemm_raster;
     RZ_HIP(launch_gemm(dtype, epilogue, g, (hipStream_t)stream));
     return 0;
 }
@@ -1479,7 +1482,7 @@ int rz_gemm_qkv(int dtype, const void* x, const void* w, const float* bias, void
     GemmArgs g;
     g.A = x; g.lda = D; g.W = w; g.ldw = D; g.M = M; g.N = 3 * D; g.K = D; g.bias = bias; g.out = qk; g.ldo = 0;
     g.scale = nullptr; g.resid = nullptr; g.ldr = 0; g.rows_per_image = rows_per_image; g.heads_total = 2 * heads;
-    g.out2 = vt; g.heads_total2 = heads; g.split_n = 2 * D; g.variant = g_opt.gemm_variant; g.raster = g_opt.gemm_raster;
+    g.out2 = vt; g.heads_total2 = heads; g.split_n = 2 * D; g.variant = g_opt.gemm_variant; g.small_tile = g_opt.gemm_small_tile; g.raster = g_opt.gemm_raster;
     const bool fused = gemm_qkv_fused_ok(dtype, g);
     if (fused_out) *fused_out = fused ? 1 : 0;
     if (fused) {
@@ -1575,7 +1578,7 @@ int rz_patch_embed(int dtype, const float* px, int B, int C, int Himg, int Wimg,
     RZ_HIP(launch_im2col(dtype, px, ws, B, C, Himg, Wimg, P, gh, gw, n_pad, k_pad, s));
     GemmArgs g;
     g.A = ws; g.lda = k_pad; g.W = weight; g.ldw = k_pad; g.M = B * n_pad; g.N = 768; g.K = k_pad; g.bias = nullptr; g.out = out; g.ldo = 768;
-    g.scale = table; g.resid = nullptr; g.ldr = 0; g.rows_per_image = n_pad; g.heads_total = 0; g.variant = g_opt.gemm_variant; g.raster = g_opt.gemm_raster;
+    g.scale = table; g.resid = nullptr; g.ldr = 0; g.rows_per_image = n_pad; g.heads_total = 0; g.variant = g_opt.gemm_variant; g.small_tile = g_opt.gemm_small_tile; g.raster = g_opt.gemm_raster;
     RZ_HIP(launch_gemm(dtype, EPI_PATCH, g, s));
     return 0;
 }

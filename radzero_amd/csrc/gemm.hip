@@ -27,9 +27,13 @@ namespace rz {
 // [K f16 | K / 64 pair blocks of 128 bytes], g.K = 2 K counts 128-byte panels x 64; the first half of the panels runs the f16 MFMAs (a_hi b_hi), the
 // second half ONE block-scaled e4m3 MFMA per accumulator tile (both correction terms), its 32-byte operands = the two 16-byte fragments of the panel.
 // Same products, same order as the 256 x 256 kernels: bit-identical to them (tests/test_gpu_model.py forced-variant checks).
-template <typename T, int EPI, typename OT = T, bool MXK = false>
-__global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs g) {
-    __shared__ __attribute__((aligned(1024))) char lds[4 * PANEL_BYTES];  // A0 A1 B0 B1
+// WM x WN = waves along m / n (64 x 64 outputs each): 2 x 2 is the 128 x 128 tile; the smaller geometries spread a GEMM of few tiles over more CUs
+// (one CU's LDS-DMA stream moves ~45 GB/s whatever the ring depth — profiles/r06/small_kernel_ring_depth_ab.txt — so a grid that leaves CUs idle is
+// bound by bytes per ACTIVE CU).  Same K order and accumulator ownership in every geometry: bit-identical outputs.
+template <typename T, int EPI, typename OT = T, bool MXK = false, int WM = 2, int WN = 2>
+__global__ __launch_bounds__(64 * WM * WN, 2) void gemm_kernel(GemmArgs g) {
+    constexpr int TBM = 64 * WM, TBN = 64 * WN, PA = TBM * 128, PB = TBN * 128;
+    __shared__ __attribute__((aligned(1024))) char lds[2 * PA + 2 * PB];  // A0 A1 B0 B1
     if constexpr (sizeof(T) == 4) {      // exact-fp32 instantiations: predicated launch (fp32 mode's overflow guard, rz_kernels.h GemmArgs::run_if)
         if (g.run_if && *g.run_if == 0) return;
     }
@@ -38,14 +42,14 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs g) {
     typedef typename Traits<T>::frag frag_t;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = WN == 2 ? wave >> 1 : wave, wn = WN == 2 ? wave & 1 : 0;
     const int l15 = lane & 15, lg = lane >> 4;
 
-    const int tiles_n = g.N / BN, tiles_m = g.M / BM;
+    const int tiles_n = g.N / TBN, tiles_m = g.M / TBM;
     const int bid = xcd_remap(blockIdx.x, tiles_m * tiles_n);
     int tm, tn;
     tile_coords<8>(bid, tiles_m, tiles_n, tm, tn);
-    const int m0 = tm * BM, n0 = tn * BN;
+    const int m0 = tm * TBM, n0 = tn * TBN;
 
     const char* Ab = reinterpret_cast<const char*>(g.A) + (int64_t)m0 * g.lda * sizeof(T);
     const char* Wb = reinterpret_cast<const char*>(g.W) + (int64_t)n0 * g.ldw * sizeof(T);
@@ -56,14 +60,18 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs g) {
     [[maybe_unused]] const int nkh = MXK ? nk / 2 : nk;
 
     auto stage = [&](int kt, int buf) {
-        char* sa = lds + buf * PANEL_BYTES;
-        char* sb = lds + (2 + buf) * PANEL_BYTES;
+        char* sa = lds + buf * PA;
+        char* sb = lds + 2 * PA + buf * PB;
         const char* ga = Ab + (int64_t)kt * 128;
         const char* gb = Wb + (int64_t)kt * 128;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int row8 = (wave * 4 + i) * 8;
+        for (int i = 0; i < 8 / WN; ++i) {        // A: 8 WM groups of 8 rows over WM WN waves
+            const int row8 = (wave * (8 / WN) + i) * 8;
             glds_rows8(sa + row8 * 128, ga, lda_b, row8, lane);
+        }
+#pragma unroll
+        for (int i = 0; i < 8 / WM; ++i) {        // W: 8 WN groups
+            const int row8 = (wave * (8 / WM) + i) * 8;
             glds_rows8(sb + row8 * 128, gb, ldw_b, row8, lane);
         }
     };
@@ -81,8 +89,8 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs g) {
     for (int kt = 0; kt < nk; ++kt) {
         const int buf = kt & 1;
         if (kt + 1 < nk) stage(kt + 1, buf ^ 1);
-        const char* sa = lds + buf * PANEL_BYTES;
-        const char* sb = lds + (2 + buf) * PANEL_BYTES;
+        const char* sa = lds + buf * PA;
+        const char* sb = lds + 2 * PA + buf * PB;
         // fragments of k-step ks+1 are requested before the 16 MFMAs of k-step ks (register double buffer),
         // so only the first LDS round trip of a K panel is exposed
         frag_t fa[2][4], fb[2][4];
@@ -300,6 +308,25 @@ bool gemm_ln_fused_ok(int dtype, int M, int D, int F, int variant) {
     return dtype != DT_F32 && (variant == 0 || variant == 1 || persistent_variant(variant)) && M > 0 && M % BM == 0 && D == 768 && F % BN == 0;
 }
 
+// 128 x 128-kernel family: which tile geometry (GemmArgs::small_tile; 0 = by grid size).  Measured in the step, all modes (profiles/r06/small_tile_step_ab.txt,
+// small_tile_step_ab2.txt): below 40 tiles of 128 x 128 (one 224^2 image's N = 768 GEMMs, the text encoder) the one-wave 64 x 64 tile wins (-11 % step time
+// for one 224^2 image); up to ~340 tiles (N = 768 GEMMs of <= five 518^2 / one 1024^2 / sixteen 224^2 images) the two-wave 128 x 64 tile (-2 ... -7 %);
+// from 396 tiles on the smaller tiles LOSE 12-20 % (more operand bytes through each XCD's L2 once every CU already has work).
+static int small_tile_choice(const GemmArgs& g) {
+    if (g.small_tile) return g.small_tile;
+    const int n = (g.M / BM) * (g.N / BN);
+    return n < 40 ? 2 : n <= 340 ? 3 : 1;
+}
+
+template <typename T, int EPI, typename OT>
+static void launch_small(int st, const GemmArgs& g, hipStream_t s) {
+    if constexpr (sizeof(T) == 2) {
+        if (st == 2) { hipLaunchKernelGGL((gemm_kernel<T, EPI, OT, false, 1, 1>), dim3((g.M / 64) * (g.N / 64)), dim3(64), 0, s, g); return; }
+        if (st == 3) { hipLaunchKernelGGL((gemm_kernel<T, EPI, OT, false, 2, 1>), dim3((g.M / 128) * (g.N / 64)), dim3(128), 0, s, g); return; }
+    }
+    hipLaunchKernelGGL((gemm_kernel<T, EPI, OT>), dim3((g.M / BM) * (g.N / BN)), dim3(256), 0, s, g);
+}
+
 template <typename T>
 static hipError_t launch_gemm_t(int epi, const GemmArgs& g, hipStream_t s) {
     const bool ok3 = (g.M % BM2 == 0) && (g.M >= 4 * BM2) && (g.N % BN3 == 0);
@@ -346,13 +373,14 @@ static hipError_t launch_gemm_t(int epi, const GemmArgs& g, hipStream_t s) {
     }
     if (variant != 1 && variant != 3) return hipErrorInvalidValue;
     if (variant == 3 && !ok3) variant = 1;
-    const int ntiles = variant == 3 ? (g.M / BM2) * (g.N / BN3) : (g.M / BM) * (g.N / BN);
-    dim3 grid(ntiles), block(variant == 1 ? 256 : 512);
+    const int ntiles = (g.M / BM2) * (g.N / BN3);
+    dim3 grid(ntiles), block(512);
+    const int st = variant == 1 ? small_tile_choice(g) : 0;
 #define RZ_CASE(E) \
     case E: if (variant == 3) hipLaunchKernelGGL((gemm_kernel_v3<T, E>), grid, block, 0, s, g); \
-            else hipLaunchKernelGGL((gemm_kernel<T, E>), grid, block, 0, s, g); break;
+            else launch_small<T, E, T>(st, g, s); break;
 #define RZ_CASE1(E) case E: if (variant != 1 || sizeof(T) != 2) return hipErrorInvalidValue; \
-                       if constexpr (sizeof(T) == 2) hipLaunchKernelGGL((gemm_kernel<T, E>), grid, block, 0, s, g); break;
+                       if constexpr (sizeof(T) == 2) launch_small<T, E, T>(st, g, s); break;
     switch (epi) {
         RZ_CASE(EPI_STORE)
         RZ_CASE(EPI_GELU)
@@ -384,11 +412,11 @@ hipError_t launch_gemm_split_f32out(int epi, const GemmArgs& g, hipStream_t s, b
     if (g.M <= 0 || g.N <= 0 || g.K <= 0 || g.M % BM || g.N % BN || (g.K * 2) % 128 || (g.lda * 2) % 16 || (g.ldw * 2) % 16) return hipErrorInvalidValue;
     const bool v3 = big_tiles_pay(g, epi);
     if (v3 && (g.variant == 0 || g.variant == 7) && gemm_v7_ok(DT_F16, g)) return launch_gemm_v7_f16_out(epi, g, split_out, s);   // the deeper-pipelined K loop
-    const int ntiles = v3 ? (g.M / BM2) * (g.N / BN3) : (g.M / BM) * (g.N / BN);
-    dim3 grid(ntiles), block(v3 ? 512 : 256);
+    dim3 grid((g.M / BM2) * (g.N / BN3)), block(512);
+    const int st = v3 ? 0 : small_tile_choice(g);
 #define RZ_CASE(E, OT) \
     case E: if (v3) hipLaunchKernelGGL((gemm_kernel_v3<f16_t, E, OT>), grid, block, 0, s, g); \
-            else hipLaunchKernelGGL((gemm_kernel<f16_t, E, OT>), grid, block, 0, s, g); break;
+            else launch_small<f16_t, E, OT>(st, g, s); break;
     if (split_out) {          // outputs leave as hi/lo f16 planes (the next split GEMM's A operand, the split attention's q / k / V^T)
         switch (epi) {
             RZ_CASE(EPI_GELU, split_f16)
@@ -427,8 +455,12 @@ bool gemm_small_mx_pays(int epi, const GemmArgs& g) {
 }
 hipError_t launch_gemm_small_mx(int epi, const GemmArgs& g, int out_kind, hipStream_t s) {
     if (!gemm_small_mx_ok(epi, out_kind, g)) return hipErrorInvalidValue;
-    dim3 grid((g.M / BM) * (g.N / BN)), block(256);
-#define RZ_CASEM(E, OT) case E: hipLaunchKernelGGL((gemm_kernel<f16_t, E, OT, true>), grid, block, 0, s, g); break;
+    const int st = small_tile_choice(g);
+#define RZ_CASEM(E, OT) case E: \
+        if (st == 2) hipLaunchKernelGGL((gemm_kernel<f16_t, E, OT, true, 1, 1>), dim3((g.M / 64) * (g.N / 64)), dim3(64), 0, s, g); \
+        else if (st == 3) hipLaunchKernelGGL((gemm_kernel<f16_t, E, OT, true, 2, 1>), dim3((g.M / 128) * (g.N / 64)), dim3(128), 0, s, g); \
+        else hipLaunchKernelGGL((gemm_kernel<f16_t, E, OT, true>), dim3((g.M / BM) * (g.N / BN)), dim3(256), 0, s, g); \
+        break;
     if (out_kind == 0) {
         switch (epi) { RZ_CASEM(EPI_RESID_SCALE, f16_t) RZ_CASEM(EPI_PATCH, f16_t) default: return hipErrorInvalidValue; }
     } else if (out_kind == 1) {
