@@ -246,9 +246,11 @@ int rz_gemm_f32_split(int form, const float* a_dev, const float* w_dev, const fl
  *                      10 / 11 / 12 (other K loops; two 256x128 workgroups per CU) are retired experiments: bit-identical, never faster
  *                      inside the step, compiled into the RZ_EXPERIMENTS tools library only — the product library runs 8 for them
  *   "gemm_v1_only"     (process-wide only) 1 = same as gemm_variant 1
- *   "gemm_small_tile"  tile of the 128x128 kernel family (variant 1, every mode): 0 (default) = by grid size — 64x64 tiles of one wave below 40
- *                      tiles of 128x128, 128x64 tiles of two waves up to 340, 128x128 above (a small grid is bound by operand bytes per ACTIVE
- *                      CU) | 1 / 2 / 3 = 128x128 / 64x64 / 128x64 forced (tests, A/B).  Same K order in each: bit-identical outputs
+ *   "gemm_small_tile"  the 128x128 kernel family (variant 1, every mode): 0 (default) = by grid size, n = tiles of 128x128 — up to 256 tiles (every
+ *                      workgroup owns a CU) a four-stage LDS ring, three operand panel pairs in flight, on 128x128 tiles above 96 tiles, 128x64
+ *                      (two waves) from 40, 64x64 (one wave) below; up to 340 tiles two stages on 128x64; above, two stages on 128x128 (rounds 1-5
+ *                      everywhere).  1 / 2 / 3 force 128x128 / 64x64 / 128x64, + 20 / + 40 force two / four stages (tests, A/B).  Same K order in
+ *                      each: bit-identical outputs
  *   "attn_variant"     0 default (16x16x32 MFMA, 4 waves x 32 query rows, row sums on the matrix pipe; bf16 without the running
  *                      maximum in the hot loop; round 6, bf16: 4 waves x 16 query rows — 64-row workgroups, same bits per row — where the grid
  *                      has fewer than 384 blocks of 128 rows, e.g. one 518^2 image) | 417 = the 128-row shape with the running maximum

@@ -43,7 +43,7 @@ struct Options {
     int attn_f32_mx;      // fp32 mode, with the MX GEMM form: 1 (default) = the attention's P V correction terms as block-scaled fp8 MFMAs, scores at 22 bits; 2 = scores too; 0 = f16 planes
     int gemm_raster;      // gemm12.hip: tile order inside an XCD (GemmArgs::raster): 0 = 4 x tiles_n groups | S > 0 = slab walk, <= S n tiles per slab
     int attn_f32_pv;      // fp32 mode: 1 = the attention's P V product on the hi planes alone (f16 P and V, row sums of the rounded P on the matrix pipe); 0 = with its correction terms ("f32_precision high")
-    int gemm_small_tile;  // 128x128-kernel family's tile (GemmArgs::small_tile): 0 = by grid size | 1 128 x 128 | 2 64 x 64 | 3 128 x 64
+    int gemm_small_tile;  // 128x128-kernel family's tile (GemmArgs::small_tile): 0 = by grid size | 1 128 x 128 | 2 64 x 64 | 3 128 x 64; + 20 / + 40 = two / four LDS stages
     int f32_drop;         // fp32 mode, ACCURACY ABLATION (tools/fp32_term_ablation.py; three-plane form): bit mask of product classes computed hi . hi only — 1 q|k projection, 2 V projection, 4 out-projection, 8 fc1, 16 fc2, 32 patch embedding; tools build also: 64 scores, 128 P (V keeps hi + lo)
 };
 Options g_opt = {0, 1, 0, 0, 0, 1, 1, 1, 0, 0, 1, 1, 1, 0, 0, 0, 0};

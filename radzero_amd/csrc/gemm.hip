@@ -27,13 +27,20 @@ namespace rz {
 // [K f16 | K / 64 pair blocks of 128 bytes], g.K = 2 K counts 128-byte panels x 64; the first half of the panels runs the f16 MFMAs (a_hi b_hi), the
 // second half ONE block-scaled e4m3 MFMA per accumulator tile (both correction terms), its 32-byte operands = the two 16-byte fragments of the panel.
 // Same products, same order as the 256 x 256 kernels: bit-identical to them (tests/test_gpu_model.py forced-variant checks).
-// WM x WN = waves along m / n (64 x 64 outputs each): 2 x 2 is the 128 x 128 tile; the smaller geometries spread a GEMM of few tiles over more CUs
-// (one CU's LDS-DMA stream moves ~45 GB/s whatever the ring depth — profiles/r06/small_kernel_ring_depth_ab.txt — so a grid that leaves CUs idle is
-// bound by bytes per ACTIVE CU).  Same K order and accumulator ownership in every geometry: bit-identical outputs.
-template <typename T, int EPI, typename OT = T, bool MXK = false, int WM = 2, int WN = 2>
-__global__ __launch_bounds__(64 * WM * WN, 2) void gemm_kernel(GemmArgs g) {
+// WM x WN = waves along m / n (64 x 64 outputs each): 2 x 2 is the 128 x 128 tile; the smaller geometries spread a GEMM of few tiles over more CUs.
+// S = panel pairs in the LDS ring: S - 1 pairs in flight behind a COUNTED vmcnt and a bare s_barrier.  (A __syncthreads() is a fence — the compiler puts
+// s_waitcnt vmcnt(0) before its s_barrier, i.e. it waits for every outstanding LDS-DMA — which is what made this round's first ring experiment a no-op
+// and its "not latency-bound" conclusion wrong: profiles/NOTEBOOK.md.)  On a small grid nothing hides the global -> LDS round trip (~0.9 us per panel pair with
+// one pair in flight) but the workgroup itself.  Same K order and accumulator ownership in every geometry and depth: bit-identical outputs.
+template <int N> __device__ __forceinline__ void wait_vm_barrier() {
+    asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(N) : "memory");
+}
+template <typename T, int EPI, typename OT = T, bool MXK = false, int WM = 2, int WN = 2, int S = 2>
+__global__ __launch_bounds__(64 * WM * WN, S == 2 ? 2 : 1) void gemm_kernel(GemmArgs g) {
     constexpr int TBM = 64 * WM, TBN = 64 * WN, PA = TBM * 128, PB = TBN * 128;
-    __shared__ __attribute__((aligned(1024))) char lds[2 * PA + 2 * PB];  // A0 A1 B0 B1
+    constexpr int NPER = 8 / WN + 8 / WM;      // LDS-DMA instructions per wave and panel pair
+    static_assert((S == 2 || S == 4) && (S - 2) * NPER < 64, "ring depth");
+    __shared__ __attribute__((aligned(1024))) char lds[S * PA + S * PB];  // A0 .. A(S-1) B0 .. B(S-1)
     if constexpr (sizeof(T) == 4) {      // exact-fp32 instantiations: predicated launch (fp32 mode's overflow guard, rz_kernels.h GemmArgs::run_if)
         if (g.run_if && *g.run_if == 0) return;
     }
@@ -61,7 +68,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_kernel(GemmArgs g) {
 
     auto stage = [&](int kt, int buf) {
         char* sa = lds + buf * PA;
-        char* sb = lds + 2 * PA + buf * PB;
+        char* sb = lds + S * PA + buf * PB;
         const char* ga = Ab + (int64_t)kt * 128;
         const char* gb = Wb + (int64_t)kt * 128;
 #pragma unroll
@@ -82,15 +89,27 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_kernel(GemmArgs g) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    stage(0, 0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+    // every wave waits until all but the `younger` youngest of its panel pairs have landed, then the workgroup meets
+    auto ring_wait = [&](int younger) {
+        if (S >= 4 && younger >= 2) wait_vm_barrier<2 * NPER>();
+        else if (S >= 3 && younger == 1) wait_vm_barrier<NPER>();
+        else wait_vm_barrier<0>();
+    };
+    // prologue: panels 0 .. S-2 requested, panel 0 waited for
+#pragma unroll
+    for (int p = 0; p < S - 1; ++p)
+        if (p < nk) stage(p, p);
+    ring_wait(min(nk, S - 1) - 1);
 
+    int buf = 0;
     for (int kt = 0; kt < nk; ++kt) {
-        const int buf = kt & 1;
-        if (kt + 1 < nk) stage(kt + 1, buf ^ 1);
+        // panel kt + S - 1 goes into the buffer iteration kt - 1 read (every wave is past that iteration's closing barrier)
+        if (kt + S - 1 < nk) stage(kt + S - 1, buf == 0 ? S - 1 : buf - 1);
+        // panel kt + 1 must have landed before the next iteration; the pairs requested after it stay in flight
+        const int younger = min(nk - 1, kt + S - 1) - (kt + 1);
         const char* sa = lds + buf * PA;
-        const char* sb = lds + 2 * PA + buf * PB;
+        const char* sb = lds + S * PA + buf * PB;
+        buf = buf + 1 == S ? 0 : buf + 1;
         // fragments of k-step ks+1 are requested before the 16 MFMAs of k-step ks (register double buffer),
         // so only the first LDS round trip of a K panel is exposed
         frag_t fa[2][4], fb[2][4];
@@ -116,8 +135,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_kernel(GemmArgs g) {
                             else acc[i][j] = mma_mx(fa[0][i], fa[1][i], fb[0][j], fb[1][j], acc[i][j], sa_mx, sw_mx);
                         }
                 }
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                __syncthreads();
+                ring_wait(younger);
                 continue;
             }
         }
@@ -139,8 +157,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_kernel(GemmArgs g) {
                     else acc[i][j] = mma(fa[ks & 1][i], fb[ks & 1][j], acc[i][j]);        // D[row=m][col=n]
                 }
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
+        ring_wait(younger);
     }
 
     gemm_epilogue<OT, EPI>(g, acc, m0 + wm * 64, n0 + wn * 64, l15, lg);
@@ -308,23 +325,42 @@ bool gemm_ln_fused_ok(int dtype, int M, int D, int F, int variant) {
     return dtype != DT_F32 && (variant == 0 || variant == 1 || persistent_variant(variant)) && M > 0 && M % BM == 0 && D == 768 && F % BN == 0;
 }
 
-// 128 x 128-kernel family: which tile geometry (GemmArgs::small_tile; 0 = by grid size).  Measured in the step, all modes (profiles/r06/small_tile_step_ab.txt,
-// small_tile_step_ab2.txt): below 40 tiles of 128 x 128 (one 224^2 image's N = 768 GEMMs, the text encoder) the one-wave 64 x 64 tile wins (-11 % step time
-// for one 224^2 image); up to ~340 tiles (N = 768 GEMMs of <= five 518^2 / one 1024^2 / sixteen 224^2 images) the two-wave 128 x 64 tile (-2 ... -7 %);
-// from 396 tiles on the smaller tiles LOSE 12-20 % (more operand bytes through each XCD's L2 once every CU already has work).
+// 128 x 128-kernel family: tile geometry and ring depth of a launch (GemmArgs::small_tile = geometry + 10 S forces either; 0 = this rule).  Measured per GEMM inside
+// the step from kernel traces (profiles/r06/small_kernel_per_gemm.txt: nine forced combinations x six shapes), n = tiles of 128 x 128:
+//   n <= 256  every workgroup can own a CU: the four-stage ring (three panel pairs in flight) on the LARGEST tile that still spreads the work — 128 x 128 above 96
+//             tiles (fc2 of two 518^2 images, 132 tiles: 51.7 -> 40.5 us; of one 1024^2 image, 252: 57.3 -> 43.2), 128 x 64 from 40 (one 518^2 image, 72: 51.1 -> 38.1),
+//             64 x 64 below (224^2 x 2, 36: 44.2 -> 37.1; the text encoder);
+//   n <= 340  two or three workgroups per CU hide the latency instead: two stages, 128 x 64 (fc2 of four 518^2 images, 264: 61.2 -> 54.6 us; the deep rings 77-108);
+//   above     two stages, 128 x 128 (smaller tiles only add operand bytes through each XCD's L2: 396 tiles -16 % in the step).
 static int small_tile_choice(const GemmArgs& g) {
-    if (g.small_tile) return g.small_tile;
+    const int forced = g.small_tile % 10;
+    if (forced) return forced;
     const int n = (g.M / BM) * (g.N / BN);
-    return n < 40 ? 2 : n <= 340 ? 3 : 1;
+    if (n <= 256) return n > 96 ? 1 : n >= 40 ? 3 : 2;
+    return n <= 340 ? 3 : 1;
+}
+static int small_stages_choice(const GemmArgs& g, int st) {
+    const int forced = g.small_tile / 10;
+    if (forced == 2 || forced == 4) return forced;
+    const int wgs = st == 2 ? (g.M / 64) * (g.N / 64) : st == 3 ? (g.M / 128) * (g.N / 64) : (g.M / 128) * (g.N / 128);
+    const int kb = st == 2 ? 16 : st == 3 ? 24 : 32;      // LDS per stage: the deep ring only where every workgroup is resident at once
+    return wgs <= 256 * (160 / (kb * 4)) ? 4 : 2;
 }
 
-template <typename T, int EPI, typename OT>
+template <typename T, int EPI, typename OT, bool MXK, int S>
+static void launch_small_s(int st, const GemmArgs& g, hipStream_t s) {
+    if constexpr (sizeof(T) == 2) {
+        if (st == 2) { hipLaunchKernelGGL((gemm_kernel<T, EPI, OT, MXK, 1, 1, S>), dim3((g.M / 64) * (g.N / 64)), dim3(64), 0, s, g); return; }
+        if (st == 3) { hipLaunchKernelGGL((gemm_kernel<T, EPI, OT, MXK, 2, 1, S>), dim3((g.M / 128) * (g.N / 64)), dim3(128), 0, s, g); return; }
+    }
+    hipLaunchKernelGGL((gemm_kernel<T, EPI, OT, MXK, 2, 2, S>), dim3((g.M / BM) * (g.N / BN)), dim3(256), 0, s, g);
+}
+template <typename T, int EPI, typename OT, bool MXK = false>
 static void launch_small(int st, const GemmArgs& g, hipStream_t s) {
     if constexpr (sizeof(T) == 2) {
-        if (st == 2) { hipLaunchKernelGGL((gemm_kernel<T, EPI, OT, false, 1, 1>), dim3((g.M / 64) * (g.N / 64)), dim3(64), 0, s, g); return; }
-        if (st == 3) { hipLaunchKernelGGL((gemm_kernel<T, EPI, OT, false, 2, 1>), dim3((g.M / 128) * (g.N / 64)), dim3(128), 0, s, g); return; }
+        if (small_stages_choice(g, st) == 4) return launch_small_s<T, EPI, OT, MXK, 4>(st, g, s);
     }
-    hipLaunchKernelGGL((gemm_kernel<T, EPI, OT>), dim3((g.M / BM) * (g.N / BN)), dim3(256), 0, s, g);
+    launch_small_s<T, EPI, OT, MXK, 2>(st, g, s);
 }
 
 template <typename T>
@@ -456,11 +492,7 @@ bool gemm_small_mx_pays(int epi, const GemmArgs& g) {
 hipError_t launch_gemm_small_mx(int epi, const GemmArgs& g, int out_kind, hipStream_t s) {
     if (!gemm_small_mx_ok(epi, out_kind, g)) return hipErrorInvalidValue;
     const int st = small_tile_choice(g);
-#define RZ_CASEM(E, OT) case E: \
-        if (st == 2) hipLaunchKernelGGL((gemm_kernel<f16_t, E, OT, true, 1, 1>), dim3((g.M / 64) * (g.N / 64)), dim3(64), 0, s, g); \
-        else if (st == 3) hipLaunchKernelGGL((gemm_kernel<f16_t, E, OT, true, 2, 1>), dim3((g.M / 128) * (g.N / 64)), dim3(128), 0, s, g); \
-        else hipLaunchKernelGGL((gemm_kernel<f16_t, E, OT, true>), dim3((g.M / BM) * (g.N / BN)), dim3(256), 0, s, g); \
-        break;
+#define RZ_CASEM(E, OT) case E: launch_small<f16_t, E, OT, true>(st, g, s); break;
     if (out_kind == 0) {
         switch (epi) { RZ_CASEM(EPI_RESID_SCALE, f16_t) RZ_CASEM(EPI_PATCH, f16_t) default: return hipErrorInvalidValue; }
     } else if (out_kind == 1) {

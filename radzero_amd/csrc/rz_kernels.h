@@ -46,7 +46,7 @@ struct GemmArgs {
     unsigned* ovf_flag = nullptr; // hi/lo-split outputs: word that receives 1 when a value leaves the f16 range (rz_common.h flag_f16_range)
     int mx_w_e8_hi = 123, mx_w_e8_lo = 112;   // fp32 mode, MX form: E8M0 scale bytes (127 + log2 scale) of THIS weight matrix's hi8 / lo8 planes; defaults = 2^-4 / 2^-15 (rz_common.h)
     const unsigned* run_if = nullptr;  // exact-fp32 kernels only (fp32 mode's overflow guard, api.hip rz_vision_forward): non-null => the launch does nothing unless *run_if != 0
-    int small_tile = 0;           // 128x128-kernel family (gemm.hip): 0 by grid size | 1 128 x 128 (4 waves) | 2 64 x 64 (1 wave) | 3 128 x 64 (2 waves)
+    int small_tile = 0;           // 128x128-kernel family (gemm.hip): 0 by grid size | 1 128 x 128 (4 waves) | 2 64 x 64 (1 wave) | 3 128 x 64 (2 waves); + 10 S forces a ring of S = 2 / 4 panel pairs
     int raster = 0;               // gemm12.hip tile order inside an XCD: 0 = gemm8's (4 x tiles_n groups) | S > 0 = slab walk, slabs of <= S n tiles
     int variant = 0;              // kernel choice: 0 auto | 1 128x128 two-stage | 3 256x256 two-stage | 7 staggered 8-phase (gemm7.hip) | 8 persistent (gemm8.hip) | 10 persistent, 4 waves x 128x128, asm K loop (gemm10.hip) | 11 persistent, 8 waves, one phase per K tile (gemm11.hip)
 };
