@@ -73,6 +73,13 @@ int* option_field(Options& o, const char* name) {
     return nullptr;
 }
 inline int pick(int own, int process_wide) { return own == RZ_OPT_INHERIT ? process_wide : own; }
+// gemm_small_tile: geometry (0 rule | 1 | 2 | 3) + 10 x stages (0 rule | 2 | 4)
+inline bool small_tile_ok(int value) {
+    if (value == RZ_OPT_INHERIT) return true;
+    if (value < 0) return false;
+    const int geo = value % 10, st = value / 10;
+    return geo <= 3 && (st == 0 || st == 2 || st == 4);
+}
 inline bool f32_drop_ok(int value) {
 #ifdef RZ_EXPERIMENTS
     (void)value;
@@ -1599,6 +1606,7 @@ int rz_set_option(const char* name, int value) {
     int* f = option_field(g_opt, name);
     if (!f) return fail(RZ_ERR_INVALID, std::string("rz_set_option: unknown option ") + name);
     if (f == &g_opt.f32_drop && !f32_drop_ok(value)) return fail(RZ_ERR_INVALID, "rz_set_option: f32_drop bits 64 / 128 (scores / P on the hi planes alone) exist only in the -DRZ_EXPERIMENTS tools build");
+    if (f == &g_opt.gemm_small_tile && (value == RZ_OPT_INHERIT || !small_tile_ok(value))) return fail(RZ_ERR_INVALID, "rz_set_option: gemm_small_tile is geometry (0 - 3) + 10 x stages (0, 2 or 4)");
     *f = value;
     return 0;
 }
@@ -1608,6 +1616,7 @@ int rz_set_model_option(rz_handle_t m, const char* name, int value) {
     int* f = option_field(m->opt, name);
     if (!f) return fail(RZ_ERR_INVALID, std::string("rz_set_model_option: unknown option ") + name);
     if (f == &m->opt.f32_drop && !f32_drop_ok(value)) return fail(RZ_ERR_INVALID, "rz_set_model_option: f32_drop bits 64 / 128 (scores / P on the hi planes alone) exist only in the -DRZ_EXPERIMENTS tools build");
+    if (f == &m->opt.gemm_small_tile && !small_tile_ok(value)) return fail(RZ_ERR_INVALID, "rz_set_model_option: gemm_small_tile is geometry (0 - 3) + 10 x stages (0, 2 or 4)");
     if (f == &m->opt.pad_rows) {
         if (value != RZ_OPT_INHERIT && value != 0 && value != 128 && value != 256) return fail(RZ_ERR_INVALID, "rz_set_model_option: pad_rows is 0, 128 or 256");
         RZ_HIP(hipDeviceSynchronize());
