@@ -85,6 +85,9 @@ def build(force: bool = False, verbose: bool = False) -> str:
         raise RuntimeError(f"hipcc not found at {HIPCC}; cannot build libradzero_hip.so")
     import fcntl
     obj_dir = os.path.join(PKG_DIR, "build_experiments" if EXPERIMENTS else "build")
+    if os.environ.get("RZ_CXXFLAGS", "").strip():        # an A/B build: its objects must never be mistaken for the product's (they are reused by file time alone)
+        import hashlib
+        obj_dir += "_" + hashlib.sha256(os.environ["RZ_CXXFLAGS"].encode()).hexdigest()[:10]
     os.makedirs(obj_dir, exist_ok=True)
     with open(os.path.join(obj_dir, ".lock"), "w") as lock:
         fcntl.flock(lock, fcntl.LOCK_EX)
