@@ -44,12 +44,13 @@ struct Options {
     int gemm_raster;      // gemm12.hip: tile order inside an XCD (GemmArgs::raster): 0 = 4 x tiles_n groups | S > 0 = slab walk, <= S n tiles per slab
     int attn_f32_pv;      // fp32 mode: 1 = the attention's P V product on the hi planes alone (f16 P and V, row sums of the rounded P on the matrix pipe); 0 = with its correction terms ("f32_precision high")
     int gemm_small_tile;  // 128x128-kernel family's tile (GemmArgs::small_tile): 0 = by grid size | 1 128 x 128 | 2 64 x 64 | 3 128 x 64; + 20 / + 40 = two / four LDS stages
+    int gemm_qkv_pair;    // 16-bit modes, small batches: 1 (default) = the q|k and v projections of a block as ONE launch of the 128x128 kernel family (gemm_pair_kernel) where the persistent kernel's merged projection does not apply; 0 = two launches
     int f32_drop;         // fp32 mode, ACCURACY ABLATION (tools/fp32_term_ablation.py; three-plane form): bit mask of product classes computed hi . hi only — 1 q|k projection, 2 V projection, 4 out-projection, 8 fc1, 16 fc2, 32 patch embedding; tools build also: 64 scores, 128 P (V keeps hi + lo)
 };
-Options g_opt = {0, 1, 0, 0, 0, 1, 1, 1, 0, 0, 1, 1, 1, 0, 0, 0, 0};
+Options g_opt = {0, 1, 0, 0, 0, 1, 1, 1, 0, 0, 1, 1, 1, 0, 0, 0, 1, 0};
 const Options kInherit = {RZ_OPT_INHERIT, RZ_OPT_INHERIT, RZ_OPT_INHERIT, RZ_OPT_INHERIT, RZ_OPT_INHERIT, RZ_OPT_INHERIT, RZ_OPT_INHERIT,
                           RZ_OPT_INHERIT, RZ_OPT_INHERIT, RZ_OPT_INHERIT, RZ_OPT_INHERIT, RZ_OPT_INHERIT, RZ_OPT_INHERIT, RZ_OPT_INHERIT,
-                          RZ_OPT_INHERIT, RZ_OPT_INHERIT, RZ_OPT_INHERIT};
+                          RZ_OPT_INHERIT, RZ_OPT_INHERIT, RZ_OPT_INHERIT, RZ_OPT_INHERIT};
 int* option_field(Options& o, const char* name) {
 #ifdef RZ_EXPERIMENTS      // measured, never a gain (profiles/NOTEBOOK.md): known to the tools build only; the product runs one pass, one stream
     if (!strcmp(name, "vision_chunk")) return &o.vision_chunk;
@@ -60,6 +61,7 @@ int* option_field(Options& o, const char* name) {
     if (!strcmp(name, "attn_variant")) return &o.attn_variant;
     if (!strcmp(name, "gemm_variant")) return &o.gemm_variant;
     if (!strcmp(name, "gemm_small_tile")) return &o.gemm_small_tile;
+    if (!strcmp(name, "gemm_qkv_pair")) return &o.gemm_qkv_pair;
     if (!strcmp(name, "gemm_f32_split")) return &o.gemm_f32_split;
     if (!strcmp(name, "attn_f32_split")) return &o.attn_f32_split;
     if (!strcmp(name, "ln_fused")) return &o.ln_fused;
@@ -184,6 +186,13 @@ struct rz_model {
 #endif
     int o_attn_variant() const { return pick(opt.attn_variant, g_opt.attn_variant); }
     int o_gemm_variant() const { return pick(opt.gemm_variant, g_opt.gemm_variant); }
+    bool o_gemm_qkv_pair() const { return pick(opt.gemm_qkv_pair, g_opt.gemm_qkv_pair) != 0; }
+    // the pair in front of the persistent kernel's merged projection: measured in the step (profiles/r06/qkv_pair_step_ab2.txt) the pair wins up to 432 tiles of 128 x 128
+    // (224^2 x 4 / x 8 -7 / -3 %, 518^2 x 1 / x 2 -6 / -3 %) and loses from 648 on (518^2 x 3 +6 %, 1024^2 x 1 +5 %); option value 2 = wherever the pair applies (A/B)
+    bool o_gemm_qkv_pair_first(int M) const {
+        const int v = pick(opt.gemm_qkv_pair, g_opt.gemm_qkv_pair);
+        return v == 2 || (v == 1 && o_gemm_variant() == 0 && (int64_t)(M / 128) * (3 * D / 128) <= 448);
+    }
     int o_gemm_small_tile() const { return pick(opt.gemm_small_tile, g_opt.gemm_small_tile); }
     int o_gemm_raster() const { return pick(opt.gemm_raster, g_opt.gemm_raster); }
     int o_gemm_f32_mx() const { return pick(opt.gemm_f32_mx, g_opt.gemm_f32_mx); }
@@ -606,6 +615,25 @@ int gemm_ln(rz_model* m, int epi, const void* hb, const Tensor& wf, const Tensor
     return 0;
 }
 
+// the block's q|k and v projections behind a fused LayerNorm as ONE launch of the 128 x 128 family (gemm.hip gemm_pair_kernel); *done = false: not applicable, the caller launches the two
+int gemm_ln_qkv_pair(rz_model* m, const void* hb, const DinoBlock& b, const float* stat, int M, int np, void* qk, void* vt, hipStream_t s, bool* done) {
+    const int D = m->D, H = m->H;
+    *done = false;
+    if (!m->o_gemm_qkv_pair()) return 0;
+    GemmArgs ga, gb;
+    ga.A = hb; ga.lda = D; ga.W = b.wqkv.p; ga.ldw = D; ga.M = M; ga.N = 2 * D; ga.K = D; ga.bias = (const float*)b.c2qkv.p; ga.out = qk; ga.ldo = 0;
+    ga.scale = (const float*)b.c1qkv.p; ga.resid = nullptr; ga.ldr = 0; ga.rows_per_image = np; ga.heads_total = 2 * H; ga.ln_stat = stat;
+    ga.variant = m->o_gemm_variant(); ga.small_tile = m->o_gemm_small_tile(); ga.raster = m->o_gemm_raster();
+    gb = ga;
+    gb.W = (const char*)b.wqkv.p + (size_t)2 * D * D * dsize(m->dt); gb.N = D; gb.bias = (const float*)b.c2qkv.p + 2 * D; gb.scale = (const float*)b.c1qkv.p + 2 * D;
+    gb.out = vt; gb.heads_total = H;
+    if (!gemm_pair_ok(m->dt, EPI_HEADS_LN, ga, EPI_VT_LN, gb)) return 0;
+    ProfScope ps(m, RZ_PROF_GEMM, s);
+    RZ_HIP(launch_gemm_pair(m->dt, EPI_HEADS_LN, ga, EPI_VT_LN, gb, s));
+    *done = true;
+    return 0;
+}
+
 // residual GEMM that precedes a LayerNorm, fused form: also writes the T copy of the new residual and partial statistics,
 // then the 12 partials per row are merged into (mean, rstd)
 int gemm_resid_ln(rz_model* m, const void* A, int64_t lda, const Tensor& W, const Tensor& bias, const Tensor& ls, int M, int K, float* h,
@@ -629,13 +657,29 @@ int gemm_qkv(rz_model* m, const void* xn, const DinoBlock& b, int M, int np, voi
     g.A = xn; g.lda = D; g.W = b.wqkv.p; g.ldw = D; g.M = M; g.N = 3 * D; g.K = D; g.bias = (const float*)b.bqkv.p;
     g.out = qk; g.ldo = 0; g.scale = nullptr; g.resid = nullptr; g.ldr = 0; g.rows_per_image = np; g.heads_total = 2 * H;
     g.out2 = vt; g.heads_total2 = H; g.split_n = 2 * D; g.variant = m->o_gemm_variant(); g.small_tile = m->o_gemm_small_tile(); g.raster = m->o_gemm_raster();
+    const char* wv = (const char*)b.wqkv.p + (size_t)2 * D * D * dsize(m->dt);
+    int rc;
+    auto pair = [&](bool* done) -> int {      // 16-bit modes: the q|k and v launches as one (gemm.hip gemm_pair_kernel)
+        *done = false;
+        if (m->dt == RZ_F32 || !m->o_gemm_qkv_pair()) return 0;
+        GemmArgs ga = g, gb;
+        ga.N = 2 * D; ga.out2 = nullptr; ga.heads_total2 = 0; ga.split_n = 0;
+        gb = ga;
+        gb.W = wv; gb.N = D; gb.bias = (const float*)b.bqkv.p + 2 * D; gb.out = vt; gb.heads_total = H;
+        if (!gemm_pair_ok(m->dt, EPI_HEADS, ga, EPI_VT, gb)) return 0;
+        ProfScope ps(m, RZ_PROF_GEMM, s);
+        RZ_HIP(launch_gemm_pair(m->dt, EPI_HEADS, ga, EPI_VT, gb, s));
+        *done = true;
+        return 0;
+    };
+    bool done = false;
+    if (m->o_gemm_qkv_pair_first(M) && ((rc = pair(&done)) || done)) return rc;
     if (gemm_qkv_fused_ok(m->dt, g)) {
         ProfScope ps(m, RZ_PROF_GEMM, s);
         RZ_HIP(launch_gemm(m->dt, EPI_QKV, g, s));
         return 0;
     }
-    const char* wv = (const char*)b.wqkv.p + (size_t)2 * D * D * dsize(m->dt);
-    int rc;
+    if ((rc = pair(&done)) || done) return rc;
     if ((rc = gemm(m, EPI_HEADS, xn, D, b.wqkv.p, D, M, 2 * D, D, (const float*)b.bqkv.p, qk, 0, nullptr, nullptr, 0, np, 2 * H, s))) return rc;
     return gemm(m, EPI_VT, xn, D, wv, D, M, D, D, (const float*)b.bqkv.p + 2 * D, vt, 0, nullptr, nullptr, 0, np, H, s, A_REUSE);
 }
@@ -1084,15 +1128,22 @@ static int vision_forward_once(rz_handle_t m, const float* px, int B, int C, int
             } else {
                 GemmArgs probe;
                 probe.A = xn; probe.lda = D; probe.W = b.wqkv.p; probe.ldw = D; probe.M = M; probe.N = 3 * D; probe.K = D; probe.out2 = vtb; probe.split_n = 2 * D; probe.variant = m->o_gemm_variant(); probe.small_tile = m->o_gemm_small_tile(); probe.raster = m->o_gemm_raster();
-                if (gemm_qkv_fused_ok(m->dt, probe)) {
+                bool paired_first = false;
+                if (m->o_gemm_qkv_pair_first(M) && (rc = gemm_ln_qkv_pair(m, xn, b, stat, M, np, qkb, vtb, s, &paired_first))) return rc;
+                if (paired_first) {
+                } else if (gemm_qkv_fused_ok(m->dt, probe)) {
                     if ((rc = gemm_ln(m, EPI_QKV_LN, xn, b.wqkv, b.c1qkv, b.c2qkv, stat, M, 3 * D, np, qkb, 0, 2 * H, vtb, H, 2 * D, s))) return rc;
                 } else {        // small batches: the same projection as q|k and v launches of the 128x128 kernel
                     Tensor wv = b.wqkv, c1v = b.c1qkv, c2v = b.c2qkv;
                     wv.p = (char*)b.wqkv.p + (size_t)2 * D * D * es;
                     c1v.p = (float*)b.c1qkv.p + 2 * D;
                     c2v.p = (float*)b.c2qkv.p + 2 * D;
-                    if ((rc = gemm_ln(m, EPI_HEADS_LN, xn, b.wqkv, b.c1qkv, b.c2qkv, stat, M, 2 * D, np, qkb, 0, 2 * H, nullptr, 0, 0, s))) return rc;
-                    if ((rc = gemm_ln(m, EPI_VT_LN, xn, wv, c1v, c2v, stat, M, D, np, vtb, 0, H, nullptr, 0, 0, s))) return rc;
+                    bool paired = false;
+                    if ((rc = gemm_ln_qkv_pair(m, xn, b, stat, M, np, qkb, vtb, s, &paired))) return rc;
+                    if (!paired) {
+                        if ((rc = gemm_ln(m, EPI_HEADS_LN, xn, b.wqkv, b.c1qkv, b.c2qkv, stat, M, 2 * D, np, qkb, 0, 2 * H, nullptr, 0, 0, s))) return rc;
+                        if ((rc = gemm_ln(m, EPI_VT_LN, xn, wv, c1v, c2v, stat, M, D, np, vtb, 0, H, nullptr, 0, 0, s))) return rc;
+                    }
                 }
             }
             {

@@ -35,15 +35,12 @@ namespace rz {
 template <int N> __device__ __forceinline__ void wait_vm_barrier() {
     asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(N) : "memory");
 }
-template <typename T, int EPI, typename OT = T, bool MXK = false, int WM = 2, int WN = 2, int S = 2>
-__global__ __launch_bounds__(64 * WM * WN, S == 2 ? 2 : 1) void gemm_kernel(GemmArgs g) {
+// One output tile (tm, tn) of the GEMM `g`: the body of gemm_kernel and of gemm_pair_kernel (two GEMMs over the same rows in one launch).
+template <typename T, int EPI, typename OT, bool MXK, int WM, int WN, int S>
+__device__ __forceinline__ void gemm_tile_body(const GemmArgs& g, int tm, int tn, char* lds) {
     constexpr int TBM = 64 * WM, TBN = 64 * WN, PA = TBM * 128, PB = TBN * 128;
     constexpr int NPER = 8 / WN + 8 / WM;      // LDS-DMA instructions per wave and panel pair
     static_assert((S == 2 || S == 4) && (S - 2) * NPER < 64, "ring depth");
-    __shared__ __attribute__((aligned(1024))) char lds[S * PA + S * PB];  // A0 .. A(S-1) B0 .. B(S-1)
-    if constexpr (sizeof(T) == 4) {      // exact-fp32 instantiations: predicated launch (fp32 mode's overflow guard, rz_kernels.h GemmArgs::run_if)
-        if (g.run_if && *g.run_if == 0) return;
-    }
     constexpr bool SWAP = (EPI != EPI_VT && EPI != EPI_VT_LN);
     constexpr int KS = 128 / (32 * (int)sizeof(T));  // MFMA k-steps (of 32 elements) per panel
     typedef typename Traits<T>::frag frag_t;
@@ -51,11 +48,6 @@ __global__ __launch_bounds__(64 * WM * WN, S == 2 ? 2 : 1) void gemm_kernel(Gemm
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = WN == 2 ? wave >> 1 : wave, wn = WN == 2 ? wave & 1 : 0;
     const int l15 = lane & 15, lg = lane >> 4;
-
-    const int tiles_n = g.N / TBN, tiles_m = g.M / TBM;
-    const int bid = xcd_remap(blockIdx.x, tiles_m * tiles_n);
-    int tm, tn;
-    tile_coords<8>(bid, tiles_m, tiles_n, tm, tn);
     const int m0 = tm * TBM, n0 = tn * TBN;
 
     const char* Ab = reinterpret_cast<const char*>(g.A) + (int64_t)m0 * g.lda * sizeof(T);
@@ -161,6 +153,33 @@ __global__ __launch_bounds__(64 * WM * WN, S == 2 ? 2 : 1) void gemm_kernel(Gemm
     }
 
     gemm_epilogue<OT, EPI>(g, acc, m0 + wm * 64, n0 + wn * 64, l15, lg);
+}
+
+template <typename T, int EPI, typename OT = T, bool MXK = false, int WM = 2, int WN = 2, int S = 2>
+__global__ __launch_bounds__(64 * WM * WN, S == 2 ? 2 : 1) void gemm_kernel(GemmArgs g) {
+    constexpr int TBM = 64 * WM, TBN = 64 * WN;
+    __shared__ __attribute__((aligned(1024))) char lds[S * (TBM + TBN) * 128];  // A0 .. A(S-1) B0 .. B(S-1)
+    if constexpr (sizeof(T) == 4) {      // exact-fp32 instantiations: predicated launch (fp32 mode's overflow guard, rz_kernels.h GemmArgs::run_if)
+        if (g.run_if && *g.run_if == 0) return;
+    }
+    const int tiles_n = g.N / TBN, tiles_m = g.M / TBM;
+    int tm, tn;
+    tile_coords<8>(xcd_remap(blockIdx.x, tiles_m * tiles_n), tiles_m, tiles_n, tm, tn);
+    gemm_tile_body<T, EPI, OT, MXK, WM, WN, S>(g, tm, tn, lds);
+}
+
+// Two GEMMs over the SAME rows (A, M, K) in one launch: the block's q|k projection (ga) and its v projection (gb) where the merged projection of the persistent
+// kernel does not apply (small batches, odd row counts).  Rastered as ONE GEMM of ga.N + gb.N columns — the tiles of a row block share their A panels through the
+// XCD's L2 whichever GEMM they belong to; a tile's arithmetic is gemm_kernel's: same bits as the two launches.
+template <typename T, int EPIA, int EPIB, typename OTA, typename OTB, bool MXK, int WM, int WN, int S>
+__global__ __launch_bounds__(64 * WM * WN, S == 2 ? 2 : 1) void gemm_pair_kernel(GemmArgs ga, GemmArgs gb) {
+    constexpr int TBM = 64 * WM, TBN = 64 * WN;
+    __shared__ __attribute__((aligned(1024))) char lds[S * (TBM + TBN) * 128];
+    const int tna = ga.N / TBN, tiles_n = tna + gb.N / TBN, tiles_m = ga.M / TBM;
+    int tm, tn;
+    tile_coords<8>(xcd_remap(blockIdx.x, tiles_m * tiles_n), tiles_m, tiles_n, tm, tn);
+    if (tn < tna) gemm_tile_body<T, EPIA, OTA, MXK, WM, WN, S>(ga, tm, tn, lds);
+    else gemm_tile_body<T, EPIB, OTB, MXK, WM, WN, S>(gb, tm, tn - tna, lds);
 }
 
 constexpr int BM2 = 256;
@@ -436,6 +455,36 @@ static hipError_t launch_gemm_t(int epi, const GemmArgs& g, hipStream_t s) {
 #undef RZ_CASE
 #undef RZ_CASE1
     return hipGetLastError();
+}
+
+// ---- two GEMMs over the same rows in one launch (gemm_pair_kernel): the 16-bit modes' q|k + v projections on the 128 x 128 family ----
+bool gemm_pair_ok(int dtype, int epi_a, const GemmArgs& ga, int epi_b, const GemmArgs& gb) {
+    if (dtype != DT_BF16 && dtype != DT_F16) return false;
+    if (!((epi_a == EPI_HEADS_LN && epi_b == EPI_VT_LN) || (epi_a == EPI_HEADS && epi_b == EPI_VT))) return false;
+    if (ga.A != gb.A || ga.lda != gb.lda || ga.M != gb.M || ga.K != gb.K || ga.variant != gb.variant || ga.small_tile != gb.small_tile) return false;
+    if (ga.M <= 0 || ga.M % BM || ga.N <= 0 || ga.N % BN || gb.N <= 0 || gb.N % BN || (ga.K * 2) % 128 || (ga.lda * 2) % 16 || (ga.ldw * 2) % 16 || (gb.ldw * 2) % 16) return false;
+    if (ga.variant == 1) return true;
+    return ga.variant == 0 && !big_tiles_pay(ga, epi_a) && !big_tiles_pay(gb, epi_b);      // each would have gone to this family on its own
+}
+template <typename T, int EPIA, int EPIB, int S>
+static void launch_pair_s(int st, const GemmArgs& ga, const GemmArgs& gb, hipStream_t s) {
+    const int n = ga.N + gb.N;
+    if (st == 2) hipLaunchKernelGGL((gemm_pair_kernel<T, EPIA, EPIB, T, T, false, 1, 1, S>), dim3((ga.M / 64) * (n / 64)), dim3(64), 0, s, ga, gb);
+    else if (st == 3) hipLaunchKernelGGL((gemm_pair_kernel<T, EPIA, EPIB, T, T, false, 2, 1, S>), dim3((ga.M / 128) * (n / 64)), dim3(128), 0, s, ga, gb);
+    else hipLaunchKernelGGL((gemm_pair_kernel<T, EPIA, EPIB, T, T, false, 2, 2, S>), dim3((ga.M / BM) * (n / BN)), dim3(256), 0, s, ga, gb);
+}
+template <typename T>
+static hipError_t launch_pair_t(int epi_a, const GemmArgs& ga, const GemmArgs& gb, hipStream_t s) {
+    GemmArgs whole = ga;                 // geometry and ring depth as for ONE GEMM of ga.N + gb.N columns
+    whole.N = ga.N + gb.N;
+    const int st = small_tile_choice(whole), S = small_stages_choice(whole, st);
+    if (epi_a == EPI_HEADS_LN) { if (S == 4) launch_pair_s<T, EPI_HEADS_LN, EPI_VT_LN, 4>(st, ga, gb, s); else launch_pair_s<T, EPI_HEADS_LN, EPI_VT_LN, 2>(st, ga, gb, s); }
+    else { if (S == 4) launch_pair_s<T, EPI_HEADS, EPI_VT, 4>(st, ga, gb, s); else launch_pair_s<T, EPI_HEADS, EPI_VT, 2>(st, ga, gb, s); }
+    return hipGetLastError();
+}
+hipError_t launch_gemm_pair(int dtype, int epi_a, const GemmArgs& ga, int epi_b, const GemmArgs& gb, hipStream_t s) {
+    if (!gemm_pair_ok(dtype, epi_a, ga, epi_b, gb)) return hipErrorInvalidValue;
+    return dtype == DT_BF16 ? launch_pair_t<bf16_t>(epi_a, ga, gb, s) : launch_pair_t<f16_t>(epi_a, ga, gb, s);
 }
 
 // fp32 mode on the f16 matrix pipe.  The caller has split both operands into f16 planes laid side by side along K:

@@ -60,6 +60,10 @@ bool gemm_v8_ok(int dtype, int epi, const GemmArgs& g);
 bool gemm_v8_mx_ok(int epi, int out_kind, const GemmArgs& g);          // fp32 mode's MX form on the persistent kernel (gemm8.hip): which epilogues / output forms / shapes
 hipError_t launch_gemm_v8_mx(int epi, int out_kind, const GemmArgs& g, hipStream_t s);
 bool gemm_qkv_fused_ok(int dtype, const GemmArgs& g);
+// two GEMMs over the same rows (A, M, K) in one launch of the 128x128 family (gemm.hip gemm_pair_kernel): (EPI_HEADS_LN, EPI_VT_LN) or (EPI_HEADS, EPI_VT), 16-bit modes,
+// where each of the two would have gone to that family on its own; same bits as the two launches
+bool gemm_pair_ok(int dtype, int epi_a, const GemmArgs& ga, int epi_b, const GemmArgs& gb);
+hipError_t launch_gemm_pair(int dtype, int epi_a, const GemmArgs& ga, int epi_b, const GemmArgs& gb, hipStream_t s);
 bool gemm_patch_ln_ok(int dtype, const GemmArgs& g);                  // may the patch-embedding GEMM write block 0's LayerNorm inputs itself (EPI_PATCH_LN)
 bool gemm_ln_fused_ok(int dtype, int M, int D, int F, int variant);   // may a Dinov2 block of M token rows use the fused-LayerNorm epilogues
 // fp32 mode on the f16 matrix pipe: operands split into f16 planes along K (gemm.hip)

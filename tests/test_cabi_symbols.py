@@ -84,7 +84,7 @@ def test_set_option_known_and_unknown_names():
     from radzero_amd.modeling import RadZeroModel
     defaults = {"gemm_variant": 0, "attn_variant": 0, "ln_fused": 1, "attn_f32_split": 1, "gemm_f32_split": 1,
                 "pad_rows": 0, "f32_split_guard": 1, "gemm_v1_only": 0, "sim_op": 0, "gemm_f32_mx": 1, "attn_f32_mx": 1,
-                "attn_f32_pv": 0, "f32_drop": 0, "gemm_small_tile": 0}
+                "attn_f32_pv": 0, "f32_drop": 0, "gemm_small_tile": 0, "gemm_qkv_pair": 1}
     for name, value in defaults.items():
         RadZeroModel.set_option(name, value)
     with pytest.raises(ValueError):

@@ -91,6 +91,15 @@ hipError_t launch_gemm(int dtype, int epi, const GemmArgs& g, hipStream_t) {
     gemm_ranges(dtype, epi, g, esz(dtype));
     return hipSuccess;
 }
+bool gemm_pair_ok(int dtype, int epi_a, const GemmArgs& ga, int epi_b, const GemmArgs& gb) {
+    if (dtype == DT_F32 || !((epi_a == EPI_HEADS_LN && epi_b == EPI_VT_LN) || (epi_a == EPI_HEADS && epi_b == EPI_VT))) return false;
+    return ga.A == gb.A && ga.lda == gb.lda && ga.M == gb.M && ga.K == gb.K && ga.M > 0 && ga.M % 128 == 0 && ga.N % 128 == 0 && gb.N % 128 == 0;
+}
+hipError_t launch_gemm_pair(int dtype, int epi_a, const GemmArgs& ga, int epi_b, const GemmArgs& gb, hipStream_t s) {
+    if (!gemm_pair_ok(dtype, epi_a, ga, epi_b, gb)) return hipErrorInvalidValue;
+    hipError_t e = launch_gemm(dtype, epi_a, ga, s);
+    return e != hipSuccess ? e : launch_gemm(dtype, epi_b, gb, s);
+}
 // fp32 mode: f16 planes along K (g.K = 3 K), fp32 or hi/lo-split outputs (gemm.hip launch_gemm_split_f32out)
 hipError_t launch_gemm_split_f32out(int epi, const GemmArgs& g, hipStream_t s, bool split_out) {
     if (epi == EPI_RESID_SCALE || epi == EPI_RESID_ADD || epi == EPI_PATCH || epi == EPI_STORE_F32) return launch_gemm(DT_F16, epi, g, s);
