@@ -251,10 +251,11 @@ int rz_gemm_f32_split(int form, const float* a_dev, const float* w_dev, const fl
  *                      (two waves) from 40, 64x64 (one wave) below; up to 340 tiles two stages on 128x64; above, two stages on 128x128 (rounds 1-5
  *                      everywhere).  1 / 2 / 3 force 128x128 / 64x64 / 128x64, + 20 / + 40 force two / four stages (tests, A/B).  Same K order in
  *                      each: bit-identical outputs
- *   "gemm_qkv_pair"    16-bit modes: 1 (default) = the block's q|k and v projections as ONE launch of the 128x128 kernel family, rastered as one GEMM
- *                      of 3 D columns, where the persistent kernel's merged q|k|v projection does not apply (odd row counts) and, up to 448 tiles of
- *                      128x128 (one or two 518^2 images, up to eight 224^2 images), in front of it; 2 = in front of it wherever the pair applies
- *                      (A/B); 0 = two launches (rounds 1-5).  Same tiles, same arithmetic: same bits
+ *   "gemm_qkv_pair"    1 (default) = the block's q|k and v projections as ONE launch of the 128x128 kernel family, rastered as one GEMM of 3 D columns:
+ *                      16-bit modes — where the persistent kernel's merged q|k|v projection does not apply (odd row counts) and, up to 448 tiles of
+ *                      128x128 (one or two 518^2 images, up to eight 224^2 images), in front of it; fp32 mode (MX and three-plane forms, which have no
+ *                      merged projection) — wherever each of the two would take that family alone.  2 = wherever the shapes allow (A/B);
+ *                      0 = two launches (rounds 1-5).  Same tiles, same arithmetic: same bits
  *   "attn_variant"     0 default (16x16x32 MFMA, 4 waves x 32 query rows, row sums on the matrix pipe; bf16 without the running
  *                      maximum in the hot loop; round 6, bf16: 4 waves x 16 query rows — 64-row workgroups, same bits per row — where the grid
  *                      has fewer than 384 blocks of 128 rows, e.g. one 518^2 image) | 417 = the 128-row shape with the running maximum

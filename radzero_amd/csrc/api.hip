@@ -526,6 +526,35 @@ int gemm_f32_split(rz_model* m, int epi, GemmArgs g, int a_mode, bool out_split,
     return 0;
 }
 
+// fp32 mode, split forms: a block's q|k and v projections (A = the LayerNorm's planes, both outputs planes for the split attention) as ONE launch of the 128 x 128 family
+// where each would have taken that family alone (gemm.hip launch_gemm_pair_f32); *done = false: not applicable, the caller launches the two
+int gemm_f32_split_qkv_pair(rz_model* m, const void* xn, const DinoBlock& b, int M, int np, void* qk, void* vt, int mx, hipStream_t s, bool* done) {
+    *done = false;
+    const int D = m->D, H = m->H;
+    if (!m->o_gemm_qkv_pair() || m->o_f32_drop() != 0 || (mx & 4) || M % 128) return 0;
+    const rz_model::SplitW* e = nullptr;
+    for (const auto& c : m->split_w)
+        if ((const char*)b.wqkv.p == c.p) { e = &c; break; }
+    if (!e || (mx && !e->p4)) return 0;
+    GemmArgs ga, gb;
+    ga.A = xn; ga.M = M; ga.N = 2 * D; ga.bias = (const float*)b.bqkv.p; ga.out = qk; ga.ldo = 0; ga.scale = nullptr; ga.resid = nullptr; ga.ldr = 0;
+    ga.rows_per_image = np; ga.heads_total = 2 * H; ga.plane_off = (int64_t)M * 2 * D; ga.ovf_flag = (unsigned*)m->ovf.p; ga.run_if = m->run_if;
+    ga.variant = m->o_gemm_variant(); ga.small_tile = m->o_gemm_small_tile(); ga.raster = m->o_gemm_raster();
+    ga.mx_w_e8_hi = e->e8_hi; ga.mx_w_e8_lo = e->e8_hi - 11;
+    const int form = mx ? 1 : 0, v_kind = (mx & 2) ? 3 : 1;
+    if (mx) { ga.W = e->p4; ga.lda = ga.ldw = 2 * (int64_t)D; ga.K = 2 * D; }
+    else { ga.W = e->p3; ga.lda = ga.ldw = 3 * (int64_t)D; ga.K = 3 * D; }
+    gb = ga;
+    gb.W = (const char*)ga.W + (size_t)2 * D * (mx ? 4 : 6) * D;      // row 2 D of the split copy: 4 K (MX) / 6 K (three planes) bytes per row
+    gb.N = D; gb.bias = (const float*)b.bqkv.p + 2 * D; gb.out = vt; gb.heads_total = H; gb.plane_off = (int64_t)M * D;
+    if (pick(m->opt.gemm_qkv_pair, g_opt.gemm_qkv_pair) == 2 && ga.variant == 0) ga.variant = gb.variant = 1;      // A/B: the pair wherever the shapes allow
+    if (!gemm_pair_f32_ok(form, ga, gb, v_kind)) return 0;
+    ProfScope ps(m, RZ_PROF_GEMM, s);
+    RZ_HIP(launch_gemm_pair_f32(form, ga, gb, v_kind, s));
+    *done = true;
+    return 0;
+}
+
 // fp32 mode, text encoder (round 6): the MPNet GEMMs (EPI_STORE q|k|v, EPI_RESID_ADD o / fc2, EPI_GELU fc1) on the three-plane f16 form —
 // the weight's [hi | hi | lo] copy was built by rz_weights_ready; fp32 outputs, or planes again for fc1 (exact-erf GELU).
 // Plane overflows raise the TEXT guard word (ovf[5]): rz_text_forward repeats the encode on the exact kernels behind a predicate, as the vision forward does.
@@ -1114,9 +1143,13 @@ static int vision_forward_once(rz_handle_t m, const float* px, int B, int C, int
                 }
                 // q | k -> hi / lo planes of [Bc][2H][np][64]; V^T -> hi / lo planes of [Bc][H][64][np]
                 const char* wv = (const char*)b.wqkv.p + (size_t)2 * D * D * 4;
-                if ((rc = gemm(m, EPI_HEADS, xn, D, b.wqkv.p, D, M, 2 * D, D, (const float*)b.bqkv.p, qkb, 0, nullptr, nullptr, 0, np, 2 * H, s, A_SPLIT, true,
-                               (int64_t)M * 2 * D, mx))) return rc;
-                if ((rc = gemm(m, EPI_VT, xn, D, wv, D, M, D, D, (const float*)b.bqkv.p + 2 * D, vtb, 0, nullptr, nullptr, 0, np, H, s, A_SPLIT, true, (int64_t)M * D, mx))) return rc;
+                bool paired = false;
+                if ((rc = gemm_f32_split_qkv_pair(m, xn, b, M, np, qkb, vtb, mx, s, &paired))) return rc;
+                if (!paired) {
+                    if ((rc = gemm(m, EPI_HEADS, xn, D, b.wqkv.p, D, M, 2 * D, D, (const float*)b.bqkv.p, qkb, 0, nullptr, nullptr, 0, np, 2 * H, s, A_SPLIT, true,
+                                   (int64_t)M * 2 * D, mx))) return rc;
+                    if ((rc = gemm(m, EPI_VT, xn, D, wv, D, M, D, D, (const float*)b.bqkv.p + 2 * D, vtb, 0, nullptr, nullptr, 0, np, H, s, A_SPLIT, true, (int64_t)M * D, mx))) return rc;
+                }
             } else if (!fused) {
                 {
                     ProfScope ps(m, RZ_PROF_ROWOPS, s);

@@ -466,12 +466,12 @@ bool gemm_pair_ok(int dtype, int epi_a, const GemmArgs& ga, int epi_b, const Gem
     if (ga.variant == 1) return true;
     return ga.variant == 0 && !big_tiles_pay(ga, epi_a) && !big_tiles_pay(gb, epi_b);      // each would have gone to this family on its own
 }
-template <typename T, int EPIA, int EPIB, int S>
+template <typename T, int EPIA, int EPIB, int S, typename OTA = T, typename OTB = T, bool MXK = false>
 static void launch_pair_s(int st, const GemmArgs& ga, const GemmArgs& gb, hipStream_t s) {
     const int n = ga.N + gb.N;
-    if (st == 2) hipLaunchKernelGGL((gemm_pair_kernel<T, EPIA, EPIB, T, T, false, 1, 1, S>), dim3((ga.M / 64) * (n / 64)), dim3(64), 0, s, ga, gb);
-    else if (st == 3) hipLaunchKernelGGL((gemm_pair_kernel<T, EPIA, EPIB, T, T, false, 2, 1, S>), dim3((ga.M / 128) * (n / 64)), dim3(128), 0, s, ga, gb);
-    else hipLaunchKernelGGL((gemm_pair_kernel<T, EPIA, EPIB, T, T, false, 2, 2, S>), dim3((ga.M / BM) * (n / BN)), dim3(256), 0, s, ga, gb);
+    if (st == 2) hipLaunchKernelGGL((gemm_pair_kernel<T, EPIA, EPIB, OTA, OTB, MXK, 1, 1, S>), dim3((ga.M / 64) * (n / 64)), dim3(64), 0, s, ga, gb);
+    else if (st == 3) hipLaunchKernelGGL((gemm_pair_kernel<T, EPIA, EPIB, OTA, OTB, MXK, 2, 1, S>), dim3((ga.M / 128) * (n / 64)), dim3(128), 0, s, ga, gb);
+    else hipLaunchKernelGGL((gemm_pair_kernel<T, EPIA, EPIB, OTA, OTB, MXK, 2, 2, S>), dim3((ga.M / BM) * (n / BN)), dim3(256), 0, s, ga, gb);
 }
 template <typename T>
 static hipError_t launch_pair_t(int epi_a, const GemmArgs& ga, const GemmArgs& gb, hipStream_t s) {
@@ -485,6 +485,32 @@ static hipError_t launch_pair_t(int epi_a, const GemmArgs& ga, const GemmArgs& g
 hipError_t launch_gemm_pair(int dtype, int epi_a, const GemmArgs& ga, int epi_b, const GemmArgs& gb, hipStream_t s) {
     if (!gemm_pair_ok(dtype, epi_a, ga, epi_b, gb)) return hipErrorInvalidValue;
     return dtype == DT_BF16 ? launch_pair_t<bf16_t>(epi_a, ga, gb, s) : launch_pair_t<f16_t>(epi_a, ga, gb, s);
+}
+
+// fp32 mode: the same pair for its split forms (both outputs leave as planes: the split attention's operands).  form 0 = three f16 planes along K (ga / gb as for
+// launch_gemm_split_f32out: K = 3 K), form 1 = MX (as for launch_gemm_small_mx: K = 2 K); v_kind = output form of the V^T GEMM: 1 hi / lo f16 planes, 3 hi f16 + e4m3 pair plane
+bool gemm_pair_f32_ok(int form, const GemmArgs& ga, const GemmArgs& gb, int v_kind) {
+    if (ga.A != gb.A || ga.lda != gb.lda || ga.M != gb.M || ga.K != gb.K || ga.variant != gb.variant || ga.small_tile != gb.small_tile) return false;
+    if (ga.M <= 0 || ga.M % BM || ga.N <= 0 || ga.N % BN || gb.N <= 0 || gb.N % BN || (ga.K * 2) % 128 || (ga.lda * 2) % 16 || (ga.ldw * 2) % 16 || (gb.ldw * 2) % 16) return false;
+    if (ga.variant != 0 && ga.variant != 1) return false;
+    if (form == 1) {
+        if (!(v_kind == 1 || v_kind == 3) || !gemm_small_mx_ok(EPI_HEADS, 1, ga) || !gemm_small_mx_ok(EPI_VT, v_kind, gb)) return false;
+        return ga.variant == 1 || (gemm_small_mx_pays(EPI_HEADS, ga) && gemm_small_mx_pays(EPI_VT, gb));
+    }
+    return form == 0 && v_kind == 1 && (ga.variant == 1 || (!big_tiles_pay(ga, EPI_HEADS) && !big_tiles_pay(gb, EPI_VT)));
+}
+hipError_t launch_gemm_pair_f32(int form, const GemmArgs& ga, const GemmArgs& gb, int v_kind, hipStream_t s) {
+    if (!gemm_pair_f32_ok(form, ga, gb, v_kind)) return hipErrorInvalidValue;
+    GemmArgs whole = ga;
+    whole.N = ga.N + gb.N;
+    const int st = small_tile_choice(whole), S = small_stages_choice(whole, st);
+#define RZ_PAIR(OTB, MXKV) do { if (S == 4) launch_pair_s<f16_t, EPI_HEADS, EPI_VT, 4, split_f16, OTB, MXKV>(st, ga, gb, s); \
+                                 else launch_pair_s<f16_t, EPI_HEADS, EPI_VT, 2, split_f16, OTB, MXKV>(st, ga, gb, s); } while (0)
+    if (form == 0) RZ_PAIR(split_f16, false);
+    else if (v_kind == 3) RZ_PAIR(split_mxa, true);
+    else RZ_PAIR(split_f16, true);
+#undef RZ_PAIR
+    return hipGetLastError();
 }
 
 // fp32 mode on the f16 matrix pipe.  The caller has split both operands into f16 planes laid side by side along K:

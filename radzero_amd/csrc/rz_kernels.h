@@ -64,6 +64,10 @@ bool gemm_qkv_fused_ok(int dtype, const GemmArgs& g);
 // where each of the two would have gone to that family on its own; same bits as the two launches
 bool gemm_pair_ok(int dtype, int epi_a, const GemmArgs& ga, int epi_b, const GemmArgs& gb);
 hipError_t launch_gemm_pair(int dtype, int epi_a, const GemmArgs& ga, int epi_b, const GemmArgs& gb, hipStream_t s);
+// fp32 mode's split forms of the same pair (EPI_HEADS -> hi / lo f16 planes, EPI_VT -> v_kind 1 hi / lo f16 planes | 3 hi f16 + e4m3 pair plane): form 0 = three f16 planes
+// along K (operands as for launch_gemm_split_f32out), 1 = MX (as for launch_gemm_small_mx)
+bool gemm_pair_f32_ok(int form, const GemmArgs& ga, const GemmArgs& gb, int v_kind);
+hipError_t launch_gemm_pair_f32(int form, const GemmArgs& ga, const GemmArgs& gb, int v_kind, hipStream_t s);
 bool gemm_patch_ln_ok(int dtype, const GemmArgs& g);                  // may the patch-embedding GEMM write block 0's LayerNorm inputs itself (EPI_PATCH_LN)
 bool gemm_ln_fused_ok(int dtype, int M, int D, int F, int variant);   // may a Dinov2 block of M token rows use the fused-LayerNorm epilogues
 // fp32 mode on the f16 matrix pipe: operands split into f16 planes along K (gemm.hip)

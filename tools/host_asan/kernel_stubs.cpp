@@ -100,6 +100,8 @@ hipError_t launch_gemm_pair(int dtype, int epi_a, const GemmArgs& ga, int epi_b,
     hipError_t e = launch_gemm(dtype, epi_a, ga, s);
     return e != hipSuccess ? e : launch_gemm(dtype, epi_b, gb, s);
 }
+bool gemm_pair_f32_ok(int, const GemmArgs&, const GemmArgs&, int) { return false; }      // the host build runs the two launches (same accesses)
+hipError_t launch_gemm_pair_f32(int, const GemmArgs&, const GemmArgs&, int, hipStream_t) { return hipErrorInvalidValue; }
 // fp32 mode: f16 planes along K (g.K = 3 K), fp32 or hi/lo-split outputs (gemm.hip launch_gemm_split_f32out)
 hipError_t launch_gemm_split_f32out(int epi, const GemmArgs& g, hipStream_t s, bool split_out) {
     if (epi == EPI_RESID_SCALE || epi == EPI_RESID_ADD || epi == EPI_PATCH || epi == EPI_STORE_F32) return launch_gemm(DT_F16, epi, g, s);
