@@ -7,10 +7,10 @@
 // :342-380; TF:mpnet/modeling_mpnet.py:131-171,:204-231; the patch-embedding conv
 // TF:dinov2/modeling_dinov2.py:139-148 as an im2col GEMM.
 //
-// Structure (v1): 128x128 output tile, 4 waves (2x2, 64x64 each = 4x4 MFMA 16x16 tiles), K panel of
-// 128 bytes per step (64 x 16-bit or 32 x f32), two LDS stages filled by global_load_lds_dwordx4 with
-// the panel XOR swizzle of rz_common.h.  M must be a multiple of 128 (callers pad rows per image),
-// N a multiple of 128, K*sizeof(T) a multiple of 128.
+// Structure (v1, the "128x128 family"): every wave owns a 64x64 output block (4x4 MFMA 16x16 tiles); a workgroup is 2x2 waves (128x128 tile), 2x1 (128x64) or 1x1 (64x64);
+// K panels of 128 bytes per step (64 x 16-bit or 32 x f32) in an LDS ring of two or four stages filled by global_load_lds_dwordx4 with the panel XOR swizzle of
+// rz_common.h (four stages: three panel pairs in flight behind a counted vmcnt + bare s_barrier; round 6, small grids).  M must be a multiple of 128 (callers pad rows
+// per image), N a multiple of 128, K*sizeof(T) a multiple of 128.  gemm_pair_kernel runs two GEMMs over the same rows (a block's q|k and v projections) as one launch.
 // fp32 mode: launch_gemm_split_f32out — the f16 kernels over hi/lo-split operands laid side by side along K (three MFMAs per product).
 #include <cstring>
 
