@@ -65,3 +65,20 @@ def test_ring_waits_are_counted_and_sit_in_front_of_the_barrier(code_objects, sy
             assert m, f"{symbol}: s_barrier at {i} behind '{ins[i - 1]}', not behind the ring's own wait"
             seen.add(int(m.group(1)))
     assert seen == {0, nper, 2 * nper}, f"{symbol}: vmcnt immediates {sorted(seen)}, expected 0 / {nper} / {2 * nper} (three panel pairs in flight)"
+
+
+@pytest.mark.parametrize("symbol", ["_ZN2rz14gemm_kernel_v8IDF16bLi10ELb0ELb0ELin1EEEvNS_8GemmArgsE",       # bf16 fc1 (EPI_GELU_LN)
+                                    "_ZN2rz14gemm_kernel_v8IDF16bLi9ELb0ELb0ELin1EEEvNS_8GemmArgsE",        # bf16 out-projection / fc2 (EPI_RESID_SCALE_LN)
+                                    "_ZN2rz14gemm_kernel_v8IDF16bLi1ELb0ELb0ELin1EEEvNS_8GemmArgsE"])       # bf16 fc1, plain GELU epilogue
+def test_persistent_gemm_loop_has_only_its_counted_waits(code_objects, symbol):
+    """The headline GEMM kernel (gemm8.hip): between its first and last MFMA — the staggered K loop and the epilogue that runs under the next tile's loop — every vector-memory
+    wait is one of the counted ones the schedule was built on; a `vmcnt(0)` there (a fence, a compiler-inserted wait in front of an LDS read) would drain the operand ring once per
+    phase.  Round 6 found exactly that kind of wait elsewhere twice; this pins the kernel that the headline number rests on."""
+    ins = disassemble(code_objects, symbol)
+    assert ins is not None, f"{symbol} not in the library (instantiation renamed? update the list)"
+    mfma = [i for i, x in enumerate(ins) if x.startswith("v_mfma")]
+    span = ins[mfma[0]:mfma[-1] + 1]
+    waits = [x for x in span if re.match(r"s_waitcnt .*vmcnt\(\d+\)", x)]
+    assert len(mfma) >= 128 and sum(x.startswith("s_barrier") for x in span) >= 8 and len(waits) >= 4, "not the K loop this test was written for"
+    drained = [x for x in waits if "vmcnt(0)" in x]
+    assert not drained, f"{symbol}: {len(drained)} x '{drained[0]}' inside the K loop"
