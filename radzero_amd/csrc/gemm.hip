@@ -351,10 +351,19 @@ bool gemm_ln_fused_ok(int dtype, int M, int D, int F, int variant) {
 //             64 x 64 below (224^2 x 2, 36: 44.2 -> 37.1; the text encoder);
 //   n <= 340  two or three workgroups per CU hide the latency instead: two stages, 128 x 64 (fc2 of four 518^2 images, 264: 61.2 -> 54.6 us; the deep rings 77-108);
 //   above     two stages, 128 x 128 (smaller tiles only add operand bytes through each XCD's L2: 396 tiles -16 % in the step).
+// CUs of the device (the thresholds below were measured on 256: a partitioned or smaller part scales them)
+static int cu_count() {
+    static int cus = 0;
+    if (cus == 0) {
+        int dev = 0, n = 0;
+        cus = (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n >= 8) ? n : 256;
+    }
+    return cus;
+}
 static int small_tile_choice(const GemmArgs& g) {
     const int forced = g.small_tile % 10;
     if (forced) return forced;
-    const int n = (g.M / BM) * (g.N / BN);
+    const int64_t n = (int64_t)(g.M / BM) * (g.N / BN) * 256 / cu_count();      // tiles, in units of a 256-CU chip
     if (n <= 256) return n > 96 ? 1 : n >= 40 ? 3 : 2;
     return n <= 340 ? 3 : 1;
 }
@@ -363,7 +372,7 @@ static int small_stages_choice(const GemmArgs& g, int st) {
     if (forced == 2 || forced == 4) return forced;
     const int wgs = st == 2 ? (g.M / 64) * (g.N / 64) : st == 3 ? (g.M / 128) * (g.N / 64) : (g.M / 128) * (g.N / 128);
     const int kb = st == 2 ? 16 : st == 3 ? 24 : 32;      // LDS per stage: the deep ring only where every workgroup is resident at once
-    return wgs <= 256 * (160 / (kb * 4)) ? 4 : 2;
+    return wgs <= cu_count() * (160 / (kb * 4)) ? 4 : 2;
 }
 
 template <typename T, int EPI, typename OT, bool MXK, int S>
